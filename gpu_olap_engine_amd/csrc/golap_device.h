@@ -1,0 +1,127 @@
+// golap_device.h -- device-side helpers shared by the gfx950 kernels (wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace golap {
+
+// join_kernels.cuh:26-35  MurmurHash3 32-bit finalizer.
+__device__ __forceinline__ uint32_t hash_int32(int32_t key) {
+    uint32_t h = (uint32_t)key;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// join_kernels.cuh:37-41  fold hi^lo then fmix32.
+__device__ __forceinline__ uint32_t hash_int64(long long key) {
+    uint32_t h = (uint32_t)(key ^ (key >> 32));
+    return hash_int32((int32_t)h);
+}
+
+// Table-slot hash for the LDS / broadcast tables.  Deliberately independent of
+// hash_int64: the reference's fold makes every key i<<32 collide,
+// and all rows of one sub-partition share their low hash bits anyway.  Results
+// do not depend on it (probe compares full keys, join_kernels.cuh:152-153).
+__device__ __forceinline__ uint32_t slot_hash(long long key, uint32_t log2_slots) {
+    return (uint32_t)(((unsigned long long)key * 0x9E3779B97F4A7C15ull) >> (64u - log2_slots));
+}
+
+// splitmix64 finalizer of seed + i*golden  (SURVEY 8(d) generators)
+__device__ __host__ __forceinline__ unsigned long long sm64(unsigned long long seed, unsigned long long i) {
+    unsigned long long z = seed + i * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __host__ __forceinline__ unsigned long long pair_mix(uint32_t b, uint32_t p) {
+    unsigned long long z = (((unsigned long long)p << 32) | b) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---- wave64 primitives ------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_reduce_add64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_addf(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_minf(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_maxf(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// Exclusive prefix of `v` over the lanes of a wave + wave total.  Fast path for
+// the 0/1 case (match flags): wavefront ballot + mbcnt, no shuffles.
+__device__ __forceinline__ uint32_t wave_exclusive_count(uint32_t v, uint32_t& total) {
+    unsigned long long big = __ballot(v > 1u);
+    if (big == 0ull) {
+        unsigned long long m = __ballot(v != 0u);
+        total = (uint32_t)__popcll(m);
+        return mbcnt(m);
+    }
+    uint32_t inc = wave_inclusive_scan(v);
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
+// ---- partition pass configuration ------------------------------------------
+struct PassCfg {
+    uint32_t shift;        // hash bits consumed by earlier passes
+    uint32_t F;            // fan-out of this pass (power of two, <= 1024)
+    uint32_t S;            // chunk slots per group
+    uint32_t mode;         // 0: bucket = (h >> shift) & (F-1)
+                           // 1: first pass: reference partition p = h & 255 (join_kernels.cuh:69) laid out
+                           //    owner-major, refined by e1 further hash bits
+    uint32_t e1;           // extra bits of the first pass (F = 256 << e1)
+    uint32_t owners_log2;  // log2(n_owners)
+};
+
+__device__ __forceinline__ uint32_t bucket_of(uint32_t h, const PassCfg& c) {
+    if (c.mode == 0) return (h >> c.shift) & (c.F - 1u);
+    const uint32_t p = h & 255u;                                   // join_kernels.cuh:69, radix_shift = 0
+    const uint32_t sub = (h >> 8) & ((1u << c.e1) - 1u);
+    const uint32_t slot = ((p & ((1u << c.owners_log2) - 1u)) << (8u - c.owners_log2)) | (p >> c.owners_log2);
+    return (slot << c.e1) | sub;
+}
+
+}  // namespace golap

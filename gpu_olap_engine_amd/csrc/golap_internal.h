@@ -1,0 +1,160 @@
+// golap_internal.h -- host-side internals shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/golap.h"
+
+namespace golap {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+void set_thread_error(const char* msg);
+int32_t fail(golap_ctx* ctx, int32_t code, const char* fmt, ...);
+
+#define GOLAP_HIP_TRY(ctx, expr)                                                                 \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return ::golap::fail((ctx), GOLAP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);                     \
+    } while (0)
+
+#define GOLAP_TRY(expr)                          \
+    do {                                         \
+        int32_t _s = (expr);                     \
+        if (_s != GOLAP_OK) return _s;           \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// SlabAllocator (gpu-memory-manager/src/slab_allocator.rs)
+// ---------------------------------------------------------------------------
+struct SlabClass {
+    uint64_t size = 0;
+    std::deque<uint64_t> free_slabs;   // slab_allocator.rs:19
+    uint32_t max_slabs = 0;            // :20
+    uint32_t allocated_count = 0;      // :21
+};
+
+struct SlabAllocator {
+    std::mutex mu;
+    std::vector<SlabClass> classes;
+    uint64_t bytes_reserved = 0;
+    uint64_t max_bytes = 0;            // EngineConfig::max_gpu_memory (0 = uncapped)
+    void init(uint64_t max_bytes, uint32_t max_slabs_per_class);
+    int32_t allocate(golap_ctx* ctx, uint64_t size, uint64_t* ptr, uint32_t* cls);
+    int32_t release(golap_ctx* ctx, uint64_t ptr, uint32_t cls);
+    void destroy();
+};
+
+// ---------------------------------------------------------------------------
+// TransferQueue (gpu-memory-manager/src/transfer_queue.rs)
+// ---------------------------------------------------------------------------
+struct XferStream {
+    hipStream_t stream = nullptr;
+    void* bounce[2] = {nullptr, nullptr};   // pinned double buffer for pageable host memory
+    hipEvent_t bounce_free[2] = {nullptr, nullptr};
+    uint32_t next_bounce = 0;
+    std::mutex mu;                           // transfer_queue.rs:29 (Mutex per stream)
+};
+
+struct TransferQueue {
+    std::vector<XferStream*> streams;
+    uint64_t bounce_bytes = 0;
+    int32_t init(golap_ctx* ctx, uint32_t num_streams);
+    int32_t enqueue(golap_ctx* ctx, int32_t direction, uint64_t src, uint64_t dst, uint64_t size, uint32_t stream_id);
+    int32_t synchronize(golap_ctx* ctx);
+    void destroy();
+};
+
+// ---------------------------------------------------------------------------
+// profiling: hipEvent pairs on the launch stream, resolved lazily
+// ---------------------------------------------------------------------------
+struct PendingEvent {
+    uint32_t stat;
+    hipEvent_t start, stop;
+};
+
+struct Profiler {
+    bool enabled = false;
+    std::vector<golap_kernel_stat> stats;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> pool;
+    uint32_t stat_index(const char* name);
+    hipEvent_t get_event();
+    void resolve();
+    void destroy();
+};
+
+// Workspace: one slab, bump-allocated per call, cached in the context.
+struct Workspace {
+    uint64_t base = 0, size = 0, used = 0;
+    uint32_t cls = 0;
+};
+
+}  // namespace golap
+
+struct golap_ctx {
+    golap_engine_config cfg;
+    int device = 0;
+    hipDeviceProp_t prop;
+    hipStream_t stream = nullptr;     // the context's own stream
+    std::mutex mu;                    // serialises compute calls on one context (SURVEY 8(b) threading)
+    std::string err;
+    golap::SlabAllocator slabs;
+    golap::TransferQueue xfer;
+    golap::Profiler prof;
+    golap::Workspace ws;
+    hipEvent_t ws_done = nullptr;     // last use of the workspace (cross-stream ordering)
+    hipStream_t ws_stream = nullptr;
+    std::vector<void*> pinned_small;  // small pinned host staging buffers for table uploads
+};
+
+namespace golap {
+
+// RAII kernel timer: records start now, stop at scope exit (when profiling is on).
+struct KernelTimer {
+    golap_ctx* ctx;
+    hipStream_t st;
+    PendingEvent ev;
+    bool on;
+    KernelTimer(golap_ctx* c, const char* name, hipStream_t s, uint64_t bytes = 0) : ctx(c), st(s), on(c->prof.enabled) {
+        if (!on) return;
+        ev.stat = c->prof.stat_index(name);
+        c->prof.stats[ev.stat].launches += 1;
+        c->prof.stats[ev.stat].bytes += bytes;
+        ev.start = c->prof.get_event();
+        ev.stop = c->prof.get_event();
+        (void)hipEventRecord(ev.start, st);
+    }
+    ~KernelTimer() {
+        if (!on) return;
+        (void)hipEventRecord(ev.stop, st);
+        ctx->prof.pending.push_back(ev);
+    }
+};
+
+inline hipStream_t pick_stream(golap_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+// workspace helpers (call with ctx->mu held)
+int32_t ws_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st);
+uint64_t ws_take(golap_ctx* ctx, uint64_t bytes);   // 256-B aligned bump; returns 0 when exhausted
+void ws_end(golap_ctx* ctx, hipStream_t st);
+
+// in-place exclusive scan of n u32 values (n <= 16.7M); block_sums needs ceil(n/4096)+1 u32 (golap_join.hip)
+int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums);
+constexpr uint32_t FLAT_SCAN_BLOCK = 4096;
+
+static inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+static inline uint64_t ceil_div(uint64_t x, uint64_t a) { return (x + a - 1) / a; }
+
+}  // namespace golap

@@ -1,0 +1,1001 @@
+// golap_join.hip -- GpuHashJoin on gfx950: multi-pass LDS-staged radix partitioning
+// followed by per-sub-partition chained hash tables held in LDS.
+//
+// Reference arithmetic restated (paths relative to the reference root):
+//   hash            gpu-kernel-compiler/kernels/join_kernels.cuh:26-41
+//   radix partition join_kernels.cuh:45-76   (partition = (hash >> shift) & 255)
+//   build           join_kernels.cuh:80-111  (chained table, head swap by atomic exchange)
+//   probe           join_kernels.cuh:115-166 (walk chain, full-key compare, emit (build_rid, probe_rid))
+// What is new (MI355X-first, none of it is in the reference):
+//   * the per-row global atomicAdd of :72 is replaced by histogram -> flat exclusive
+//     scan -> LDS-staged scatter (rows are regrouped by bucket inside a 4096-row LDS
+//     tile, then written as contiguous runs), one work-group per chunk of tiles so
+//     the frontier cache lines of every bucket are completed by the same CU / L2;
+//   * partitioning is applied repeatedly (radix_shift, :53, is the hook the reference
+//     leaves for that) until a sub-partition's build side fits a 4096-row LDS table;
+//   * build/probe run on LDS tables (ds atomics), matches are counted first, the
+//     output range is reserved with ONE global atomic per work-group batch and the
+//     pairs are written with wavefront ballot/prefix compaction -- not one global
+//     atomic per match (:155).
+#include "golap_device.h"
+#include "golap_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace golap {
+
+// ---------------------------------------------------------------------------
+// constants
+// ---------------------------------------------------------------------------
+constexpr int PT_THREADS = 512;            // 8 waves
+constexpr int PT_RPT = 8;                  // rows per thread per tile
+constexpr int PT_TILE = PT_THREADS * PT_RPT;   // 4096 rows staged in LDS (48 KiB)
+constexpr int PT_MAX_F = 1024;             // max fan-out per pass (10 bits)
+constexpr int PT_WAVES = PT_THREADS / 64;
+
+constexpr int JN_THREADS = 512;
+constexpr int JN_WAVES = JN_THREADS / 64;
+constexpr int JN_CAP = 4096;               // build rows per LDS table
+constexpr int JN_LOG2_SLOTS = 12;          // 4096 chain heads
+constexpr int JN_R = 8;                    // probe rows per thread per batch
+constexpr uint32_t JN_EMPTY = 0xFFFFFFFFu; // join_kernels.cuh:146 sentinel
+static_assert(JN_R * JN_WAVES == 64, "slice x wave totals are scanned by one wave");
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_EPT = 16;
+constexpr int SC_ELEMS = SC_THREADS * SC_EPT;   // 4096 elements per scan block
+
+// ---------------------------------------------------------------------------
+// chunk descriptors
+// ---------------------------------------------------------------------------
+__global__ void k_setup_uniform(uint32_t n, uint32_t chunk_rows, uint32_t n_chunks, uint32_t* __restrict__ chunk_off,
+                                uint32_t* __restrict__ chunk_len) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    unsigned long long o = (unsigned long long)c * chunk_rows;
+    uint32_t off = o < n ? (uint32_t)o : n;
+    uint32_t len = n - off < chunk_rows ? n - off : chunk_rows;
+    chunk_off[c] = off;
+    chunk_len[c] = len;
+}
+
+// groups of this pass = (group, bucket) pairs of the previous pass: group g spans
+// [prev[g*prev_stride], prev[(g+1)*prev_stride]) in the previous pass's output.
+__global__ void k_setup_from_scan(const uint32_t* __restrict__ prev, uint32_t prev_stride, uint32_t n_groups, uint32_t S,
+                                  uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_len) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * S) return;
+    uint32_t g = i / S, s = i % S;
+    uint32_t start = prev[(size_t)g * prev_stride], end = prev[(size_t)(g + 1) * prev_stride];
+    uint32_t len = end - start;
+    uint32_t cr = (len + S - 1) / S;
+    cr = (cr + PT_TILE - 1) / PT_TILE * PT_TILE;
+    unsigned long long o = (unsigned long long)s * cr;
+    uint32_t off = o < len ? (uint32_t)o : len;
+    uint32_t l = len - off < cr ? len - off : cr;
+    chunk_off[i] = start + off;
+    chunk_len[i] = l;
+}
+
+// groups = local partition slots, each fed by n_src source segments (after the
+// partition exchange).  slot s = src * cps + c.
+__global__ void k_setup_from_segments(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_len, uint32_t n_groups,
+                                      uint32_t n_src, uint32_t cps, uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_len) {
+    uint32_t S = n_src * cps;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * S) return;
+    uint32_t g = i / S, s = i % S, src = s / cps, c = s % cps;
+    uint32_t start = seg_off[g * n_src + src], len = seg_len[g * n_src + src];
+    uint32_t cr = (len + cps - 1) / cps;
+    cr = (cr + PT_TILE - 1) / PT_TILE * PT_TILE;
+    unsigned long long o = (unsigned long long)c * cr;
+    uint32_t off = o < len ? (uint32_t)o : len;
+    uint32_t l = len - off < cr ? len - off : cr;
+    chunk_off[i] = start + off;
+    chunk_len[i] = l;
+}
+
+// ---------------------------------------------------------------------------
+// histogram: one work-group per chunk, LDS-staged counters (ds_add_u32), written
+// bucket-major so that ONE flat exclusive scan yields every output position.
+//   hist[(g*F + f)*S + s]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_THREADS) void k_hist(const long long* __restrict__ in_keys, const uint32_t* __restrict__ chunk_off,
+                                                     const uint32_t* __restrict__ chunk_len, uint32_t* __restrict__ hist, PassCfg cfg) {
+    __shared__ uint32_t s_cnt[PT_MAX_F];
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t len = chunk_len[chunk];
+    if (len == 0) return;   // hist is pre-zeroed
+    const uint32_t off = chunk_off[chunk];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t f = tid; f < cfg.F; f += PT_THREADS) s_cnt[f] = 0;
+    __syncthreads();
+    const long long* __restrict__ k = in_keys + off;
+    uint32_t i = tid;
+    // 8 independent loads in flight per thread
+    for (; i + 7 * PT_THREADS < len; i += 8 * PT_THREADS) {
+        long long v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = k[i + r * PT_THREADS];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) atomicAdd(&s_cnt[bucket_of(hash_int64(v[r]), cfg)], 1u);
+    }
+    for (; i < len; i += PT_THREADS) atomicAdd(&s_cnt[bucket_of(hash_int64(k[i]), cfg)], 1u);
+    __syncthreads();
+    const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
+    for (uint32_t f = tid; f < cfg.F; f += PT_THREADS) hist[((size_t)g * cfg.F + f) * cfg.S + s] = s_cnt[f];
+}
+
+// ---------------------------------------------------------------------------
+// flat exclusive scan (u32), 3 kernels, in place.  n_blocks <= SC_ELEMS.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* s_w /*[4]*/, uint32_t& total) {
+    // 256 threads = 4 waves
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, t = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t x = s_w[i];
+        if ((uint32_t)i < w) base += x;
+        t += x;
+    }
+    total = t;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_scan_reduce(const uint32_t* __restrict__ a, uint32_t n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t base = blockIdx.x * SC_ELEMS;
+    uint32_t v = 0;
+#pragma unroll
+    for (int e = 0; e < SC_EPT; ++e) {
+        uint32_t i = base + e * SC_THREADS + threadIdx.x;
+        v += i < n ? a[i] : 0u;
+    }
+    v = wave_reduce_add(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_scan_top(uint32_t* __restrict__ block_sums, uint32_t n_blocks) {
+    __shared__ uint32_t s_w[4];
+    // each thread owns SC_EPT consecutive block sums
+    uint32_t v[SC_EPT], sum = 0;
+#pragma unroll
+    for (int e = 0; e < SC_EPT; ++e) {
+        uint32_t i = threadIdx.x * SC_EPT + e;
+        v[e] = i < n_blocks ? block_sums[i] : 0u;
+        sum += v[e];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan_256(sum, s_w, total);
+#pragma unroll
+    for (int e = 0; e < SC_EPT; ++e) {
+        uint32_t i = threadIdx.x * SC_EPT + e;
+        if (i < n_blocks) block_sums[i] = run;
+        run += v[e];
+    }
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_scan_down(uint32_t* __restrict__ a, uint32_t n, const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t base = blockIdx.x * SC_ELEMS + threadIdx.x * SC_EPT;   // thread owns SC_EPT consecutive elements
+    uint32_t v[SC_EPT], sum = 0;
+#pragma unroll
+    for (int e = 0; e < SC_EPT; ++e) {
+        uint32_t i = base + e;
+        v[e] = i < n ? a[i] : 0u;
+        sum += v[e];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan_256(sum, s_w, total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int e = 0; e < SC_EPT; ++e) {
+        uint32_t i = base + e;
+        if (i < n) a[i] = run;
+        run += v[e];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scatter: one work-group per chunk.  Per 4096-row tile:
+//   load keys (+row ids) -> bucket + rank by returning LDS atomic -> exclusive
+//   scan of the tile's bucket counts -> regroup rows by bucket in LDS ->
+//   write each bucket's run contiguously at its running global cursor.
+// Replaces join_kernels.cuh:72-75 (per-row global atomicAdd + scattered 8/4-byte stores).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restrict__ in_keys, const uint32_t* __restrict__ in_rids,
+                                                        uint32_t rid_base, const uint32_t* __restrict__ chunk_off,
+                                                        const uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ scanned,
+                                                        long long* __restrict__ out_keys, uint32_t* __restrict__ out_rids, PassCfg cfg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    long long* s_keys = reinterpret_cast<long long*>(s_raw);                       // [PT_TILE]
+    uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + PT_TILE * 8);           // [PT_TILE]
+    uint32_t* s_cnt = s_rids + PT_TILE;                                            // [F]
+    uint32_t* s_start = s_cnt + cfg.F;                                             // [F]
+    uint32_t* s_gpos = s_start + cfg.F;                                            // [F]
+    uint32_t* s_w = s_gpos + cfg.F;                                                // [PT_WAVES]
+
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t len = chunk_len[chunk];
+    if (len == 0) return;
+    const uint32_t off = chunk_off[chunk];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t F = cfg.F;
+    {
+        const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
+        for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] = scanned[((size_t)g * F + f) * cfg.S + s];
+    }
+    for (uint32_t t0 = 0; t0 < len; t0 += PT_TILE) {
+        const uint32_t tn = len - t0 < (uint32_t)PT_TILE ? len - t0 : (uint32_t)PT_TILE;
+        const uint32_t rbase = off + t0;
+        for (uint32_t f = tid; f < F; f += PT_THREADS) s_cnt[f] = 0;
+        long long key[PT_RPT];
+        uint32_t rid[PT_RPT], br[PT_RPT];
+#pragma unroll
+        for (int r = 0; r < PT_RPT; ++r) {
+            const uint32_t i = r * PT_THREADS + tid;
+            key[r] = i < tn ? in_keys[rbase + i] : 0;
+        }
+        if (in_rids) {
+#pragma unroll
+            for (int r = 0; r < PT_RPT; ++r) {
+                const uint32_t i = r * PT_THREADS + tid;
+                rid[r] = i < tn ? in_rids[rbase + i] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PT_RPT; ++r) rid[r] = rid_base + rbase + r * PT_THREADS + tid;   // join_kernels.cuh:75
+        }
+        __syncthreads();   // s_cnt zeroed, s_gpos visible
+#pragma unroll
+        for (int r = 0; r < PT_RPT; ++r) {
+            const uint32_t i = r * PT_THREADS + tid;
+            if (i < tn) {
+                const uint32_t b = bucket_of(hash_int64(key[r]), cfg);
+                const uint32_t rank = atomicAdd(&s_cnt[b], 1u);
+                br[r] = (b << 16) | rank;   // b < 1024, rank < 4096
+            }
+        }
+        __syncthreads();
+        // exclusive scan of s_cnt[0..F) -> s_start ; F <= 1024 = 2 entries per thread
+        {
+            const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
+            const uint32_t c0 = f0 < F ? s_cnt[f0] : 0u, c1 = f1 < F ? s_cnt[f1] : 0u;
+            const uint32_t inc = wave_inclusive_scan(c0 + c1);
+            if (lane == 63) s_w[wv] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < PT_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            const uint32_t e0 = base + inc - (c0 + c1);
+            if (f0 < F) s_start[f0] = e0;
+            if (f1 < F) s_start[f1] = e0 + c0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PT_RPT; ++r) {
+            const uint32_t i = r * PT_THREADS + tid;
+            if (i < tn) {
+                const uint32_t pos = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
+                s_keys[pos] = key[r];
+                s_rids[pos] = rid[r];
+            }
+        }
+        __syncthreads();
+        // contiguous runs out: consecutive threads -> consecutive LDS slots -> (mostly) consecutive addresses
+#pragma unroll
+        for (int r = 0; r < PT_RPT; ++r) {
+            const uint32_t i = r * PT_THREADS + tid;
+            if (i < tn) {
+                const long long k = s_keys[i];
+                const uint32_t b = bucket_of(hash_int64(k), cfg);
+                const uint32_t gp = s_gpos[b] + (i - s_start[b]);
+                out_keys[gp] = k;
+                out_rids[gp] = s_rids[i];
+            }
+        }
+        __syncthreads();
+        for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] += s_cnt[f];
+        // the zeroing of s_cnt at the top of the next tile is ordered by the barrier there;
+        // s_cnt is read here by the same thread that zeroes it (same f stride), so no hazard.
+    }
+}
+
+// ---------------------------------------------------------------------------
+// join of one sub-partition per work-group, table in LDS.
+//   table: t_keys[CAP] (8 B), t_rids[CAP] (4 B), t_next[CAP] (u16), heads[4096] (u32)  = 72 KiB
+// build  = join_kernels.cuh:89-110 with LDS ds_wrxchg instead of a global atomicExch
+// probe  = join_kernels.cuh:129-165; emission: count -> one global atomic per batch -> compacted stores
+// ---------------------------------------------------------------------------
+struct JoinSide {
+    const long long* keys;
+    const uint32_t* rids;
+    const uint32_t* off;   // sub-partition sp spans [off[sp*stride], off[(sp+1)*stride])
+    uint32_t stride;
+};
+
+__global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
+                                                         unsigned long long* __restrict__ out_count, unsigned long long max_pairs) {
+    __shared__ long long t_keys[JN_CAP];
+    __shared__ uint32_t t_rids[JN_CAP];
+    __shared__ uint32_t heads[1 << JN_LOG2_SLOTS];
+    __shared__ uint16_t t_next[JN_CAP];
+    __shared__ uint32_t s_wt[JN_R * JN_WAVES];
+    __shared__ unsigned long long s_base;
+
+    const uint32_t sp = blockIdx.x;
+    const uint32_t b0 = B.off[(size_t)sp * B.stride], b1 = B.off[(size_t)(sp + 1) * B.stride];
+    const uint32_t p0 = P.off[(size_t)sp * P.stride], p1 = P.off[(size_t)(sp + 1) * P.stride];
+    if (b1 == b0 || p1 == p0) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    for (uint32_t bc = b0; bc < b1; bc += JN_CAP) {
+        const uint32_t nb = b1 - bc < (uint32_t)JN_CAP ? b1 - bc : (uint32_t)JN_CAP;
+        for (uint32_t h = tid; h < (1u << JN_LOG2_SLOTS); h += JN_THREADS) heads[h] = JN_EMPTY;
+        __syncthreads();
+        for (uint32_t i = tid; i < nb; i += JN_THREADS) {
+            const long long k = B.keys[bc + i];
+            t_keys[i] = k;
+            t_rids[i] = B.rids[bc + i];
+            const uint32_t old = atomicExch(&heads[slot_hash(k, JN_LOG2_SLOTS)], i);   // join_kernels.cuh:109
+            t_next[i] = (uint16_t)old;                                                 // :110 (0xFFFFFFFF -> 0xFFFF)
+        }
+        __syncthreads();
+
+        for (uint32_t pc = p0; pc < p1; pc += JN_THREADS * JN_R) {
+            long long pk[JN_R];
+            uint32_t prid[JN_R], cnt[JN_R], first[JN_R], lp[JN_R];
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                const uint32_t i = pc + r * JN_THREADS + tid;
+                const bool ok = i < p1;
+                pk[r] = ok ? P.keys[i] : 0;
+                prid[r] = ok ? P.rids[i] : 0u;
+                first[r] = ok ? 0u : JN_EMPTY;   // marks invalid rows until the head is read
+            }
+            // phase A: count matches per probe row (walk the chain, join_kernels.cuh:146-165)
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                uint32_t c = 0, f = 0xFFFFu;
+                if (first[r] != JN_EMPTY) {
+                    uint32_t e = heads[slot_hash(pk[r], JN_LOG2_SLOTS)] & 0xFFFFu;
+                    while (e != 0xFFFFu) {
+                        if (t_keys[e] == pk[r]) {   // full-key compare (:152-153)
+                            if (c == 0) f = e;
+                            ++c;
+                        }
+                        e = t_next[e];
+                    }
+                }
+                cnt[r] = c;
+                first[r] = f;
+            }
+            // wave-level exclusive prefix (ballot + mbcnt when every count is 0/1)
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                uint32_t tot;
+                lp[r] = wave_exclusive_count(cnt[r], tot);
+                if (lane == 0) s_wt[r * JN_WAVES + wv] = tot;
+            }
+            __syncthreads();
+            if (wv == 0) {
+                // 64 lanes <-> JN_R*JN_WAVES = 64 (slice, wave) totals, slice-major
+                const uint32_t v = s_wt[lane];
+                const uint32_t inc = wave_inclusive_scan(v);
+                const uint32_t total = __shfl(inc, 63, 64);
+                s_wt[lane] = inc - v;
+                if (lane == 0) s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;   // ONE atomic per batch
+            }
+            __syncthreads();
+            const unsigned long long base = s_base;
+            // phase B: emit.  Slice r of the batch is contiguous across the whole work-group.
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                if (cnt[r]) {
+                    unsigned long long pos = base + s_wt[r * JN_WAVES + wv] + lp[r];
+                    uint32_t e = first[r];
+                    uint32_t left = cnt[r];
+                    for (;;) {
+                        if (t_keys[e] == pk[r]) {
+                            if (pos < max_pairs) out_pairs[pos] = make_uint2(t_rids[e], prid[r]);   // join_kernels.cuh:157-160
+                            ++pos;
+                            if (--left == 0) break;
+                        }
+                        e = t_next[e];
+                    }
+                }
+            }
+            __syncthreads();   // s_wt / s_base reused by the next batch
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BroadcastHashJoin (join_kernel.rs:62-68): one global chained table over the whole
+// build side, exactly the reference's layout idea (buckets[capacity] heads seeded
+// 0xFFFFFFFF, bucket = hash % capacity, capacity = 1.5 n, README.md:114); the entry
+// index IS the build row index, so `next[]` replaces HashEntry and the key compare
+// reads build_keys[entry] directly (join_kernels.cuh:152).
+// ---------------------------------------------------------------------------
+__global__ void k_fill_u32(uint32_t* __restrict__ a, uint32_t n, uint32_t v) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_bcast_build(const long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ buckets,
+                                                      uint32_t capacity, uint32_t* __restrict__ next) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t h = hash_int64(keys[i]);
+        next[i] = atomicExch(&buckets[h % capacity], i);   // join_kernels.cuh:102, :109-110
+    }
+}
+
+constexpr int BC_THREADS = 512;
+constexpr int BC_WAVES = BC_THREADS / 64;
+constexpr int BC_R = 8;
+
+__global__ __launch_bounds__(BC_THREADS) void k_bcast_probe(const long long* __restrict__ build_keys, const uint32_t* __restrict__ buckets,
+                                                            uint32_t capacity, const uint32_t* __restrict__ next,
+                                                            const long long* __restrict__ probe_keys, uint32_t n_probe,
+                                                            uint32_t build_rid_base, uint32_t probe_rid_base, uint2* __restrict__ out_pairs,
+                                                            unsigned long long* __restrict__ out_count, unsigned long long max_pairs) {
+    __shared__ uint32_t s_wt[BC_R * BC_WAVES];
+    __shared__ unsigned long long s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t batch = BC_THREADS * BC_R;
+    for (uint32_t pc = blockIdx.x * batch; pc < n_probe; pc += gridDim.x * batch) {   // uniform per work-group
+        long long pk[BC_R];
+        uint32_t cnt[BC_R], first[BC_R], lp[BC_R];
+#pragma unroll
+        for (int r = 0; r < BC_R; ++r) {
+            const uint32_t i = pc + r * BC_THREADS + tid;
+            pk[r] = i < n_probe ? probe_keys[i] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < BC_R; ++r) {
+            const uint32_t i = pc + r * BC_THREADS + tid;
+            uint32_t c = 0, f = JN_EMPTY;
+            if (i < n_probe) {
+                uint32_t e = buckets[hash_int64(pk[r]) % capacity];   // join_kernels.cuh:142-143
+                while (e != JN_EMPTY) {                                // :146
+                    if (build_keys[e] == pk[r]) {                      // :152-153
+                        if (c == 0) f = e;
+                        ++c;
+                    }
+                    e = next[e];                                       // :164
+                }
+            }
+            cnt[r] = c;
+            first[r] = f;
+        }
+#pragma unroll
+        for (int r = 0; r < BC_R; ++r) {
+            uint32_t tot;
+            lp[r] = wave_exclusive_count(cnt[r], tot);
+            if (lane == 0) s_wt[r * BC_WAVES + wv] = tot;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const uint32_t v = s_wt[lane];
+            const uint32_t inc = wave_inclusive_scan(v);
+            const uint32_t total = __shfl(inc, 63, 64);
+            s_wt[lane] = inc - v;
+            if (lane == 0) s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
+        }
+        __syncthreads();
+        const unsigned long long base = s_base;
+#pragma unroll
+        for (int r = 0; r < BC_R; ++r) {
+            if (cnt[r]) {
+                const uint32_t i = pc + r * BC_THREADS + tid;
+                unsigned long long pos = base + s_wt[r * BC_WAVES + wv] + lp[r];
+                uint32_t e = first[r], left = cnt[r];
+                for (;;) {
+                    if (build_keys[e] == pk[r]) {
+                        if (pos < max_pairs) out_pairs[pos] = make_uint2(build_rid_base + e, probe_rid_base + i);
+                        ++pos;
+                        if (--left == 0) break;
+                    }
+                    e = next[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host: plan
+// ---------------------------------------------------------------------------
+struct PassPlan {
+    PassCfg cfg;
+    uint32_t G;   // groups entering the pass
+    uint32_t bits;
+};
+
+struct JoinPlan {
+    std::vector<PassPlan> passes;
+    uint32_t total_bits = 8;
+    uint64_t n_sub = 256;
+};
+
+static uint32_t ilog2(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) ++l; return l; }
+
+// smallest number of hash bits so that a sub-partition's build side fits the LDS table
+// with ~4.5 sigma of slack (hash partitioning is ~Poisson)
+static uint32_t bits_needed(uint64_t n_build) {
+    uint32_t b = 8;
+    for (; b < 30; ++b) {
+        double avg = (double)n_build / (double)(1ull << b);
+        if (avg + 4.5 * std::sqrt(avg) <= (double)JN_CAP) break;
+    }
+    return b;
+}
+
+// pass structure for `extra` = bits beyond the first 8, given a max of `maxb` bits per pass
+static void split_bits(uint32_t total_bits, uint32_t max_per_pass, std::vector<uint32_t>& out) {
+    out.clear();
+    const char* env = getenv("GOLAP_PASS_BITS");   // e.g. "8,5,5" -- experiment hook
+    if (env && *env) {
+        uint32_t sum = 0;
+        const char* p = env;
+        while (*p) {
+            uint32_t v = (uint32_t)strtoul(p, (char**)&p, 10);
+            if (v) { out.push_back(v); sum += v; }
+            if (*p == ',') ++p; else if (*p) break;
+        }
+        if (!out.empty() && out[0] >= 8 && sum >= total_bits) {
+            bool ok = true;
+            for (uint32_t v : out) ok = ok && v <= 10;
+            if (ok) return;
+        }
+        out.clear();
+    }
+    uint32_t n_pass = (total_bits + max_per_pass - 1) / max_per_pass;
+    if (n_pass == 0) n_pass = 1;
+    uint32_t first = std::max<uint32_t>(8, (total_bits + n_pass - 1) / n_pass);
+    out.push_back(first);
+    uint32_t rest = total_bits > first ? total_bits - first : 0;
+    uint32_t left = n_pass - 1;
+    while (rest > 0) {
+        if (left == 0) left = 1;
+        uint32_t b = (rest + left - 1) / left;
+        if (b > 10) b = 10;
+        out.push_back(b);
+        rest -= b;
+        --left;
+    }
+}
+
+static uint32_t slots_for(uint32_t G, uint64_t n_rows) {
+    // aim at ~4096 work-groups, but never chunks smaller than ~2 tiles on average
+    uint64_t by_wg = std::max<uint64_t>(1, 4096 / std::max<uint32_t>(1, G));
+    uint64_t avg_group = n_rows / std::max<uint32_t>(1, G);
+    uint64_t by_rows = std::max<uint64_t>(1, avg_group / (2 * PT_TILE));
+    return (uint32_t)std::max<uint64_t>(1, std::min(by_wg, by_rows));
+}
+
+static void make_plan(uint64_t n_build, uint32_t owners_log2, bool first_pass_is_reference_partition, JoinPlan& plan) {
+    plan.passes.clear();
+    uint32_t need = bits_needed(n_build);
+    std::vector<uint32_t> bits;
+    split_bits(need, 9, bits);
+    uint32_t shift = 0, G = 1;
+    for (size_t k = 0; k < bits.size(); ++k) {
+        PassPlan pp;
+        memset(&pp, 0, sizeof pp);
+        pp.bits = bits[k];
+        pp.cfg.F = 1u << bits[k];
+        pp.cfg.shift = shift;
+        if (k == 0 && first_pass_is_reference_partition) {
+            pp.cfg.mode = 1;
+            pp.cfg.e1 = bits[k] - 8;
+            pp.cfg.owners_log2 = owners_log2;
+        }
+        pp.G = G;
+        plan.passes.push_back(pp);
+        shift += bits[k];
+        G *= pp.cfg.F;
+    }
+    plan.total_bits = shift;
+    plan.n_sub = G;
+}
+
+// ---------------------------------------------------------------------------
+// host: one side through the passes
+// ---------------------------------------------------------------------------
+struct SideBuffers {
+    // ping-pong targets; final result of the side lands in `final_*`
+    uint64_t tmp_keys[2] = {0, 0}, tmp_rids[2] = {0, 0};
+    uint64_t final_keys = 0, final_rids = 0;
+};
+
+struct SideResult {
+    const uint32_t* off = nullptr;   // scanned hist of the last pass
+    uint32_t stride = 1;
+    const long long* keys = nullptr;
+    const uint32_t* rids = nullptr;
+};
+
+struct SegTable {
+    uint64_t dev_off = 0, dev_len = 0;   // device u32 [G*n_src]
+    uint32_t n_src = 0;
+};
+
+static size_t scatter_lds_bytes(uint32_t F) { return (size_t)PT_TILE * 12 + (size_t)F * 12 + PT_WAVES * 4 + 16; }
+
+int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums) {
+    const uint32_t n_blocks = (uint32_t)ceil_div(n, SC_ELEMS);
+    if (n_blocks > (uint32_t)SC_ELEMS) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "scan of %u elements exceeds the 2-level limit", n);
+    KernelTimer t(ctx, "scan_offsets", st);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SC_THREADS), 0, st, block_sums, n_blocks);
+    hipLaunchKernelGGL(k_scan_down, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums);
+    return GOLAP_OK;
+}
+
+// bytes of small scratch one side needs for `plan` (hist/scan arrays + chunk descriptors)
+static uint64_t side_small_bytes(const JoinPlan& plan, uint64_t n_rows, uint32_t n_src, bool has_segs) {
+    uint64_t total = 0;
+    for (size_t k = 0; k < plan.passes.size(); ++k) {
+        const PassPlan& pp = plan.passes[k];
+        uint64_t S;
+        if (k == 0 && !has_segs) S = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(std::max<uint64_t>(1, n_rows), PT_TILE)));
+        else if (k == 0) S = (uint64_t)n_src * std::max<uint32_t>(1, slots_for(pp.G * n_src, n_rows));
+        else S = slots_for(pp.G, n_rows);
+        uint64_t L = (uint64_t)pp.G * pp.cfg.F * S + 1;
+        total += round_up(L * 4, 256) + round_up(ceil_div(L, SC_ELEMS) * 4 + 4, 256) + 2 * round_up((uint64_t)pp.G * S * 4, 256) + 1024;
+    }
+    return total;
+}
+
+// Runs all passes for one side.  `in_keys`/`in_rids` describe pass 0's input; when
+// `segs` is non-null pass 0's groups are the local partition slots fed by segments.
+static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPlan& plan, uint64_t in_keys, uint64_t in_rids,
+                        uint32_t rid_base, uint64_t n_rows, const SegTable* segs, const SideBuffers& buf, SideResult& res) {
+    const size_t np = plan.passes.size();
+    uint64_t cur_keys = in_keys, cur_rids = in_rids;
+    const uint32_t* prev_scanned = nullptr;
+    uint32_t prev_S = 1;
+    char name[48];
+    for (size_t k = 0; k < np; ++k) {
+        PassPlan& pp = plan.passes[k];
+        uint32_t S;
+        uint32_t n_chunks;
+        uint32_t chunk_rows = 0;
+        if (k == 0 && !segs) {
+            // single group: uniform chunks
+            uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(std::max<uint64_t>(1, n_rows), PT_TILE)));
+            chunk_rows = (uint32_t)round_up(ceil_div(std::max<uint64_t>(1, n_rows), c1), PT_TILE);
+            S = (uint32_t)std::max<uint64_t>(1, ceil_div(std::max<uint64_t>(1, n_rows), chunk_rows));
+        } else if (k == 0) {
+            uint32_t cps = std::max<uint32_t>(1, slots_for(pp.G * segs->n_src, n_rows));
+            S = segs->n_src * cps;
+        } else {
+            S = slots_for(pp.G, n_rows);
+        }
+        pp.cfg.S = S;
+        n_chunks = pp.G * S;
+        const uint64_t L = (uint64_t)pp.G * pp.cfg.F * S;
+        if (L + 1 > 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "partition plan too large");
+        uint32_t* hist = (uint32_t*)ws_take(ctx, (L + 1) * 4);
+        uint32_t* bsums = (uint32_t*)ws_take(ctx, ceil_div(L + 1, SC_ELEMS) * 4 + 4);
+        uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)n_chunks * 4);
+        uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)n_chunks * 4);
+        if (!hist || !bsums || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (small arrays)");
+        GOLAP_HIP_TRY(ctx, hipMemsetAsync(hist, 0, (L + 1) * 4, st));
+        // descriptors
+        {
+            const uint32_t tb = 256, gb = (uint32_t)ceil_div(n_chunks, tb);
+            if (k == 0 && !segs)
+                hipLaunchKernelGGL(k_setup_uniform, dim3(gb), dim3(tb), 0, st, (uint32_t)n_rows, chunk_rows, n_chunks, c_off, c_len);
+            else if (k == 0)
+                hipLaunchKernelGGL(k_setup_from_segments, dim3(gb), dim3(tb), 0, st, (const uint32_t*)segs->dev_off,
+                                   (const uint32_t*)segs->dev_len, pp.G, segs->n_src, S / segs->n_src, c_off, c_len);
+            else
+                hipLaunchKernelGGL(k_setup_from_scan, dim3(gb), dim3(tb), 0, st, prev_scanned, prev_S, pp.G, S, c_off, c_len);
+        }
+        {
+            snprintf(name, sizeof name, "radix_hist_p%zu", k + 1);
+            KernelTimer t(ctx, name, st, 8 * n_rows);
+            hipLaunchKernelGGL(k_hist, dim3(n_chunks), dim3(PT_THREADS), 0, st, (const long long*)cur_keys, c_off, c_len, hist, pp.cfg);
+        }
+        GOLAP_TRY(flat_scan(ctx, st, hist, (uint32_t)(L + 1), bsums));
+        const bool last = k + 1 == np;
+        const uint64_t out_keys = last ? buf.final_keys : buf.tmp_keys[k & 1];
+        const uint64_t out_rids = last ? buf.final_rids : buf.tmp_rids[k & 1];
+        {
+            snprintf(name, sizeof name, "radix_scatter_p%zu", k + 1);
+            KernelTimer t(ctx, name, st, (cur_rids ? 12 : 8) * n_rows + 12 * n_rows);
+            hipLaunchKernelGGL(k_scatter, dim3(n_chunks), dim3(PT_THREADS), scatter_lds_bytes(pp.cfg.F), st, (const long long*)cur_keys,
+                               (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg);
+        }
+        GOLAP_HIP_TRY(ctx, hipGetLastError());
+        cur_keys = out_keys;
+        cur_rids = out_rids;
+        prev_scanned = hist;
+        prev_S = S;
+        (void)side;
+    }
+    res.off = prev_scanned;
+    res.stride = prev_S;
+    res.keys = (const long long*)cur_keys;
+    res.rids = (const uint32_t*)cur_rids;
+    return GOLAP_OK;
+}
+
+static int32_t ensure_scatter_lds(golap_ctx* ctx) {
+    static bool done = false;
+    if (done) return GOLAP_OK;
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)scatter_lds_bytes(PT_MAX_F)));
+    done = true;
+    return GOLAP_OK;
+}
+
+static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint64_t n_probe, uint32_t n_src, bool has_segs) {
+    const uint64_t nmax = std::max(n_build, n_probe);
+    const size_t np = plan.passes.size();
+    uint64_t bytes = 0;
+    bytes += round_up(n_build * 8, 256) + round_up(n_build * 4, 256);   // build final
+    bytes += round_up(n_probe * 8, 256) + round_up(n_probe * 4, 256);   // probe final
+    const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
+    bytes += n_tmp * (round_up(nmax * 8, 256) + round_up(nmax * 4, 256));
+    bytes += side_small_bytes(plan, n_build, n_src, has_segs) + side_small_bytes(plan, n_probe, n_src, has_segs);
+    bytes += 2 * round_up((uint64_t)4096 * 4 * 2, 256);   // segment tables
+    return bytes + (1 << 20);
+}
+
+// shared tail: both sides partitioned -> LDS join
+static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, const SideResult& b, const SideResult& p, uint64_t n_build,
+                               uint64_t n_probe, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs) {
+    JoinSide B{b.keys, b.rids, b.off, b.stride}, P{p.keys, p.rids, p.off, p.stride};
+    KernelTimer t(ctx, "join_build_probe_lds", st, 12 * (n_build + n_probe));
+    hipLaunchKernelGGL(k_join_lds, dim3((uint32_t)plan.n_sub), dim3(JN_THREADS), 0, st, B, P, (uint2*)out_pairs, (unsigned long long*)out_count,
+                       (unsigned long long)max_pairs);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipStream_t st) {
+    if (p->n_build >= 0xFFFFFFF0ull || p->n_probe >= 0xFFFFFFF0ull)
+        return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32 (join_kernels.cuh:48): at most 2^32-16 rows per side");
+    GOLAP_TRY(ensure_scatter_lds(ctx));
+    JoinPlan plan;
+    make_plan(p->n_build, 0, true, plan);
+    const size_t np = plan.passes.size();
+    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->n_build, p->n_probe, 1, false), st));
+    const uint64_t nmax = std::max(p->n_build, p->n_probe);
+    SideBuffers bb, pb;
+    bb.final_keys = ws_take(ctx, p->n_build * 8);
+    bb.final_rids = ws_take(ctx, p->n_build * 4);
+    pb.final_keys = ws_take(ctx, p->n_probe * 8);
+    pb.final_rids = ws_take(ctx, p->n_probe * 4);
+    const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
+    for (size_t i = 0; i < n_tmp; ++i) {
+        bb.tmp_keys[i] = pb.tmp_keys[i] = ws_take(ctx, nmax * 8);
+        bb.tmp_rids[i] = pb.tmp_rids[i] = ws_take(ctx, nmax * 4);
+        if (!bb.tmp_keys[i] || !bb.tmp_rids[i]) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    }
+    if (!bb.final_keys || !bb.final_rids || !pb.final_keys || !pb.final_rids) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    // With >= 3 passes the ping-pong alternates tmp[0], tmp[1], tmp[0]...; with an odd
+    // number of non-final passes beyond 2 the k&1 indexing below stays within the 2 temps.
+    JoinPlan plan_b = plan, plan_p = plan;
+    SideResult rb, rp;
+    GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build_key_ptr, 0, p->build_rid_base, p->n_build, nullptr, bb, rb));
+    GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe_key_ptr, 0, p->probe_rid_base, p->n_probe, nullptr, pb, rp));
+    GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs));
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
+static int32_t broadcast_hash_join(golap_ctx* ctx, const golap_join_params* p, hipStream_t st) {
+    if (p->n_build >= 0xFFFFFFF0ull / 2 || p->n_probe >= 0xFFFFFFF0ull)
+        return fail(ctx, GOLAP_ERR_UNSUPPORTED, "BroadcastHashJoin: side too large for u32 row ids");
+    const uint32_t nb = (uint32_t)p->n_build, npr = (uint32_t)p->n_probe;
+    const uint32_t capacity = std::max<uint32_t>(1, nb + nb / 2);   // README.md:114
+    GOLAP_TRY(ws_begin(ctx, (uint64_t)capacity * 4 + (uint64_t)nb * 4 + 4096, st));
+    uint32_t* buckets = (uint32_t*)ws_take(ctx, (uint64_t)capacity * 4);
+    uint32_t* next = (uint32_t*)ws_take(ctx, (uint64_t)nb * 4);
+    if (!buckets || !next) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    {
+        KernelTimer t(ctx, "bcast_build_table", st, 8ull * nb);
+        hipLaunchKernelGGL(k_fill_u32, dim3(std::min<uint32_t>(cus * 8, (uint32_t)ceil_div(capacity, 256))), dim3(256), 0, st, buckets, capacity,
+                           JN_EMPTY);
+        hipLaunchKernelGGL(k_bcast_build, dim3(std::min<uint32_t>(cus * 8, (uint32_t)ceil_div(nb, 256))), dim3(256), 0, st,
+                           (const long long*)p->build_key_ptr, nb, buckets, capacity, next);
+    }
+    {
+        KernelTimer t(ctx, "bcast_probe_table", st, 8ull * npr);
+        const uint32_t batch = BC_THREADS * BC_R;
+        hipLaunchKernelGGL(k_bcast_probe, dim3(std::min<uint32_t>(cus * 4, (uint32_t)ceil_div(npr, batch))), dim3(BC_THREADS), 0, st,
+                           (const long long*)p->build_key_ptr, buckets, capacity, next, (const long long*)p->probe_key_ptr, npr,
+                           p->build_rid_base, p->probe_rid_base, (uint2*)p->out_pairs_ptr, (unsigned long long*)p->out_count_ptr,
+                           (unsigned long long)p->max_pairs);
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
+}  // namespace golap
+
+using namespace golap;
+
+extern "C" {
+
+int32_t golap_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_join_params* p, void* stream) {
+    if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+    if (p->max_pairs && !p->out_pairs_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_pairs_ptr is null but max_pairs > 0");
+    if ((p->n_build && !p->build_key_ptr) || (p->n_probe && !p->probe_key_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null key column");
+    if (strategy == GOLAP_JOIN_SORT_MERGE)
+        return fail(ctx, GOLAP_ERR_UNSUPPORTED, "SortMergeJoin is out of scope (the planner never emits it, physical_plan.rs:144)");
+    if (strategy != GOLAP_JOIN_RADIX_HASH && strategy != GOLAP_JOIN_BROADCAST_HASH)
+        return fail(ctx, GOLAP_ERR_INVALID_ARG, "unknown join strategy %d", (int)strategy);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_count_ptr, 0, 8, st));
+    if (p->n_build == 0 || p->n_probe == 0) return GOLAP_OK;   // executor.rs:231-233
+    if (strategy == GOLAP_JOIN_BROADCAST_HASH) return broadcast_hash_join(ctx, p, st);
+    return radix_hash_join(ctx, p, st);
+}
+
+uint64_t golap_join_scratch_bytes(golap_ctx* ctx, uint64_t n_build, uint64_t n_probe) {
+    (void)ctx;
+    JoinPlan plan;
+    make_plan(n_build, 0, true, plan);
+    return radix_join_ws_bytes(plan, n_build, n_probe, 1, false);
+}
+
+int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners, golap_join_plan* out) {
+    if (!out) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (n_owners == 0 || (n_owners & (n_owners - 1)) || n_owners > 256) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_owners must be a power of two <= 256");
+    JoinPlan plan;
+    make_plan(n_build, ilog2(n_owners), true, plan);
+    memset(out, 0, sizeof *out);
+    out->bits1 = plan.passes[0].bits;
+    out->bits2 = plan.total_bits - plan.passes[0].bits;
+    out->tile_rows = PT_TILE;
+    out->table_capacity = JN_CAP;
+    out->n_subpartitions = plan.n_sub;
+    return GOLAP_OK;
+}
+
+// radix_partition_kernel as a stand-alone step: exactly 256 partitions (join_kernels.cuh:22-23, :69).
+int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* p, void* stream) {
+    if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (!p->out_offsets_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_offsets_ptr is null");
+    if (p->n_rows && (!p->key_ptr || !p->out_key_ptr || !p->out_row_id_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
+    if (p->n_owners == 0 || (p->n_owners & (p->n_owners - 1)) || p->n_owners > 256)
+        return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_owners must be a power of two <= 256");
+    if (p->n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32: at most 2^32-16 rows");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    GOLAP_TRY(ensure_scatter_lds(ctx));
+    JoinPlan plan;
+    PassPlan pp;
+    memset(&pp, 0, sizeof pp);
+    pp.bits = 8;
+    pp.cfg.F = 256;
+    pp.cfg.mode = 1;
+    pp.cfg.e1 = 0;
+    pp.cfg.owners_log2 = ilog2(p->n_owners);
+    pp.G = 1;
+    plan.passes.push_back(pp);
+    plan.total_bits = 8;
+    plan.n_sub = 256;
+    GOLAP_TRY(ws_begin(ctx, side_small_bytes(plan, p->n_rows, 1, false) + 4096, st));
+    SideBuffers buf;
+    buf.final_keys = p->out_key_ptr;
+    buf.final_rids = p->out_row_id_ptr;
+    SideResult res;
+    if (p->n_rows == 0) {
+        GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_offsets_ptr, 0, 257 * 4, st));
+        return GOLAP_OK;
+    }
+    GOLAP_TRY(run_side(ctx, st, "part", plan, p->key_ptr, p->row_id_ptr, p->rid_base, p->n_rows, nullptr, buf, res));
+    // offsets[s] = scanned[s * S] for s in 0..256 (the scan carries the total in its last slot)
+    GOLAP_HIP_TRY(ctx, hipMemcpy2DAsync((void*)p->out_offsets_ptr, 4, res.off, (size_t)res.stride * 4, 4, 257, hipMemcpyDeviceToDevice, st));
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
+// Join of radix-partitioned inputs: groups = local partition slots fed by per-source segments.
+int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_params* p, void* stream) {
+    if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+    if (p->n_slots == 0 || p->n_slots > 256 || (p->n_slots & (p->n_slots - 1))) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_slots must be a power of two <= 256");
+    if (p->n_sources == 0 || p->n_sources > 64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_sources must be in 1..64");
+    if (!p->build.seg_off || !p->build.seg_len || !p->probe.seg_off || !p->probe.seg_len) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null segment table");
+    if (p->build.n_rows >= 0xFFFFFFF0ull || p->probe.n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "too many rows for u32 offsets");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_count_ptr, 0, 8, st));
+    if (p->build.n_rows == 0 || p->probe.n_rows == 0) return GOLAP_OK;
+    GOLAP_TRY(ensure_scatter_lds(ctx));
+    const uint32_t nseg = p->n_slots * p->n_sources;
+    for (uint32_t i = 0; i < nseg; ++i) {
+        if (p->build.seg_off[i] + p->build.seg_len[i] > p->build.n_rows || p->probe.seg_off[i] + p->probe.seg_len[i] > p->probe.n_rows)
+            return fail(ctx, GOLAP_ERR_INVALID_ARG, "segment %u exceeds its buffer", i);
+    }
+    // Sub-partition fan-out: the rows of one slot already share 8 hash bits (the
+    // exchange-time radix partition), so the remaining passes start at shift 8.
+    const uint64_t hint = p->total_build_rows_hint ? p->total_build_rows_hint : p->build.n_rows;
+    const uint64_t per_slot = ceil_div(hint, p->n_slots);
+    uint32_t need = 0;
+    for (; need < 22; ++need) {
+        double avg = (double)per_slot / (double)(1ull << need);
+        if (avg + 4.5 * std::sqrt(avg) <= (double)JN_CAP) break;
+    }
+    if (need == 0) need = 1;   // always run at least one local pass: it also merges the source segments
+    JoinPlan plan;
+    {
+        uint32_t n_pass = (need + 8) / 9;
+        uint32_t shift = 8, G = p->n_slots, rest = need;
+        for (uint32_t k = 0; k < n_pass; ++k) {
+            uint32_t b = (rest + (n_pass - k) - 1) / (n_pass - k);
+            PassPlan pp;
+            memset(&pp, 0, sizeof pp);
+            pp.bits = b;
+            pp.cfg.F = 1u << b;
+            pp.cfg.shift = shift;
+            pp.cfg.mode = 0;
+            pp.G = G;
+            plan.passes.push_back(pp);
+            shift += b;
+            G *= pp.cfg.F;
+            rest -= b;
+        }
+        plan.total_bits = shift;
+        plan.n_sub = G;
+    }
+    const size_t np = plan.passes.size();
+    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->build.n_rows, p->probe.n_rows, p->n_sources, true), st));
+    const uint64_t nmax = std::max(p->build.n_rows, p->probe.n_rows);
+    SideBuffers bb, pb;
+    bb.final_keys = ws_take(ctx, p->build.n_rows * 8);
+    bb.final_rids = ws_take(ctx, p->build.n_rows * 4);
+    pb.final_keys = ws_take(ctx, p->probe.n_rows * 8);
+    pb.final_rids = ws_take(ctx, p->probe.n_rows * 4);
+    const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
+    for (size_t i = 0; i < n_tmp; ++i) {
+        bb.tmp_keys[i] = pb.tmp_keys[i] = ws_take(ctx, nmax * 8);
+        bb.tmp_rids[i] = pb.tmp_rids[i] = ws_take(ctx, nmax * 4);
+        if (!bb.tmp_keys[i] || !bb.tmp_rids[i]) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    }
+    if (!bb.final_keys || !bb.final_rids || !pb.final_keys || !pb.final_rids) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    // upload the segment tables (u32)
+    std::vector<uint32_t> h_stage_v((size_t)nseg * 4);   // pageable: hipMemcpyAsync stages it before returning
+    uint32_t* h_stage = h_stage_v.data();
+    for (uint32_t i = 0; i < nseg; ++i) {
+        h_stage[i] = (uint32_t)p->build.seg_off[i];
+        h_stage[nseg + i] = (uint32_t)p->build.seg_len[i];
+        h_stage[2 * nseg + i] = (uint32_t)p->probe.seg_off[i];
+        h_stage[3 * nseg + i] = (uint32_t)p->probe.seg_len[i];
+    }
+    uint64_t d_seg = ws_take(ctx, (uint64_t)nseg * 16);
+    if (!d_seg) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)d_seg, h_stage, (size_t)nseg * 16, hipMemcpyHostToDevice, st));
+    SegTable sb{d_seg, d_seg + (uint64_t)nseg * 4, p->n_sources}, sp{d_seg + (uint64_t)nseg * 8, d_seg + (uint64_t)nseg * 12, p->n_sources};
+    JoinPlan plan_b = plan, plan_p = plan;
+    SideResult rb, rp;
+    GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build.key_ptr, p->build.row_id_ptr, 0, p->build.n_rows, &sb, bb, rb));
+    GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe.key_ptr, p->probe.row_id_ptr, 0, p->probe.n_rows, &sp, pb, rp));
+    GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->build.n_rows, p->probe.n_rows, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs));
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,627 @@
+// golap_ops.hip -- GpuFilter, GpuAggregate, arrow-interop widening, synthetic
+// generators and the pair verifier, as ahead-of-time gfx950 kernels.
+//
+// Reference semantics restated (paths relative to the reference root):
+//   filter     gpu-olap-core/src/executor.rs:443-476 (mask), :478-507 (compaction/take);
+//              gpu-kernel-compiler/src/filter_kernel.rs:3-5 (u8 mask, then prefix-sum + scatter);
+//              codegen.rs:11-28 (CmpOp / FilterPredicate) -- the PTX emitter (:36-47, body `ret;`)
+//              is replaced by kernels that take `op` as a runtime argument.
+//   aggregate  executor.rs:297-355 + :509-527 (f64 accumulators, Int64 `as f64`);
+//              aggregate_kernel.rs:17-58 (AggFunc, identities, [agg][group] output);
+//              join_kernels.cuh:216-240 (slot = key % num_groups).
+//   widening   arrow-interop/src/record_batch_convert.rs:35-110.
+#include "golap_device.h"
+#include "golap_internal.h"
+
+#include <algorithm>
+
+namespace golap {
+
+constexpr int OP_THREADS = 256;
+constexpr int OP_WAVES = OP_THREADS / 64;
+
+__device__ __forceinline__ bool cmp_i64(int op, long long l, long long r) {
+    switch (op) {                       // executor.rs:457-465
+        case GOLAP_CMP_EQ: return l == r;
+        case GOLAP_CMP_NE: return l != r;
+        case GOLAP_CMP_LT: return l < r;
+        case GOLAP_CMP_LE: return l <= r;
+        case GOLAP_CMP_GT: return l > r;
+        case GOLAP_CMP_GE: return l >= r;
+        default: return false;          // :464 unknown operator -> no row
+    }
+}
+
+// ---------------------------------------------------------------------------
+// filter mask: 4 rows per thread, 2 x 16-byte loads, one packed 4-byte mask store
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(OP_THREADS) void k_filter_mask4(const longlong2* __restrict__ col2, unsigned long long n4, int op, long long lit,
+                                                             uint32_t* __restrict__ mask4) {
+    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (unsigned long long)gridDim.x * blockDim.x) {
+        const longlong2 a = col2[2 * q], b = col2[2 * q + 1];
+        uint32_t m = (cmp_i64(op, a.x, lit) ? 1u : 0u) | (cmp_i64(op, a.y, lit) ? 1u << 8 : 0u) | (cmp_i64(op, b.x, lit) ? 1u << 16 : 0u) |
+                     (cmp_i64(op, b.y, lit) ? 1u << 24 : 0u);
+        mask4[q] = m;
+    }
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_filter_mask1(const long long* __restrict__ col, unsigned long long first, unsigned long long n, int op,
+                                                             long long lit, uint8_t* __restrict__ mask) {
+    for (unsigned long long i = first + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        mask[i] = cmp_i64(op, col[i], lit) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// fused predicate + ordered compaction (selection vector of ascending row ids).
+// block b owns rows [b*4096, (b+1)*4096): count -> flat scan -> write with
+// wavefront ballot + mbcnt prefix (no atomics, order preserved: executor.rs:479-484).
+// ---------------------------------------------------------------------------
+constexpr int FC_ROWS = 4096;
+constexpr int FC_RPT = FC_ROWS / OP_THREADS;   // 16 rows per thread, interleaved by wave-sized strips
+
+__global__ __launch_bounds__(OP_THREADS) void k_filter_count(const long long* __restrict__ col, unsigned long long n, int op, long long lit,
+                                                             uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_w[OP_WAVES];
+    const unsigned long long base = (unsigned long long)blockIdx.x * FC_ROWS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < FC_RPT; ++r) {
+        const unsigned long long i = base + r * OP_THREADS + threadIdx.x;
+        c += (i < n && cmp_i64(op, col[i], lit)) ? 1u : 0u;
+    }
+    c = wave_reduce_add(c);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_filter_write(const long long* __restrict__ col, unsigned long long n, int op, long long lit,
+                                                             const uint32_t* __restrict__ scanned, uint32_t n_blocks, uint32_t* __restrict__ out_idx,
+                                                             unsigned long long* __restrict__ out_count) {
+    __shared__ uint32_t s_w[FC_RPT * OP_WAVES];   // strip-major (r, wave) totals -> exclusive offsets
+    const unsigned long long base = (unsigned long long)blockIdx.x * FC_ROWS;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool keep[FC_RPT];
+    uint32_t lp[FC_RPT];
+#pragma unroll
+    for (int r = 0; r < FC_RPT; ++r) {
+        const unsigned long long i = base + r * OP_THREADS + threadIdx.x;
+        keep[r] = i < n && cmp_i64(op, col[i], lit);
+        const unsigned long long m = __ballot(keep[r]);
+        lp[r] = mbcnt(m);
+        if (lane == 0) s_w[r * OP_WAVES + wv] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (wv == 0) {   // 64 (strip, wave) totals, row order = strip-major then wave
+        const uint32_t v = s_w[lane];
+        const uint32_t inc = wave_inclusive_scan(v);
+        s_w[lane] = inc - v;
+    }
+    __syncthreads();
+    const uint32_t gbase = scanned[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < FC_RPT; ++r) {
+        if (keep[r]) out_idx[gbase + s_w[r * OP_WAVES + wv] + lp[r]] = (uint32_t)(base + r * OP_THREADS + threadIdx.x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = scanned[n_blocks];
+}
+static_assert(FC_RPT * OP_WAVES == 64, "strip totals are scanned by one wave");
+
+// take_int64 (executor.rs:496-507) for any 8-byte column
+__global__ __launch_bounds__(OP_THREADS) void k_take8(const unsigned long long* __restrict__ col, const uint32_t* __restrict__ idx,
+                                                      const unsigned long long* __restrict__ count_ptr, unsigned long long n_max,
+                                                      unsigned long long* __restrict__ out) {
+    unsigned long long n = count_ptr ? *count_ptr : n_max;
+    if (n > n_max) n = n_max;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        out[i] = col[idx[i]];
+}
+
+// ---------------------------------------------------------------------------
+// reductions: per-block partials in a fixed order, then one block folds them in
+// index order -> bitwise reproducible run to run (no float atomics).
+// partial layout: [block][4] = sum, count, min, max
+// ---------------------------------------------------------------------------
+struct Acc4 { double sum, cnt, mn, mx; };
+
+__device__ __forceinline__ void block_reduce_acc(Acc4& a, double* s /*[4*OP_WAVES]*/) {
+    a.sum = wave_reduce_addf(a.sum);
+    a.cnt = wave_reduce_addf(a.cnt);
+    a.mn = wave_reduce_minf(a.mn);
+    a.mx = wave_reduce_maxf(a.mx);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s[wv * 4 + 0] = a.sum; s[wv * 4 + 1] = a.cnt; s[wv * 4 + 2] = a.mn; s[wv * 4 + 3] = a.mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < OP_WAVES; ++w) {
+            a.sum += s[w * 4 + 0]; a.cnt += s[w * 4 + 1];
+            a.mn = s[w * 4 + 2] < a.mn ? s[w * 4 + 2] : a.mn;
+            a.mx = s[w * 4 + 3] > a.mx ? s[w * 4 + 3] : a.mx;
+        }
+    }
+}
+
+#define GOLAP_F64_MAX 1.7976931348623157e308
+
+template <bool VAL_F64, bool HAS_PRED>
+__global__ __launch_bounds__(OP_THREADS) void k_reduce_partials(const long long* __restrict__ key, const void* __restrict__ val, unsigned long long n, int op,
+                                                                long long lit, double* __restrict__ partials) {
+    __shared__ double s[4 * OP_WAVES];
+    Acc4 a{0.0, 0.0, GOLAP_F64_MAX, -GOLAP_F64_MAX};   // executor.rs:308-311 seeds
+    const long long* vi = (const long long*)val;
+    const double* vf = (const double*)val;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        bool keep = true;
+        if (HAS_PRED) keep = cmp_i64(op, key[i], lit);
+        if (keep) {
+            const double x = VAL_F64 ? vf[i] : (double)vi[i];   // executor.rs:521 `as f64`
+            a.sum += x; a.cnt += 1.0;                            // :317-318
+            a.mn = x < a.mn ? x : a.mn;                          // :319-321
+            a.mx = x > a.mx ? x : a.mx;                          // :322-324
+        }
+    }
+    block_reduce_acc(a, s);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 4 + 0] = a.sum; partials[blockIdx.x * 4 + 1] = a.cnt;
+        partials[blockIdx.x * 4 + 2] = a.mn;  partials[blockIdx.x * 4 + 3] = a.mx;
+    }
+}
+
+// folds partials[0..n_part) in index order (strided per thread, then a fixed tree)
+__global__ __launch_bounds__(OP_THREADS) void k_reduce_final(const double* __restrict__ partials, uint32_t n_part, double* __restrict__ out4) {
+    __shared__ double s[4 * OP_WAVES];
+    Acc4 a{0.0, 0.0, GOLAP_F64_MAX, -GOLAP_F64_MAX};
+    for (uint32_t i = threadIdx.x; i < n_part; i += OP_THREADS) {
+        a.sum += partials[i * 4 + 0]; a.cnt += partials[i * 4 + 1];
+        a.mn = partials[i * 4 + 2] < a.mn ? partials[i * 4 + 2] : a.mn;
+        a.mx = partials[i * 4 + 3] > a.mx ? partials[i * 4 + 3] : a.mx;
+    }
+    block_reduce_acc(a, s);
+    if (threadIdx.x == 0) { out4[0] = a.sum; out4[1] = a.cnt; out4[2] = a.mn; out4[3] = a.mx; }
+}
+
+// out[spec plane * n_groups + g] from stats4[g] = sum,count,min,max (executor.rs:334-346)
+struct SpecDev { int32_t func; uint32_t plane; };
+__global__ void k_finalize_specs(const double* __restrict__ stats4, uint32_t n_groups, SpecDev sp, double* __restrict__ out) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        const double sum = stats4[g * 4 + 0], cnt = stats4[g * 4 + 1], mn = stats4[g * 4 + 2], mx = stats4[g * 4 + 3];
+        double v;
+        switch (sp.func) {
+            case GOLAP_AGG_SUM: v = sum; break;
+            case GOLAP_AGG_COUNT: v = cnt; break;                 // count as f64, executor.rs:336
+            case GOLAP_AGG_MIN: v = mn; break;
+            case GOLAP_AGG_MAX: v = mx; break;
+            default: v = cnt > 0.0 ? sum / cnt : 0.0; break;      // AVG, :339-345
+        }
+        out[(size_t)sp.plane * n_groups + g] = v;
+    }
+}
+
+__global__ void k_counts_from_stats(const double* __restrict__ stats4, uint32_t n_groups, unsigned long long* __restrict__ out_count) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x)
+        out_count[g] = (unsigned long long)stats4[g * 4 + 1];
+}
+
+// ---------------------------------------------------------------------------
+// grouped aggregate, LDS pre-aggregation (aggregate_kernel.rs:3-6 "phase 1" /
+// "phase 2"): every work-group folds its rows into an LDS table of n_groups
+// slots with ds_add_f64 / ds_min_f64 / ds_max_f64, then writes its table as one
+// row of a [work-group][group] partial slab; a second kernel folds the slab per
+// group in work-group order (reproducible; no global float atomics).
+// slot = key % n_groups (join_kernels.cuh:230).
+// ---------------------------------------------------------------------------
+template <typename KeyT, bool VAL_F64>
+__global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n, uint32_t n_groups,
+                                                    unsigned long long rows_per_block, double* __restrict__ slab /*[grid][4][n_groups]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double* s_sum = reinterpret_cast<double*>(s_raw);
+    double* s_mn = s_sum + n_groups;
+    double* s_mx = s_mn + n_groups;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mx + n_groups);
+    for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) { s_sum[g] = 0.0; s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; s_cnt[g] = 0; }
+    __syncthreads();
+    const long long* vi = (const long long*)val;
+    const double* vf = (const double*)val;
+    const unsigned long long lo = (unsigned long long)blockIdx.x * rows_per_block;
+    unsigned long long hi = lo + rows_per_block;
+    if (hi > n) hi = n;
+    for (unsigned long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t g = (uint32_t)((unsigned long long)keys[i] % n_groups);
+        const double x = VAL_F64 ? vf[i] : (double)vi[i];
+        atomicAdd(&s_sum[g], x);
+        atomicAdd(&s_cnt[g], 1u);
+        __hip_atomic_fetch_min(&s_mn[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&s_mx[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    double* row = slab + (size_t)blockIdx.x * 4 * n_groups;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        row[g] = s_sum[g];
+        row[n_groups + g] = (double)s_cnt[g];
+        row[2 * n_groups + g] = s_mn[g];
+        row[3 * n_groups + g] = s_mx[g];
+    }
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_group_fold(const double* __restrict__ slab, uint32_t n_rows_slab, uint32_t n_groups,
+                                                            double* __restrict__ stats4) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        double sum = 0.0, cnt = 0.0, mn = GOLAP_F64_MAX, mx = -GOLAP_F64_MAX;
+        for (uint32_t b = 0; b < n_rows_slab; ++b) {
+            const double* row = slab + (size_t)b * 4 * n_groups;
+            sum += row[g]; cnt += row[n_groups + g];
+            mn = row[2 * n_groups + g] < mn ? row[2 * n_groups + g] : mn;
+            mx = row[3 * n_groups + g] > mx ? row[3 * n_groups + g] : mx;
+        }
+        stats4[g * 4 + 0] = sum; stats4[g * 4 + 1] = cnt; stats4[g * 4 + 2] = mn; stats4[g * 4 + 3] = mx;
+    }
+}
+
+// large group counts: global table, agent-scope atomics per row ("global merge",
+// aggregate_kernel.rs:6, :84-86).  Sums of integer-valued data are exact; for
+// general doubles the order of the adds is not fixed (documented in DESIGN.md).
+__global__ void k_group_init(double* __restrict__ stats4, uint32_t n_groups) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        stats4[g * 4 + 0] = 0.0; stats4[g * 4 + 1] = 0.0; stats4[g * 4 + 2] = GOLAP_F64_MAX; stats4[g * 4 + 3] = -GOLAP_F64_MAX;
+    }
+}
+
+template <typename KeyT, bool VAL_F64>
+__global__ __launch_bounds__(OP_THREADS) void k_group_global(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
+                                                             uint32_t n_groups, double* __restrict__ stats4, int need_minmax) {
+    const long long* vi = (const long long*)val;
+    const double* vf = (const double*)val;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t g = (uint32_t)((unsigned long long)keys[i] % n_groups);
+        const double x = VAL_F64 ? vf[i] : (double)vi[i];
+        unsafeAtomicAdd(&stats4[g * 4 + 0], x);
+        unsafeAtomicAdd(&stats4[g * 4 + 1], 1.0);
+        if (need_minmax) {
+            __hip_atomic_fetch_min(&stats4[g * 4 + 2], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(&stats4[g * 4 + 3], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// widening (record_batch_convert.rs:102-110): null -> 0, 8-byte LE
+// ---------------------------------------------------------------------------
+template <typename In, typename Out>
+__global__ __launch_bounds__(OP_THREADS) void k_widen(const In* __restrict__ in, const uint8_t* __restrict__ validity, unsigned long long n,
+                                                      Out* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        out[i] = (validity && !validity[i]) ? (Out)0 : (Out)in[i];
+}
+
+// ---------------------------------------------------------------------------
+// generators
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(OP_THREADS) void k_generate(int kind, unsigned long long seed, unsigned long long first, unsigned long long count,
+                                                         unsigned long long modulus, void* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long g = first + i;
+        switch (kind) {
+            case GOLAP_GEN_BUILD_KEYS: ((long long*)out)[i] = (long long)((2654435761ull * g + 12345ull) % modulus); break;
+            case GOLAP_GEN_SM64_MOD_I64: ((long long*)out)[i] = (long long)(sm64(seed, g) % modulus); break;
+            case GOLAP_GEN_SM64_MOD_I32: ((int*)out)[i] = (int)(sm64(seed, g) % modulus); break;
+            case GOLAP_GEN_SM64_MOD_F64: ((double*)out)[i] = (double)(sm64(seed, g) % modulus); break;
+            case GOLAP_GEN_SHIFT32_I64: ((long long*)out)[i] = (long long)(g << 32); break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pair verifier
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(OP_THREADS) void k_verify_pairs(const uint2* __restrict__ pairs, unsigned long long n_pairs, const long long* __restrict__ bkeys,
+                                                             const long long* __restrict__ pkeys, uint32_t brb, uint32_t prb,
+                                                             unsigned long long* __restrict__ out4) {
+    unsigned long long eq = 0, cs = 0, ps = 0, px = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint2 p = pairs[i];
+        eq += bkeys[p.x - brb] == pkeys[p.y - prb] ? 1ull : 0ull;
+        cs += pair_mix(p.x, p.y);
+        ps += p.y;
+        px ^= sm64(0x1234, p.y);
+    }
+    eq = wave_reduce_add64(eq);
+    cs = wave_reduce_add64(cs);
+    ps = wave_reduce_add64(ps);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) px ^= __shfl_xor(px, d, 64);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out4[0], eq);
+        atomicAdd(&out4[1], cs);
+        atomicAdd(&out4[2], ps);
+        atomicXor(&out4[3], px);
+    }
+}
+
+static uint32_t stream_grid(golap_ctx* ctx, uint64_t n, uint32_t per_block) {
+    uint64_t want = ceil_div(std::max<uint64_t>(1, n), per_block);
+    uint64_t cap = (uint64_t)ctx->prop.multiProcessorCount * 8;   // guideline 11: cap at ~2048 blocks, grid-stride the rest
+    return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+}  // namespace golap
+
+using namespace golap;
+
+extern "C" {
+
+int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, const golap_filter_params* p, void* stream) {
+    if (!ctx || !pred || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (p->n_rows && (!p->column_ptr || !p->out_mask_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column/mask pointer");
+    if (pred->op < 0 || pred->op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", pred->op);
+    if (p->n_rows == 0) return GOLAP_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    KernelTimer t(ctx, "filter_mask", st, 9 * p->n_rows);
+    const bool aligned = (p->column_ptr % 16 == 0) && (p->out_mask_ptr % 4 == 0);
+    uint64_t done = 0;
+    if (aligned && p->n_rows >= 4) {
+        const uint64_t n4 = p->n_rows / 4;
+        hipLaunchKernelGGL(k_filter_mask4, dim3(stream_grid(ctx, n4, OP_THREADS)), dim3(OP_THREADS), 0, st, (const longlong2*)p->column_ptr,
+                           (unsigned long long)n4, pred->op, (long long)pred->literal, (uint32_t*)p->out_mask_ptr);
+        done = n4 * 4;
+    }
+    if (done < p->n_rows)
+        hipLaunchKernelGGL(k_filter_mask1, dim3(stream_grid(ctx, p->n_rows - done, OP_THREADS)), dim3(OP_THREADS), 0, st, (const long long*)p->column_ptr,
+                           (unsigned long long)done, (unsigned long long)p->n_rows, pred->op, (long long)pred->literal, (uint8_t*)p->out_mask_ptr);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t n_rows, uint64_t out_indices_ptr,
+                             uint64_t out_count_ptr, void* stream) {
+    if (!ctx || !pred) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (!out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+    if (n_rows && (!column_ptr || !out_indices_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column/indices pointer");
+    if (pred->op < 0 || pred->op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", pred->op);
+    if (n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32: at most 2^32-16 rows per batch");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    if (n_rows == 0) { GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)out_count_ptr, 0, 8, st)); return GOLAP_OK; }
+    const uint32_t n_blocks = (uint32_t)ceil_div(n_rows, FC_ROWS);
+    GOLAP_TRY(ws_begin(ctx, (uint64_t)(n_blocks + 1) * 4 + ceil_div(n_blocks + 1, FLAT_SCAN_BLOCK) * 4 + 8192, st));
+    uint32_t* counts = (uint32_t*)ws_take(ctx, (uint64_t)(n_blocks + 1) * 4);
+    uint32_t* bsums = (uint32_t*)ws_take(ctx, ceil_div(n_blocks + 1, FLAT_SCAN_BLOCK) * 4 + 4);
+    if (!counts || !bsums) return fail(ctx, GOLAP_ERR_OOM, "filter workspace exhausted");
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync(counts + n_blocks, 0, 4, st));
+    {
+        KernelTimer t(ctx, "filter_count", st, 8 * n_rows);
+        hipLaunchKernelGGL(k_filter_count, dim3(n_blocks), dim3(OP_THREADS), 0, st, (const long long*)column_ptr, (unsigned long long)n_rows, pred->op,
+                           (long long)pred->literal, counts);
+    }
+    GOLAP_TRY(flat_scan(ctx, st, counts, n_blocks + 1, bsums));
+    {
+        KernelTimer t(ctx, "filter_compact", st, 8 * n_rows);
+        hipLaunchKernelGGL(k_filter_write, dim3(n_blocks), dim3(OP_THREADS), 0, st, (const long long*)column_ptr, (unsigned long long)n_rows, pred->op,
+                           (long long)pred->literal, counts, n_blocks, (uint32_t*)out_indices_ptr, (unsigned long long*)out_count_ptr);
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
+int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_ptr, uint64_t count_ptr, uint64_t n_indices_max, uint64_t out_ptr,
+                         void* stream) {
+    if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
+    if (n_indices_max == 0) return GOLAP_OK;
+    if (!column_ptr || !indices_ptr || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    KernelTimer t(ctx, "take_8byte", st, 20 * n_indices_max);
+    hipLaunchKernelGGL(k_take8, dim3(stream_grid(ctx, n_indices_max, OP_THREADS)), dim3(OP_THREADS), 0, st, (const unsigned long long*)column_ptr,
+                       (const uint32_t*)indices_ptr, (const unsigned long long*)count_ptr, (unsigned long long)n_indices_max,
+                       (unsigned long long*)out_ptr);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+int32_t golap_filter_sum(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t key_column_ptr, uint64_t value_column_ptr, int32_t value_is_f64,
+                         uint64_t n_rows, uint64_t out_ptr, void* stream) {
+    if (!ctx || !pred || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (n_rows && (!key_column_ptr || !value_column_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
+    if (pred->op < 0 || pred->op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", pred->op);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    const uint32_t grid = stream_grid(ctx, n_rows, OP_THREADS * 8);
+    GOLAP_TRY(ws_begin(ctx, (uint64_t)grid * 32 + 4096, st));
+    double* partials = (double*)ws_take(ctx, (uint64_t)grid * 32);
+    double* out4 = (double*)ws_take(ctx, 32);
+    if (!partials || !out4) return fail(ctx, GOLAP_ERR_OOM, "workspace exhausted");
+    {
+        KernelTimer t(ctx, "filter_sum", st, 16 * n_rows);
+        if (value_is_f64)
+            hipLaunchKernelGGL((k_reduce_partials<true, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)key_column_ptr,
+                               (const void*)value_column_ptr, (unsigned long long)n_rows, pred->op, (long long)pred->literal, partials);
+        else
+            hipLaunchKernelGGL((k_reduce_partials<false, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)key_column_ptr,
+                               (const void*)value_column_ptr, (unsigned long long)n_rows, pred->op, (long long)pred->literal, partials);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, grid, out4);
+    }
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)out_ptr, out4, 16, hipMemcpyDeviceToDevice, st));   // sum, kept-count
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
+int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, void* stream) {
+    if (!ctx || !p || (n_specs && !specs)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (n_specs == 0) return GOLAP_OK;
+    if (!p->out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_ptr is null");
+    if (p->n_groups == 0) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_groups must be >= 1");
+    if (!p->group_key_ptr && p->n_groups != 1) return fail(ctx, GOLAP_ERR_INVALID_ARG, "ungrouped aggregate needs n_groups == 1");
+    if (p->key_dtype != GOLAP_DT_INT64 && p->key_dtype != GOLAP_DT_INT32) return fail(ctx, GOLAP_ERR_INVALID_ARG, "key_dtype must be INT64 or INT32");
+    for (uint32_t i = 0; i < n_specs; ++i) {
+        if (specs[i].func < GOLAP_AGG_SUM || specs[i].func > GOLAP_AGG_AVG) return fail(ctx, GOLAP_ERR_INVALID_ARG, "spec %u: bad func %d", i, specs[i].func);
+        if (specs[i].value_col_index >= p->n_value_cols) return fail(ctx, GOLAP_ERR_INVALID_ARG, "spec %u: value_col_index out of range", i);
+        if (specs[i].output_col_index >= n_specs) return fail(ctx, GOLAP_ERR_INVALID_ARG, "spec %u: output_col_index out of range", i);
+    }
+    if (p->n_rows && !p->value_ptrs) return fail(ctx, GOLAP_ERR_INVALID_ARG, "value_ptrs is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    const uint32_t G = p->n_groups;
+    const bool grouped = p->group_key_ptr != 0;
+    // LDS path when the 28-byte-per-group table fits comfortably (2 work-groups per CU)
+    const bool lds_path = grouped && (uint64_t)G * 28 <= 64 * 1024;
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    uint32_t lds_grid = 0;
+    uint64_t rows_per_block = 0;
+    if (lds_path) {
+        lds_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 2, ceil_div(std::max<uint64_t>(1, p->n_rows), 4096)));
+        rows_per_block = ceil_div(std::max<uint64_t>(1, p->n_rows), lds_grid);
+    }
+    const uint32_t red_grid = stream_grid(ctx, p->n_rows, OP_THREADS * 8);
+    uint64_t ws = (uint64_t)G * 32 + 8192;
+    ws += lds_path ? (uint64_t)lds_grid * 4 * G * 8 : 0;
+    ws += grouped ? 0 : (uint64_t)red_grid * 32;
+    GOLAP_TRY(ws_begin(ctx, ws + 4096, st));
+    double* stats4 = (double*)ws_take(ctx, (uint64_t)G * 32);
+    double* slab = lds_path ? (double*)ws_take(ctx, (uint64_t)lds_grid * 4 * G * 8) : nullptr;
+    double* partials = grouped ? nullptr : (double*)ws_take(ctx, (uint64_t)red_grid * 32);
+    if (!stats4 || (lds_path && !slab) || (!grouped && !partials)) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted");
+    if (lds_path) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<int, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<int, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<long long, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<long long, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr_done = true;
+        }
+    }
+    // one pass per distinct value column; every spec on that column is finalised from the same stats
+    for (uint32_t col = 0; col < p->n_value_cols; ++col) {
+        bool used = false, need_minmax = false;
+        for (uint32_t i = 0; i < n_specs; ++i)
+            if (specs[i].value_col_index == col) { used = true; need_minmax = need_minmax || specs[i].func == GOLAP_AGG_MIN || specs[i].func == GOLAP_AGG_MAX; }
+        if (!used) continue;
+        const int32_t vdt = p->value_dtypes ? p->value_dtypes[col] : GOLAP_DT_INT64;
+        if (vdt != GOLAP_DT_INT64 && vdt != GOLAP_DT_FLOAT64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "value column %u: dtype must be INT64 or FLOAT64", col);
+        const bool vf = vdt == GOLAP_DT_FLOAT64;
+        const void* val = p->n_rows ? (const void*)p->value_ptrs[col] : nullptr;
+        if (p->n_rows && !val) return fail(ctx, GOLAP_ERR_INVALID_ARG, "value column %u is null", col);
+        const uint64_t key_bytes = grouped ? (p->key_dtype == GOLAP_DT_INT32 ? 4 : 8) : 0;
+        if (!grouped) {
+            KernelTimer t(ctx, "aggregate_ungrouped", st, 8 * p->n_rows);
+            if (vf) hipLaunchKernelGGL((k_reduce_partials<true, false>), dim3(red_grid), dim3(OP_THREADS), 0, st, (const long long*)nullptr, val,
+                                       (unsigned long long)p->n_rows, 0, 0ll, partials);
+            else hipLaunchKernelGGL((k_reduce_partials<false, false>), dim3(red_grid), dim3(OP_THREADS), 0, st, (const long long*)nullptr, val,
+                                    (unsigned long long)p->n_rows, 0, 0ll, partials);
+            hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, red_grid, stats4);
+        } else if (lds_path) {
+            const size_t lds = (size_t)G * 28 + 16;
+            {
+                KernelTimer t(ctx, "hash_aggregate_lds", st, (key_bytes + 8) * p->n_rows + 12ull * G);
+                if (p->key_dtype == GOLAP_DT_INT32) {
+                    if (vf) hipLaunchKernelGGL((k_group_lds<int, true>), dim3(lds_grid), dim3(512), lds, st, (const int*)p->group_key_ptr, val,
+                                               (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
+                    else hipLaunchKernelGGL((k_group_lds<int, false>), dim3(lds_grid), dim3(512), lds, st, (const int*)p->group_key_ptr, val,
+                                            (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
+                } else {
+                    if (vf) hipLaunchKernelGGL((k_group_lds<long long, true>), dim3(lds_grid), dim3(512), lds, st, (const long long*)p->group_key_ptr, val,
+                                               (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
+                    else hipLaunchKernelGGL((k_group_lds<long long, false>), dim3(lds_grid), dim3(512), lds, st, (const long long*)p->group_key_ptr, val,
+                                            (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
+                }
+            }
+            {
+                KernelTimer t(ctx, "hash_aggregate_fold", st, 0);
+                hipLaunchKernelGGL(k_group_fold, dim3((uint32_t)ceil_div(G, OP_THREADS)), dim3(OP_THREADS), 0, st, slab, lds_grid, G, stats4);
+            }
+        } else {
+            hipLaunchKernelGGL(k_group_init, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, stats4, G);
+            KernelTimer t(ctx, "hash_aggregate_global", st, (key_bytes + 8) * p->n_rows + 12ull * G);
+            const uint32_t grid = stream_grid(ctx, p->n_rows, OP_THREADS * 4);
+            if (p->key_dtype == GOLAP_DT_INT32) {
+                if (vf) hipLaunchKernelGGL((k_group_global<int, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, val,
+                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+                else hipLaunchKernelGGL((k_group_global<int, false>), dim3(grid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, val,
+                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+            } else {
+                if (vf) hipLaunchKernelGGL((k_group_global<long long, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, val,
+                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+                else hipLaunchKernelGGL((k_group_global<long long, false>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, val,
+                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+            }
+        }
+        const uint32_t fg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS)));
+        for (uint32_t i = 0; i < n_specs; ++i) {
+            if (specs[i].value_col_index != col) continue;
+            SpecDev sd{specs[i].func, (uint32_t)specs[i].output_col_index};
+            hipLaunchKernelGGL(k_finalize_specs, dim3(fg), dim3(OP_THREADS), 0, st, stats4, G, sd, (double*)p->out_ptr);
+        }
+        if (p->out_count_ptr) hipLaunchKernelGGL(k_counts_from_stats, dim3(fg), dim3(OP_THREADS), 0, st, stats4, G, (unsigned long long*)p->out_count_ptr);
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
+int32_t golap_widen_to_8byte(golap_ctx* ctx, uint64_t in_ptr, int32_t in_dtype, uint64_t validity_ptr, uint64_t n_rows, uint64_t out_ptr, void* stream) {
+    if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
+    if (n_rows == 0) return GOLAP_OK;
+    if (!in_ptr || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    const dim3 g(stream_grid(ctx, n_rows, OP_THREADS * 4)), b(OP_THREADS);
+    const uint8_t* v = (const uint8_t*)validity_ptr;
+    const unsigned long long n = n_rows;
+    KernelTimer t(ctx, "widen_to_8byte", st, 9 * n_rows);
+    switch (in_dtype) {
+        case GOLAP_WIDEN_I8: hipLaunchKernelGGL((k_widen<int8_t, long long>), g, b, 0, st, (const int8_t*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_I16: hipLaunchKernelGGL((k_widen<int16_t, long long>), g, b, 0, st, (const int16_t*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_I32: hipLaunchKernelGGL((k_widen<int32_t, long long>), g, b, 0, st, (const int32_t*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_I64: hipLaunchKernelGGL((k_widen<long long, long long>), g, b, 0, st, (const long long*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_U8: hipLaunchKernelGGL((k_widen<uint8_t, long long>), g, b, 0, st, (const uint8_t*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_U16: hipLaunchKernelGGL((k_widen<uint16_t, long long>), g, b, 0, st, (const uint16_t*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_U32: hipLaunchKernelGGL((k_widen<uint32_t, long long>), g, b, 0, st, (const uint32_t*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_U64: hipLaunchKernelGGL((k_widen<unsigned long long, long long>), g, b, 0, st, (const unsigned long long*)in_ptr, v, n, (long long*)out_ptr); break;
+        case GOLAP_WIDEN_F32: hipLaunchKernelGGL((k_widen<float, double>), g, b, 0, st, (const float*)in_ptr, v, n, (double*)out_ptr); break;
+        case GOLAP_WIDEN_F64: hipLaunchKernelGGL((k_widen<double, double>), g, b, 0, st, (const double*)in_ptr, v, n, (double*)out_ptr); break;
+        default: return fail(ctx, GOLAP_ERR_INVALID_ARG, "unsupported column type for GPU conversion: %d", in_dtype);   // record_batch_convert.rs:98
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+int32_t golap_generate(golap_ctx* ctx, int32_t kind, uint64_t seed, uint64_t first, uint64_t count, uint64_t modulus, uint64_t out_ptr, void* stream) {
+    if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
+    if (count == 0) return GOLAP_OK;
+    if (!out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null out_ptr");
+    if (kind < GOLAP_GEN_BUILD_KEYS || kind > GOLAP_GEN_SHIFT32_I64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad generator kind %d", kind);
+    if (kind != GOLAP_GEN_SHIFT32_I64 && modulus == 0) return fail(ctx, GOLAP_ERR_INVALID_ARG, "modulus must be > 0");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    hipLaunchKernelGGL(k_generate, dim3(stream_grid(ctx, count, OP_THREADS * 4)), dim3(OP_THREADS), 0, st, kind, (unsigned long long)seed,
+                       (unsigned long long)first, (unsigned long long)count, (unsigned long long)modulus, (void*)out_ptr);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+int32_t golap_verify_pairs(golap_ctx* ctx, uint64_t pairs_ptr, uint64_t n_pairs, uint64_t build_key_ptr, uint64_t probe_key_ptr, uint32_t build_rid_base,
+                           uint32_t probe_rid_base, uint64_t out_ptr, void* stream) {
+    if (!ctx || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (n_pairs && (!pairs_ptr || !build_key_ptr || !probe_key_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)out_ptr, 0, 32, st));
+    if (n_pairs == 0) return GOLAP_OK;
+    hipLaunchKernelGGL(k_verify_pairs, dim3(stream_grid(ctx, n_pairs, OP_THREADS * 4)), dim3(OP_THREADS), 0, st, (const uint2*)pairs_ptr,
+                       (unsigned long long)n_pairs, (const long long*)build_key_ptr, (const long long*)probe_key_ptr, build_rid_base, probe_rid_base,
+                       (unsigned long long*)out_ptr);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+"""Device-level host API: a thin, typed wrapper over the C ABI for torch device tensors.
+
+Mirrors the reference's kernel-wrapper crate (gpu-kernel-compiler/src): JoinKernel,
+AggregateKernel, FilterKernel plus the memory manager (SlabAllocator, TransferQueue).
+torch is only used for device memory and streams -- all compute is in libgolap_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from ._native import GolapError  # noqa: F401
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_tensor(t, dtype, name, n=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if n is not None and t.numel() < n:
+        raise ValueError(f"{name} has {t.numel()} elements, need {n}")
+
+
+def choose_strategy(n_build):
+    """JoinKernel::choose_strategy, join_kernel.rs:71-77."""
+    return N.load().golap_choose_strategy(n_build)
+
+
+def compute_launch_params(n_rows):
+    """FilterKernel::compute_launch_params, filter_kernel.rs:75-79."""
+    g, b = C.c_uint32(0), C.c_uint32(0)
+    N.load().golap_compute_launch_params(n_rows, C.byref(g), C.byref(b))
+    return g.value, b.value
+
+
+def agg_identity_value(func):
+    """AggFunc::identity_value, aggregate_kernel.rs:27-33."""
+    return N.load().golap_agg_identity_value(func)
+
+
+def parse_cmp_op(op):
+    """executor.rs:457-465 operator spellings."""
+    return N.load().golap_parse_cmp_op(op.encode())
+
+
+def default_config():
+    cfg = N.EngineConfig()
+    N.load().golap_engine_config_default(C.byref(cfg))
+    return cfg
+
+
+class Context:
+    """One golap_ctx on the current torch device (one process per GPU)."""
+
+    def __init__(self, config=None, profiling=False, max_gpu_memory=None):
+        self._lib = N.load()
+        if not torch.cuda.is_available():
+            raise GolapError(N.ERR_NO_DEVICE, "no HIP device visible to torch; this package has no CPU fallback")
+        cfg = config if config is not None else default_config()
+        cfg.device_id = torch.cuda.current_device()
+        if profiling:
+            cfg.enable_profiling = 1
+        if max_gpu_memory is not None:
+            cfg.max_gpu_memory = max_gpu_memory
+        self.config = cfg
+        h = C.c_void_p()
+        st = self._lib.golap_ctx_create(C.byref(cfg), C.byref(h))
+        N.check(None, st)
+        self._h = h
+        self.device = torch.device("cuda", cfg.device_id)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.golap_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, status):
+        N.check(self._h, status)
+
+    # ---- info / stats ------------------------------------------------------
+    def device_info(self):
+        d = N.DeviceInfo()
+        self._ck(self._lib.golap_device_info_get(self._h, C.byref(d)))
+        return {f: (getattr(d, f).decode() if isinstance(getattr(d, f), bytes) else getattr(d, f)) for f, _ in d._fields_}
+
+    def stats(self):
+        s = N.Stats()
+        self._ck(self._lib.golap_stats_get(self._h, C.byref(s)))
+        out = {}
+        for i in range(s.n):
+            k = s.k[i]
+            out[k.name.decode()] = {"launches": k.launches, "total_ms": k.total_ms, "bytes": k.bytes}
+        return out
+
+    def stats_reset(self):
+        self._ck(self._lib.golap_stats_reset(self._h))
+
+    def join_plan(self, n_build, n_owners=1):
+        p = N.JoinPlan()
+        self._ck(self._lib.golap_join_plan_get(self._h, n_build, n_owners, C.byref(p)))
+        return {f: getattr(p, f) for f, _ in p._fields_}
+
+    def join_scratch_bytes(self, n_build, n_probe):
+        return self._lib.golap_join_scratch_bytes(self._h, n_build, n_probe)
+
+    # ---- SlabAllocator / TransferQueue ------------------------------------------
+    def slab_alloc(self, size):
+        p, c = C.c_uint64(0), C.c_uint32(0)
+        self._ck(self._lib.golap_slab_alloc(self._h, size, C.byref(p), C.byref(c)))
+        return p.value, c.value
+
+    def slab_free(self, ptr, class_idx):
+        self._ck(self._lib.golap_slab_free(self._h, ptr, class_idx))
+
+    def slab_stats(self):
+        s = N.SlabStats()
+        self._ck(self._lib.golap_slab_get_stats(self._h, C.byref(s)))
+        return {"class_size": list(s.class_size)[:s.n_classes], "allocated": list(s.allocated)[:s.n_classes],
+                "pooled": list(s.pooled)[:s.n_classes], "bytes_reserved": s.bytes_reserved}
+
+    def xfer_enqueue(self, direction, src, dst, size, stream_id=0):
+        self._ck(self._lib.golap_xfer_enqueue(self._h, direction, src, dst, size, stream_id))
+
+    def xfer_synchronize(self):
+        self._ck(self._lib.golap_xfer_synchronize(self._h))
+
+    # ---- GpuFilter ------------------------------------------------------------
+    def filter_mask(self, column, op, literal):
+        """FilterKernel::launch -> u8 mask (1 = pass)."""
+        _chk_tensor(column, torch.int64, "column")
+        n = column.numel()
+        mask = torch.empty(n, dtype=torch.uint8, device=column.device)
+        pred = N.FilterPredicate(0, op if isinstance(op, int) else parse_cmp_op(op), int(literal))
+        g, b = compute_launch_params(n)
+        prm = N.FilterParams(_ptr(column), n, _ptr(mask), g, b)
+        self._ck(self._lib.golap_filter_launch(self._h, C.byref(pred), C.byref(prm), _stream()))
+        return mask
+
+    def filter_compact(self, column, op, literal):
+        """-> (indices u32 as int32 tensor view [n], count tensor u64 as int64[1]); indices[:count] are valid."""
+        _chk_tensor(column, torch.int64, "column")
+        n = column.numel()
+        idx = torch.empty(max(n, 1), dtype=torch.int32, device=column.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=column.device)
+        pred = N.FilterPredicate(0, op if isinstance(op, int) else parse_cmp_op(op), int(literal))
+        self._ck(self._lib.golap_filter_compact(self._h, C.byref(pred), _ptr(column), n, _ptr(idx), _ptr(cnt), _stream()))
+        return idx, cnt
+
+    def take(self, column, indices, count=None, n_max=None):
+        if column.element_size() != 8:
+            raise TypeError("take: 8-byte columns only (executor.rs:496-507)")
+        n_max = indices.numel() if n_max is None else n_max
+        out = torch.empty(n_max, dtype=column.dtype, device=column.device)
+        self._ck(self._lib.golap_take_8byte(self._h, _ptr(column), _ptr(indices), _ptr(count), n_max, _ptr(out), _stream()))
+        return out
+
+    def filter_sum(self, key_column, value_column, op, literal):
+        """-> f64[2] device tensor: (sum of kept values as f64, kept rows)."""
+        _chk_tensor(key_column, torch.int64, "key_column")
+        n = key_column.numel()
+        if value_column.dtype not in (torch.int64, torch.float64) or value_column.numel() < n:
+            raise TypeError("value_column must be int64/float64 with >= n rows")
+        out = torch.zeros(2, dtype=torch.float64, device=key_column.device)
+        pred = N.FilterPredicate(0, op if isinstance(op, int) else parse_cmp_op(op), int(literal))
+        self._ck(self._lib.golap_filter_sum(self._h, C.byref(pred), _ptr(key_column), _ptr(value_column),
+                                            1 if value_column.dtype == torch.float64 else 0, n, _ptr(out), _stream()))
+        return out
+
+    # ---- GpuHashJoin ------------------------------------------------------------
+    def join(self, build_keys, probe_keys, out_pairs=None, max_pairs=None, strategy=None, build_rid_base=0, probe_rid_base=0,
+             out_count=None):
+        """JoinKernel::join.  -> (pairs int32[max_pairs,2] holding u32 (build_rid, probe_rid), count int64[1] device).
+
+        Pair order is unspecified; the count keeps counting past max_pairs (join_kernels.cuh:155-160).
+        """
+        _chk_tensor(build_keys, torch.int64, "build_keys")
+        _chk_tensor(probe_keys, torch.int64, "probe_keys")
+        nb, npr = build_keys.numel(), probe_keys.numel()
+        if strategy is None:
+            strategy = choose_strategy(nb)
+        if out_pairs is None:
+            max_pairs = npr if max_pairs is None else max_pairs
+            out_pairs = torch.empty((max(max_pairs, 1), 2), dtype=torch.int32, device=build_keys.device)
+        else:
+            _chk_tensor(out_pairs, torch.int32, "out_pairs")
+            max_pairs = out_pairs.numel() // 2 if max_pairs is None else max_pairs
+        if out_count is None:
+            out_count = torch.zeros(1, dtype=torch.int64, device=build_keys.device)
+        prm = N.JoinParams(_ptr(build_keys), _ptr(probe_keys), nb, npr, _ptr(out_pairs), _ptr(out_count), max_pairs,
+                           build_rid_base, probe_rid_base)
+        self._ck(self._lib.golap_join(self._h, strategy, C.byref(prm), _stream()))
+        return out_pairs, out_count
+
+    def radix_partition(self, keys, row_ids=None, rid_base=0, n_owners=1, out_keys=None, out_rids=None):
+        """radix_partition_kernel as a stand-alone step -> (keys, row_ids(int32 view of u32), offsets int32[257] by slot)."""
+        _chk_tensor(keys, torch.int64, "keys")
+        n = keys.numel()
+        if out_keys is None:
+            out_keys = torch.empty(max(n, 1), dtype=torch.int64, device=keys.device)
+        if out_rids is None:
+            out_rids = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device)
+        offs = torch.zeros(257, dtype=torch.int32, device=keys.device)
+        prm = N.PartitionParams(_ptr(keys), _ptr(row_ids), n, rid_base, n_owners, _ptr(out_keys), _ptr(out_rids), _ptr(offs))
+        self._ck(self._lib.golap_radix_partition(self._h, C.byref(prm), _stream()))
+        return out_keys, out_rids, offs
+
+    def join_partitioned(self, b_keys, b_rids, b_seg_off, b_seg_len, p_keys, p_rids, p_seg_off, p_seg_len, n_slots, n_sources,
+                         out_pairs, total_build_rows_hint=0, b_rows=None, p_rows=None, out_count=None):
+        """Join of radix-partitioned (post-exchange) inputs; seg_off/seg_len: host sequences [n_slots*n_sources]."""
+        nseg = n_slots * n_sources
+        arr = C.c_uint64 * nseg
+        bo, bl, po, pl = arr(*b_seg_off), arr(*b_seg_len), arr(*p_seg_off), arr(*p_seg_len)
+        if out_count is None:
+            out_count = torch.zeros(1, dtype=torch.int64, device=b_keys.device)
+        b = N.PartitionedSide(_ptr(b_keys), _ptr(b_rids), b_keys.numel() if b_rows is None else b_rows, bo, bl)
+        p = N.PartitionedSide(_ptr(p_keys), _ptr(p_rids), p_keys.numel() if p_rows is None else p_rows, po, pl)
+        prm = N.JoinPartitionedParams(b, p, n_slots, n_sources, total_build_rows_hint, _ptr(out_pairs), _ptr(out_count),
+                                      out_pairs.numel() // 2)
+        self._ck(self._lib.golap_join_partitioned(self._h, C.byref(prm), _stream()))
+        return out_pairs, out_count
+
+    # ---- GpuAggregate -----------------------------------------------------------
+    def aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False):
+        """AggregateKernel::aggregate.
+
+        specs  : list of (func, value_col_index) -- output plane i belongs to specs[i]
+        values : list of int64/float64 device tensors
+        -> f64[n_specs, n_groups] (and u64 counts as int64[n_groups] when want_counts)
+        """
+        dev = values[0].device
+        n_rows = values[0].numel()
+        nv = len(values)
+        vptrs = (C.c_uint64 * nv)(*[_ptr(v) for v in values])
+        vdt = (C.c_int32 * nv)(*[N.DT_FLOAT64 if v.dtype == torch.float64 else N.DT_INT64 for v in values])
+        for v in values:
+            if v.dtype not in (torch.int64, torch.float64):
+                raise TypeError("aggregate inputs must be int64 or float64 (executor.rs:520-526)")
+            if v.numel() != n_rows:
+                raise ValueError("value columns differ in length")
+        sp = (N.AggregateSpec * len(specs))(*[N.AggregateSpec(f, c, i) for i, (f, c) in enumerate(specs)])
+        out = torch.zeros((len(specs), n_groups), dtype=torch.float64, device=dev)
+        counts = torch.zeros(n_groups, dtype=torch.int64, device=dev) if want_counts else None
+        kd = N.DT_INT64
+        if group_keys is not None:
+            if group_keys.dtype == torch.int32:
+                kd = N.DT_INT32
+            elif group_keys.dtype != torch.int64:
+                raise TypeError("group keys must be int32 or int64")
+            if group_keys.numel() != n_rows:
+                raise ValueError("group key column differs in length")
+        prm = N.AggregateParams(_ptr(group_keys), vptrs, nv, n_rows, n_groups, _ptr(out), kd, vdt, _ptr(counts))
+        self._ck(self._lib.golap_aggregate(self._h, sp, len(specs), C.byref(prm), _stream()))
+        return (out, counts) if want_counts else out
+
+    # ---- arrow-interop widening ----------------------------------------------------
+    _WIDEN = {torch.int8: N.WIDEN_I8, torch.int16: N.WIDEN_I16, torch.int32: N.WIDEN_I32, torch.int64: N.WIDEN_I64,
+              torch.uint8: N.WIDEN_U8, torch.float32: N.WIDEN_F32, torch.float64: N.WIDEN_F64}
+
+    def widen(self, column, validity=None, in_dtype=None):
+        code = self._WIDEN[column.dtype] if in_dtype is None else in_dtype
+        out_dt = torch.float64 if code in (N.WIDEN_F32, N.WIDEN_F64) else torch.int64
+        out = torch.empty(column.numel(), dtype=out_dt, device=column.device)
+        self._ck(self._lib.golap_widen_to_8byte(self._h, _ptr(column), code, _ptr(validity), column.numel(), _ptr(out), _stream()))
+        return out
+
+    # ---- generators / verifier ---------------------------------------------------
+    def generate(self, kind, count, modulus=1, seed=0, first=0, out=None):
+        dt = {N.GEN_BUILD_KEYS: torch.int64, N.GEN_SM64_MOD_I64: torch.int64, N.GEN_SM64_MOD_I32: torch.int32,
+              N.GEN_SM64_MOD_F64: torch.float64, N.GEN_SHIFT32_I64: torch.int64}[kind]
+        if out is None:
+            out = torch.empty(count, dtype=dt, device=self.device)
+        self._ck(self._lib.golap_generate(self._h, kind, seed, first, count, modulus, _ptr(out), _stream()))
+        return out
+
+    def verify_pairs(self, pairs, n_pairs, build_keys, probe_keys, build_rid_base=0, probe_rid_base=0):
+        """-> int64[4] device: equal-key pairs, checksum, sum of probe ids, xor of mixed probe ids (u64 bit patterns)."""
+        out = torch.zeros(4, dtype=torch.int64, device=pairs.device)
+        self._ck(self._lib.golap_verify_pairs(self._h, _ptr(pairs), n_pairs, _ptr(build_keys), _ptr(probe_keys),
+                                              build_rid_base, probe_rid_base, _ptr(out), _stream()))
+        return out
+
+    def synchronize(self):
+        self._ck(self._lib.golap_ctx_synchronize(self._h, _stream()))

@@ -1,0 +1,322 @@
+/* golap.h -- C ABI of the MI355X-native GpuHashJoin / GpuAggregate / GpuFilter path.
+ *
+ * Drop-in boundary for codebasecomprehension987/gpu-olap-engine: every entry
+ * point below replaces one interface of the reference's (never-launched) kernel
+ * wrapper / memory-manager crates; the reference file:line it replaces is cited
+ * on each declaration (paths relative to the reference root).  A Rust host binds
+ * this header with a plain `extern "C"` block.
+ *
+ * Conventions
+ *   - plain pointers / sizes only; device addresses travel as uint64_t exactly
+ *     like the reference's param structs (join_kernel.rs:20-27).
+ *   - every call returns int32 status (GOLAP_OK == 0); golap_last_error() gives
+ *     the message.  Nothing throws or aborts across the ABI (the reference uses
+ *     anyhow::Result everywhere).
+ *   - the caller owns input and output buffers; the library owns only its
+ *     context, slabs and scratch.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the context's own stream).
+ *     Calls are asynchronous on that stream unless stated otherwise.
+ *   - there is NO CPU fallback: without a HIP device every compute call fails
+ *     with GOLAP_ERR_NO_DEVICE.
+ */
+#ifndef GOLAP_H
+#define GOLAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOLAP_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    GOLAP_OK = 0,
+    GOLAP_ERR_INVALID_ARG = 1,
+    GOLAP_ERR_NO_DEVICE = 2,
+    GOLAP_ERR_HIP = 3,
+    GOLAP_ERR_OOM = 4,          /* slab class exhausted / size above largest class */
+    GOLAP_ERR_UNSUPPORTED = 5,  /* e.g. SortMergeJoin: out of scope */
+    GOLAP_ERR_CAPACITY = 6      /* informational: join produced more pairs than max_pairs */
+};
+
+typedef struct golap_ctx golap_ctx;
+
+/* ---- context / config ---------------------------------------------------
+ * Mirrors EngineConfig, gpu-olap-core/src/lib.rs:20-31 (defaults :33-43),
+ * plus the device/radix fields the survey adds (SURVEY 8(b) "Config"). */
+typedef struct golap_engine_config {
+    uint64_t max_gpu_memory;     /* lib.rs:22  default 8 GiB (0 = no cap)       */
+    uint32_t num_streams;        /* lib.rs:24  default 8                        */
+    uint32_t use_unified_memory; /* lib.rs:26  default 1 (accepted, unused)     */
+    uint64_t batch_size;         /* lib.rs:28  default 1 Mi rows                */
+    uint32_t enable_cache;       /* lib.rs:30  default 1 (accepted, unused)     */
+    int32_t  device_id;          /* HIP ordinal; -1 = current device            */
+    uint32_t radix_bits;         /* join_kernels.cuh:22  RADIX_BITS = 8         */
+    uint32_t enable_profiling;   /* 1 = record per-kernel hipEvents (golap_stats) */
+} golap_engine_config;
+
+void    golap_engine_config_default(golap_engine_config* cfg);
+int32_t golap_ctx_create(const golap_engine_config* cfg, golap_ctx** out_ctx);
+void    golap_ctx_destroy(golap_ctx* ctx);
+/* ctx may be NULL: returns the calling thread's last error. */
+const char* golap_last_error(const golap_ctx* ctx);
+uint32_t golap_abi_version(void);
+
+typedef struct golap_device_info {
+    char     name[128];
+    char     gcn_arch[64];
+    uint32_t compute_units;
+    uint32_t lds_bytes_per_block;
+    uint32_t wavefront_size;
+    uint32_t clock_mhz;
+    uint32_t memory_clock_mhz;
+    uint32_t memory_bus_bits;
+    uint64_t total_mem_bytes;
+    uint64_t free_mem_bytes;
+    uint32_t l2_bytes;
+} golap_device_info;
+int32_t golap_device_info_get(golap_ctx* ctx, golap_device_info* out);
+int32_t golap_ctx_synchronize(golap_ctx* ctx, void* stream);
+
+/* ---- SlabAllocator -------------------------------------------------------
+ * gpu-memory-manager/src/slab_allocator.rs: new :25-47, allocate :50-68,
+ * free :71-93, find_slab_class :95-107.  Size classes 1/4/16/64/256 MiB
+ * (README.md:142) extended with 1/4/16/64 GiB classes so an 8 GB column fits
+ * (the reference's top class would reject it).  Unlike the reference
+ * (which leaks, :146) slabs beyond the pool limit are really hipFree'd. */
+int32_t golap_slab_alloc(golap_ctx* ctx, uint64_t size, uint64_t* out_ptr, uint32_t* out_class_idx);
+int32_t golap_slab_free(golap_ctx* ctx, uint64_t ptr, uint32_t class_idx);
+typedef struct golap_slab_stats {
+    uint32_t n_classes;
+    uint64_t class_size[16];
+    uint32_t allocated[16];   /* live + pooled, slab_allocator.rs:21 allocated_count */
+    uint32_t pooled[16];      /* free_slabs.len()                                     */
+    uint64_t bytes_reserved;
+} golap_slab_stats;
+int32_t golap_slab_get_stats(golap_ctx* ctx, golap_slab_stats* out);
+
+/* ---- TransferQueue -------------------------------------------------------
+ * gpu-memory-manager/src/transfer_queue.rs: TransferDirection :10-13,
+ * enqueue_transfer :55-79 (stream_id % num_streams, :72), synchronize :133-139.
+ * Really copies (hipMemcpyAsync); pageable host memory is staged through two
+ * pinned bounce buffers per stream (double buffering). */
+enum { GOLAP_HOST_TO_DEVICE = 0, GOLAP_DEVICE_TO_HOST = 1 };
+int32_t golap_xfer_enqueue(golap_ctx* ctx, int32_t direction, uint64_t src, uint64_t dst, uint64_t size, uint32_t stream_id);
+int32_t golap_xfer_synchronize(golap_ctx* ctx);
+
+/* ---- GpuFilter -----------------------------------------------------------
+ * CmpOp / FilterPredicate: gpu-kernel-compiler/src/codegen.rs:11-28.
+ * FilterParams: filter_kernel.rs:17-28.  The NVRTC/PTX string of codegen.rs:36-47
+ * is replaced by ahead-of-time gfx950 kernels with `op` as a runtime argument. */
+typedef enum golap_cmp_op {
+    GOLAP_CMP_EQ = 0, GOLAP_CMP_NE = 1, GOLAP_CMP_LT = 2,
+    GOLAP_CMP_LE = 3, GOLAP_CMP_GT = 4, GOLAP_CMP_GE = 5,
+    GOLAP_CMP_NEVER = 6     /* executor.rs:464: unknown operator selects no row */
+} golap_cmp_op;
+/* "=", "==", "!=", "<>", ">", ">=", "<", "<=" as executor.rs:457-465; else NEVER. */
+golap_cmp_op golap_parse_cmp_op(const char* op);
+
+typedef struct golap_filter_predicate {   /* codegen.rs:24-28 */
+    uint64_t col_index;
+    int32_t  op;          /* golap_cmp_op */
+    int64_t  literal;
+} golap_filter_predicate;
+
+typedef struct golap_filter_params {      /* filter_kernel.rs:17-28 */
+    uint64_t column_ptr;    /* device, int64[n_rows] */
+    uint64_t n_rows;
+    uint64_t out_mask_ptr;  /* device, u8[n_rows], 1 = pass */
+    uint32_t grid_dim;      /* accepted for API parity; 0 = library chooses */
+    uint32_t block_dim;
+} golap_filter_params;
+
+/* filter_kernel.rs:75-79 (and aggregate_kernel.rs:127-131): block 256, grid ceil(n/256) >= 1 */
+void    golap_compute_launch_params(uint64_t n_rows, uint32_t* grid, uint32_t* block);
+/* FilterKernel::launch, filter_kernel.rs:42-72: writes the u8 mask. */
+int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, const golap_filter_params* params, void* stream);
+/* The "second compaction pass (prefix-sum + scatter)" of filter_kernel.rs:3-5,
+ * fused with the predicate: writes the ascending row indices of passing rows
+ * (original order, executor.rs:479-484) and their count (u64, device). */
+int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t n_rows,
+                             uint64_t out_indices_ptr /*u32[n_rows]*/, uint64_t out_count_ptr /*u64*/, void* stream);
+/* take_int64, executor.rs:496-507: out[i] = col[indices[i]] for 8-byte columns. */
+int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_ptr, uint64_t count_ptr /*u64 device, or 0*/,
+                         uint64_t n_indices_max, uint64_t out_ptr, void* stream);
+/* BASELINE config 1 shape: execute_filter (executor.rs:161-178) feeding
+ * execute_aggregate Sum (executor.rs:297-355) in one pass:
+ * out[0] = f64 sum of v[i] (value_is_f64 ? f64 : (f64)i64) over rows with k[i] <op> literal,
+ * out[1] = (f64) number of kept rows. */
+int32_t golap_filter_sum(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t key_column_ptr, uint64_t value_column_ptr,
+                         int32_t value_is_f64, uint64_t n_rows, uint64_t out_ptr /*f64[2] device*/, void* stream);
+
+/* ---- GpuHashJoin ---------------------------------------------------------
+ * JoinStrategy join_kernel.rs:14-18, JoinParams :20-27, JoinKernel::join :39-45,
+ * choose_strategy :71-77.  Device arithmetic: join_kernels.cuh:26-41 (hash),
+ * :45-76 (radix partition), :80-111 (build), :115-166 (probe). */
+typedef enum golap_join_strategy {
+    GOLAP_JOIN_RADIX_HASH = 0,
+    GOLAP_JOIN_SORT_MERGE = 1,      /* returns GOLAP_ERR_UNSUPPORTED (out of scope) */
+    GOLAP_JOIN_BROADCAST_HASH = 2
+} golap_join_strategy;
+golap_join_strategy golap_choose_strategy(uint64_t n_build);   /* join_kernel.rs:71-77 */
+
+typedef struct golap_join_params {
+    /* --- join_kernel.rs:20-27, same names and meaning --- */
+    uint64_t build_key_ptr;   /* device int64[n_build]  (left side, executor.rs:241) */
+    uint64_t probe_key_ptr;   /* device int64[n_probe]                               */
+    uint64_t n_build;
+    uint64_t n_probe;
+    uint64_t out_pairs_ptr;   /* device u32[2*max_pairs]: (build_row_id, probe_row_id) interleaved,
+                                 = left_matches/right_matches of join_kernels.cuh:125-126 */
+    uint64_t out_count_ptr;   /* device u64: TRUE match count; keeps counting past max_pairs
+                                 (join_kernels.cuh:155-160); zeroed by the call            */
+    /* --- extensions --- */
+    uint64_t max_pairs;       /* capacity of out_pairs in pairs (join_kernels.cuh:127 max_matches) */
+    uint32_t build_rid_base;  /* global row id of build row 0 (executor.rs:249 running offset)     */
+    uint32_t probe_rid_base;
+} golap_join_params;
+
+/* Inner join on int64 keys; row ids are 0-based positions + *_rid_base.  Pair
+ * order is unspecified (as in the reference, join_kernels.cuh:155); compare
+ * after sorting by (probe_row_id, build_row_id). */
+int32_t golap_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_join_params* params, void* stream);
+
+/* Scratch bytes golap_join(RadixHashJoin) will take from the slab allocator. */
+uint64_t golap_join_scratch_bytes(golap_ctx* ctx, uint64_t n_build, uint64_t n_probe);
+
+/* radix_partition_kernel, join_kernels.cuh:45-76, as a stand-alone step (pass 1
+ * of the radix join; also what each GPU runs before the xGMI partition exchange).
+ * Partition id = (hash_int64(key) >> 0) & 255 (:69).  Writes keys/row-ids grouped
+ * by partition and the 257 exclusive offsets.  With n_owners > 1 the partitions
+ * are laid out owner-major: partition p (owner p % n_owners) sits at slot
+ * (p % n_owners) * (256 / n_owners) + p / n_owners, so the rows bound for each
+ * peer GPU are one contiguous range.  out_offsets_ptr[s] is indexed by slot. */
+typedef struct golap_partition_params {
+    uint64_t key_ptr;          /* device int64[n_rows] */
+    uint64_t row_id_ptr;       /* device u32[n_rows] or 0 -> row id = rid_base + i (join_kernels.cuh:75) */
+    uint64_t n_rows;
+    uint32_t rid_base;
+    uint32_t n_owners;         /* 1, 2, 4, 8, ... divides 256 */
+    uint64_t out_key_ptr;      /* device int64[n_rows] */
+    uint64_t out_row_id_ptr;   /* device u32[n_rows]   */
+    uint64_t out_offsets_ptr;  /* device u32[257]      */
+} golap_partition_params;
+int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* params, void* stream);
+
+/* Join of already radix-partitioned inputs (after the partition exchange).
+ * Each side is described by n_slots * n_sources segments: segment (slot s,
+ * source r) holds the rows of local partition slot s that came from source r,
+ * seg_off/seg_len in rows, row-major [slot][source] HOST arrays. */
+typedef struct golap_partitioned_side {
+    uint64_t key_ptr;      /* device int64[] */
+    uint64_t row_id_ptr;   /* device u32[]   */
+    uint64_t n_rows;       /* total rows in the buffers */
+    const uint64_t* seg_off;   /* host [n_slots*n_sources] */
+    const uint64_t* seg_len;   /* host [n_slots*n_sources] */
+} golap_partitioned_side;
+typedef struct golap_join_partitioned_params {
+    golap_partitioned_side build, probe;
+    uint32_t n_slots;      /* local partitions (256 / n_owners) */
+    uint32_t n_sources;
+    uint64_t total_build_rows_hint;  /* global build rows / n_owners: sizes the sub-partition fan-out */
+    uint64_t out_pairs_ptr, out_count_ptr, max_pairs;
+} golap_join_partitioned_params;
+int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_params* params, void* stream);
+
+/* ---- GpuAggregate --------------------------------------------------------
+ * AggFunc + identity_value aggregate_kernel.rs:17-34, AggregateSpec :38-44,
+ * AggregateParams :47-58, AggregateKernel::aggregate :80-125. */
+typedef enum golap_agg_func {
+    GOLAP_AGG_SUM = 0, GOLAP_AGG_COUNT = 1, GOLAP_AGG_MIN = 2, GOLAP_AGG_MAX = 3, GOLAP_AGG_AVG = 4
+} golap_agg_func;
+int64_t golap_agg_identity_value(int32_t func);     /* aggregate_kernel.rs:27-33 */
+
+typedef struct golap_aggregate_spec {               /* aggregate_kernel.rs:38-44 */
+    int32_t  func;               /* golap_agg_func */
+    uint64_t value_col_index;    /* index into value_ptrs */
+    uint64_t output_col_index;   /* which [agg] plane of out_ptr */
+} golap_aggregate_spec;
+
+enum { GOLAP_DT_INT64 = 0, GOLAP_DT_FLOAT64 = 1, GOLAP_DT_INT32 = 2 };
+
+typedef struct golap_aggregate_params {             /* aggregate_kernel.rs:47-58 */
+    uint64_t group_key_ptr;      /* device; int64 (reference layout, :48) or int32 (BASELINE config 4); 0 = ungrouped */
+    const uint64_t* value_ptrs;  /* host array of device pointers, one per value column */
+    uint32_t n_value_cols;
+    uint64_t n_rows;
+    uint32_t n_groups;           /* upper bound on distinct groups (:54); keys must lie in [0, n_groups) (dense) */
+    uint64_t out_ptr;            /* device f64[n_specs][n_groups] : one 8-byte slot per group per agg (:56, :98) */
+    /* --- extensions --- */
+    int32_t  key_dtype;          /* GOLAP_DT_INT64 | GOLAP_DT_INT32 */
+    const int32_t* value_dtypes; /* host, per value column: GOLAP_DT_INT64 | GOLAP_DT_FLOAT64 */
+    uint64_t out_count_ptr;      /* device u64[n_groups] rows per group (0 = not wanted); groups with 0 rows are absent */
+} golap_aggregate_params;
+
+/* Results are f64 like the CPU path (executor.rs:330-349): SUM, COUNT (as f64),
+ * MIN, MAX, AVG (= sum/count, 0.0 for an empty group, executor.rs:339-345).
+ * Int64 inputs are converted `as f64` (executor.rs:521).  Ungrouped
+ * (group_key_ptr == 0, n_groups == 1) reproduces execute_aggregate. */
+int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs,
+                        const golap_aggregate_params* params, void* stream);
+
+/* ---- arrow-interop -------------------------------------------------------
+ * record_batch_convert.rs:35-110: numeric columns widened to 8-byte LE, nulls -> 0
+ * (validity = one byte per row, column_buffer.rs:59-60; 0 pointer = all valid). */
+int32_t golap_widen_to_8byte(golap_ctx* ctx, uint64_t in_ptr, int32_t in_dtype /*GOLAP_WIDEN_* */, uint64_t validity_ptr,
+                             uint64_t n_rows, uint64_t out_ptr, void* stream);
+enum { GOLAP_WIDEN_I8 = 0, GOLAP_WIDEN_I16, GOLAP_WIDEN_I32, GOLAP_WIDEN_I64, GOLAP_WIDEN_U8, GOLAP_WIDEN_U16,
+       GOLAP_WIDEN_U32, GOLAP_WIDEN_U64, GOLAP_WIDEN_F32, GOLAP_WIDEN_F64 };
+
+/* ---- synthetic generators --------------------
+ * Counter-based, so each GPU produces its own shard.  kind selects the formula. */
+enum {
+    GOLAP_GEN_BUILD_KEYS = 0,   /* int64: (2654435761*i + 12345) mod modulus              */
+    GOLAP_GEN_SM64_MOD_I64 = 1, /* int64: sm64(seed, i) mod modulus  (probe keys: seed 43) */
+    GOLAP_GEN_SM64_MOD_I32 = 2, /* int32                                                   */
+    GOLAP_GEN_SM64_MOD_F64 = 3, /* f64 (integer-valued)                                    */
+    GOLAP_GEN_SHIFT32_I64 = 4   /* int64: i << 32  (fold-collision keys)       */
+};
+int32_t golap_generate(golap_ctx* ctx, int32_t kind, uint64_t seed, uint64_t first, uint64_t count, uint64_t modulus,
+                       uint64_t out_ptr, void* stream);
+
+/* Order-independent verification of a pair list on the device (size-independent
+ * property check for the 1B-row runs): out[0] = number of pairs i < n_pairs whose
+ * keys are equal (build_keys[b - build_rid_base] == probe_keys[p - probe_rid_base]),
+ * out[1] = sum of pair_mix(b, p) mod 2^64, out[2] = sum of probe ids, out[3] = xor of mix(probe id). */
+int32_t golap_verify_pairs(golap_ctx* ctx, uint64_t pairs_ptr, uint64_t n_pairs, uint64_t build_key_ptr, uint64_t probe_key_ptr,
+                           uint32_t build_rid_base, uint32_t probe_rid_base, uint64_t out_ptr /*u64[4] device*/, void* stream);
+
+/* ---- stats ---------------------------------------------------------------
+ * Per-kernel accumulated device time (hipEvent pairs on the launch stream),
+ * collected when enable_profiling = 1.  golap_stats_get resolves pending
+ * events (synchronises them). */
+#define GOLAP_MAX_KERNEL_STATS 48
+typedef struct golap_kernel_stat {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;
+    uint64_t bytes;        /* algorithmic bytes credited to these launches */
+} golap_kernel_stat;
+typedef struct golap_stats {
+    uint32_t n;
+    golap_kernel_stat k[GOLAP_MAX_KERNEL_STATS];
+} golap_stats;
+int32_t golap_stats_get(golap_ctx* ctx, golap_stats* out);
+int32_t golap_stats_reset(golap_ctx* ctx);
+
+/* Plan the last join used (for DESIGN/bench reporting). */
+typedef struct golap_join_plan {
+    uint32_t bits1, bits2;        /* fan-out bits of pass 1 (>= radix_bits) and pass 2 */
+    uint32_t tile_rows, chunks1, slots2;
+    uint32_t table_capacity;      /* LDS hash-table rows per sub-partition */
+    uint64_t n_subpartitions;
+} golap_join_plan;
+int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners, golap_join_plan* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLAP_H */

@@ -1,0 +1,276 @@
+"""GPU parity tests for GpuHashJoin: the HIP path (through the C ABI) vs the CPU oracle,
+bit-exact on canonicalised row-id pairs (sorted by (probe_rid, build_rid))."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import oracle  # noqa: E402
+from gpu_olap_engine_amd import _native as N  # noqa: E402
+from np_twin import canonical  # noqa: E402
+
+STRATS = [N.JOIN_RADIX_HASH, N.JOIN_BROADCAST_HASH]
+
+
+def run_join(ctx, b, p, strategy, max_pairs=None, **kw):
+    bt = torch.from_numpy(np.ascontiguousarray(b, dtype=np.int64)).cuda()
+    pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)).cuda()
+    cap = max(1, (max_pairs if max_pairs is not None else 4 * max(len(b), len(p)) + 16))
+    pairs, cnt = ctx.join(bt, pt, max_pairs=cap, strategy=strategy, **kw)
+    torch.cuda.synchronize()
+    m = int(cnt.item())
+    got = pairs[:min(m, cap)].cpu().numpy().view(np.uint32)
+    return canonical(got), m
+
+
+def check(ctx, b, p, strategy, **kw):
+    got, m = run_join(ctx, b, p, strategy, **kw)
+    exp, me = oracle.hash_join(b, p, kw.get("build_rid_base", 0), kw.get("probe_rid_base", 0))
+    assert m == me, f"match count {m} != oracle {me}"
+    assert np.array_equal(got, exp)
+    return m
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_tiny_known_answer(ctx, strategy):
+    # hand-checkable: build [10,20,30,20], probe [20,5,30,20] -> (1,0),(3,0),(2,2),(1,3),(3,3)
+    got, m = run_join(ctx, [10, 20, 30, 20], [20, 5, 30, 20], strategy)
+    assert m == 5
+    assert got.tolist() == [[1, 0], [3, 0], [2, 2], [1, 3], [3, 3]]
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+@pytest.mark.parametrize("nb,npr", [(0, 0), (0, 5), (5, 0), (1, 1), (63, 65), (4097, 4095), (1000, 100000), (100000, 1000)])
+def test_empty_and_ragged(ctx, strategy, nb, npr):
+    rng = np.random.default_rng(nb * 7 + npr)
+    b = rng.integers(0, max(1, nb // 2 + 1), nb)
+    p = rng.integers(0, max(1, nb // 2 + 2), npr)
+    check(ctx, b, p, strategy)
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_config2_1m_unique(ctx, strategy):
+    """BASELINE config 2: 1M join 1M, unique build keys, every probe row matches exactly once."""
+    n = 1_000_000
+    b = oracle.gen_build_keys(0, n, n)
+    p = oracle.gen_probe_keys(0, n, n)
+    assert check(ctx, b, p, strategy) == n
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_duplicates_both_sides(ctx, strategy):
+    """dup variant (examples/python_usage.py:301-309): both sides sm64 mod N/2 -> E[M] ~ 2N."""
+    n = 300_000
+    b = oracle.gen_sm64_mod(11, 0, n, n // 2)
+    p = oracle.gen_sm64_mod(12, 0, n, n // 2)
+    m = check(ctx, b, p, strategy)
+    assert 1.8 * n < m < 2.2 * n
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_negative_and_extreme_keys(ctx, strategy):
+    rng = np.random.default_rng(5)
+    base = np.array([0, -1, 1, -2, 2**32, 2**32 + 1, -(2**63), 2**63 - 1, 42, -42], dtype=np.int64)
+    b = np.concatenate([base, rng.integers(-2**62, 2**62, 5000)])
+    p = np.concatenate([base[::-1], b[rng.integers(0, b.size, 5000)], rng.integers(-2**62, 2**62, 100)])
+    check(ctx, b, p, strategy)
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_fold_collision_keys(ctx, strategy):
+    """keys i<<32 all fold to the same hash_int64: one radix partition gets everything,
+    full-key compare must still separate them."""
+    n = 20_000
+    b = (np.arange(n, dtype=np.int64) << 32)
+    p = (np.arange(0, 2 * n, 2, dtype=np.int64) << 32)
+    m = check(ctx, b, p, strategy)
+    assert m == n // 2
+    assert len(set(oracle.hash_int64_array(b).tolist())) <= 2
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_heavy_skew_single_key(ctx, strategy):
+    """one hot key on both sides: M = nb_hot * np_hot, overflows the LDS table chunk and the probe batch."""
+    b = np.concatenate([np.full(5000, 7, np.int64), np.arange(100, 3100, dtype=np.int64)])
+    p = np.concatenate([np.full(300, 7, np.int64), np.arange(0, 2000, dtype=np.int64)])
+    m = check(ctx, b, p, strategy)
+    assert m >= 5000 * 300
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_rid_bases(ctx, strategy):
+    rng = np.random.default_rng(9)
+    b = rng.integers(0, 5000, 10000)
+    p = rng.integers(0, 5000, 12000)
+    check(ctx, b, p, strategy, build_rid_base=1_000_000, probe_rid_base=4_000_000_000)
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_capacity_overflow_keeps_counting(ctx, strategy):
+    """join_kernels.cuh:155-160: count is the TRUE total; nothing is written past max_pairs."""
+    rng = np.random.default_rng(3)
+    b = rng.integers(0, 1000, 20000)
+    p = rng.integers(0, 1000, 20000)
+    exp, me = oracle.hash_join(b, p)
+    bt, pt = torch.from_numpy(b).cuda(), torch.from_numpy(p).cuda()
+    cap = 1000
+    buf = torch.full((cap + 64, 2), -1, dtype=torch.int32, device="cuda")
+    pairs, cnt = ctx.join(bt, pt, out_pairs=buf, max_pairs=cap, strategy=strategy)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == me
+    host = buf.cpu().numpy()
+    assert (host[cap:] == -1).all(), "wrote past max_pairs"
+    got = host[:cap].view(np.uint32)
+    expset = set(map(tuple, exp.tolist()))
+    assert all(tuple(r) in expset for r in got.tolist())
+    assert len(set(map(tuple, got.tolist()))) == cap
+
+
+def test_radix_multi_pass_16m(ctx):
+    """16M join 16M forces two partition passes (sub-partitions must fit the LDS table)."""
+    n = 16_000_000
+    plan = ctx.join_plan(n)
+    assert plan["bits2"] > 0
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    pairs, cnt = ctx.join(bt, pt, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
+    torch.cuda.synchronize()
+    m = int(cnt.item())
+    assert m == n
+    exp, me = oracle.hash_join(bt.cpu().numpy(), pt.cpu().numpy())
+    got = canonical(pairs[:m].cpu().numpy().view(np.uint32))
+    assert me == n and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("bits", ["8,4,4", "10,6", "8,7"])
+def test_forced_pass_structures(ctx, bits):
+    """every pass structure must give the same pairs (GOLAP_PASS_BITS experiment hook)."""
+    n = 2_000_000
+    b = oracle.gen_sm64_mod(21, 0, n, n)
+    p = oracle.gen_sm64_mod(22, 0, n, n)
+    os.environ["GOLAP_PASS_BITS"] = bits
+    try:
+        check(ctx, b, p, N.JOIN_RADIX_HASH)
+    finally:
+        del os.environ["GOLAP_PASS_BITS"]
+
+
+def test_generators_match_oracle(ctx):
+    n = 100_000
+    assert np.array_equal(ctx.generate(N.GEN_BUILD_KEYS, n, modulus=1_000_003, first=5).cpu().numpy(), oracle.gen_build_keys(5, n, 1_000_003))
+    assert np.array_equal(ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=999, seed=43, first=17).cpu().numpy(), oracle.gen_probe_keys(17, n, 999))
+    assert np.array_equal(ctx.generate(N.GEN_SM64_MOD_I32, n, modulus=1024, seed=7).cpu().numpy(), oracle.gen_sm64_mod(7, 0, n, 1024, np.int32))
+    assert np.array_equal(ctx.generate(N.GEN_SM64_MOD_F64, n, modulus=1024, seed=8).cpu().numpy(), oracle.gen_sm64_mod(8, 0, n, 1024, np.float64))
+
+
+def test_radix_partition_standalone(ctx):
+    """radix_partition_kernel (join_kernels.cuh:45-76): same partition contents as the oracle, any order inside."""
+    n = 500_000
+    keys = oracle.gen_sm64_mod(31, 0, n, 10**12) - 5 * 10**11
+    kt = torch.from_numpy(keys).cuda()
+    ok, orr, off = ctx.radix_partition(kt, rid_base=100)
+    torch.cuda.synchronize()
+    off = off.cpu().numpy().astype(np.int64)
+    ek, er, eoff = oracle.radix_partition(keys)
+    assert np.array_equal(off, eoff.astype(np.int64))
+    gk, gr = ok.cpu().numpy(), orr.cpu().numpy().view(np.uint32)
+    assert np.array_equal(keys[(gr - 100).astype(np.int64)], gk), "row ids do not point at their keys"
+    pid = oracle.hash_int64_array(gk) & 255
+    for p in (0, 1, 100, 255):
+        assert (pid[off[p]:off[p + 1]] == p).all()
+        assert np.array_equal(np.sort(gr[off[p]:off[p + 1]] - 100), np.sort(er[eoff[p]:eoff[p + 1]]))
+    assert np.array_equal(np.sort(gr), np.arange(100, n + 100, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("n_owners", [2, 8])
+def test_radix_partition_owner_major(ctx, n_owners):
+    n = 200_000
+    keys = oracle.gen_sm64_mod(32, 0, n, 10**9)
+    ok, orr, off = ctx.radix_partition(torch.from_numpy(keys).cuda(), n_owners=n_owners)
+    torch.cuda.synchronize()
+    off = off.cpu().numpy().astype(np.int64)
+    pid = (oracle.hash_int64_array(ok.cpu().numpy()) & 255).astype(np.int64)
+    per = 256 // n_owners
+    slot = (pid % n_owners) * per + pid // n_owners
+    assert (np.diff(slot) >= 0).all(), "slots not contiguous / owner-major"
+    counts = np.bincount(slot, minlength=256)
+    assert np.array_equal(np.diff(off), counts)
+
+
+def test_join_partitioned_two_sources(ctx):
+    """post-exchange path: 2 sources x 128 slots on one device must equal the plain join."""
+    n = 600_000
+    b = oracle.gen_build_keys(0, n, n)
+    p = oracle.gen_probe_keys(0, n, n)
+    exp, me = oracle.hash_join(b, p)
+    P = 2
+    per = 256 // P
+
+    def shard_and_partition(keys):
+        h = n // P
+        parts = []
+        for r in range(P):
+            k = torch.from_numpy(keys[r * h:(r + 1) * h]).cuda()
+            parts.append(ctx.radix_partition(k, rid_base=r * h, n_owners=P))
+        torch.cuda.synchronize()
+        return parts
+
+    bp, pp = shard_and_partition(b), shard_and_partition(p)
+    total = 0
+    allpairs = []
+    for owner in range(P):
+        def gather(parts):
+            ks, rs, so, sl = [], [], [], []
+            pos = 0
+            offs = [x[2].cpu().numpy().astype(np.int64) for x in parts]
+            srcpos = []
+            for r in range(P):
+                lo, hi = offs[r][owner * per], offs[r][(owner + 1) * per]
+                ks.append(parts[r][0][lo:hi]); rs.append(parts[r][1][lo:hi])
+                srcpos.append(pos); pos += hi - lo
+            for s in range(per):
+                for r in range(P):
+                    a = offs[r][owner * per + s] - offs[r][owner * per]
+                    so.append(srcpos[r] + a)
+                    sl.append(offs[r][owner * per + s + 1] - offs[r][owner * per + s])
+            return torch.cat(ks).contiguous(), torch.cat(rs).contiguous(), [int(x) for x in so], [int(x) for x in sl]
+        bk, br, bso, bsl = gather(bp)
+        pk, pr, pso, psl = gather(pp)
+        out = torch.empty((max(1, pk.numel()) * 2, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt = ctx.join_partitioned(bk, br, bso, bsl, pk, pr, pso, psl, per, P, out, total_build_rows_hint=n // P)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        total += m
+        allpairs.append(pairs[:m].cpu().numpy().view(np.uint32))
+    assert total == me
+    assert np.array_equal(canonical(np.concatenate(allpairs)), exp)
+
+
+def test_verify_pairs_and_determinism(ctx):
+    """size-independent properties used for the 1B-row runs + set-determinism across runs."""
+    n = 3_000_000
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    sums = []
+    for _ in range(2):
+        pairs, cnt = ctx.join(bt, pt, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
+        v = ctx.verify_pairs(pairs, n, bt, pt).cpu().numpy().view(np.uint64)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == n
+        assert int(v[0]) == n                        # every emitted pair has equal keys
+        assert int(v[2]) == n * (n - 1) // 2         # every probe row exactly once (with M == N)
+        sums.append((int(v[1]), int(v[3])))
+    assert sums[0] == sums[1]
+    exp, _ = oracle.hash_join(bt.cpu().numpy(), pt.cpu().numpy())
+    assert sums[0][0] == oracle.pairs_checksum(exp)
+
+
+def test_sort_merge_unsupported(ctx):
+    from gpu_olap_engine_amd.engine import GolapError
+    t = torch.zeros(4, dtype=torch.int64, device="cuda")
+    with pytest.raises(GolapError) as e:
+        ctx.join(t, t, strategy=N.JOIN_SORT_MERGE)
+    assert e.value.code == N.ERR_UNSUPPORTED
