@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric: join rows/s + achieved HBM GB/s on the
+1B x 1B int64 radix hash join (config C5), at 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W          (single GPU: the whole 1B x 1B join on one device)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+
+A "step" is one complete join of the synthetic tables (device-resident inputs -> device-resident
+row-id pairs): radix histogram + scatter passes, [partition exchange over xGMI when N > 1,]
+LDS build/probe, pair output.  value = (n_build + n_probe) rows of the WHOLE job / max-over-ranks
+time per step; scaling is "strong" (the 1B x 1B table pair is fixed, N GPUs share it).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per side of the WHOLE job (default: config C5, 1B)")
+    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="rows per side of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample, rank):
+    """Oracle timed on the host cores: single-thread faithful port (executor.rs:238-253 + probe) on a
+    bounded sample of the same generators, plus the multi-threaded radix variant for context."""
+    if sample <= 0 or rank != 0:
+        return None
+    import oracle
+    b = oracle.gen_build_keys(0, sample, sample)
+    p = oracle.gen_probe_keys(0, sample, sample)
+    t0 = time.perf_counter()
+    m, _ = oracle.execute_hash_join_count(b, p)
+    t1 = time.perf_counter()
+    cores = os.cpu_count() or 1
+    m2, _ = oracle.radix_join_mt(b, p, cores)
+    t2 = time.perf_counter()
+    assert m == m2 == sample
+    return {"value": 2 * sample / (t1 - t0), "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{sample} x {sample} rows, same generators as the GPU run (N={sample}), single-thread "
+                      f"HashMap<i64,Vec<usize>> build + probe as executor.rs:238-253; {t1 - t0:.2f} s",
+            "fair_value": 2 * sample / (t2 - t1), "fair_cores": cores,
+            "fair_note": f"radix-partitioned, std::thread over all {cores} host cores; {t2 - t1:.2f} s"}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from gpu_olap_engine_amd import _native as N
+    from gpu_olap_engine_amd.engine import Context
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_total = args.rows
+    ctx = Context(profiling=True, max_gpu_memory=0)
+    info = ctx.device_info()
+
+    # ---- synthetic, device-resident inputs (counter-based) -------------
+    from gpu_olap_engine_amd.distributed import HipBackend, ShardedJoin, shard_range
+    lo, hi = shard_range(n_total, rank, world)
+    n_local = hi - lo
+    bkeys = ctx.generate(N.GEN_BUILD_KEYS, n_local, modulus=n_total, first=lo)
+    pkeys = ctx.generate(N.GEN_SM64_MOD_I64, n_local, modulus=n_total, seed=43, first=lo)
+    torch.cuda.synchronize()
+
+    if world == 1:
+        cap = n_total
+        out_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        out_count = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def step():
+            ctx.join(bkeys, pkeys, out_pairs=out_pairs, max_pairs=cap, strategy=N.JOIN_RADIX_HASH, out_count=out_count)
+            return out_pairs, out_count, n_local, n_local
+    else:
+        sj = ShardedJoin(HipBackend(ctx))
+        cap = int(n_local * 1.25) + 65536
+        out_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+
+        def step():
+            return sj.join(bkeys, pkeys, lo, lo, n_total, out_pairs=out_pairs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    ctx.stats_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    pairs, count = res[0], res[1]
+    m_local = int(count.item())
+
+    # ---- size-independent correctness properties (every run, untimed) -------------------------
+    verify = {}
+    if not args.no_verify:
+        m_tot = torch.tensor([m_local], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(m_tot)
+        verify["matches"] = int(m_tot.item())
+        assert verify["matches"] == n_total, f"expected exactly one match per probe row: {verify['matches']} != {n_total}"
+        # sum / xor of probe row ids over all pairs == those of 0..N-1  (every probe row exactly once)
+        import ctypes as C
+        v = torch.zeros(4, dtype=torch.int64, device=dev)
+        # key equality needs both key columns on one device: check it on 1 GPU, id coverage everywhere
+        if world == 1:
+            v = ctx.verify_pairs(pairs, m_local, bkeys, pkeys)
+            assert int(v[0].item()) == m_local, "emitted pairs with unequal keys"
+            verify["equal_key_pairs"] = int(v[0].item())
+            psum = int(v[2].item()) & (2**64 - 1)
+        else:
+            ids = pairs[:m_local, 1].to(torch.int64) & 0xFFFFFFFF
+            s = ids.sum().reshape(1)
+            dist.all_reduce(s)
+            psum = int(s.item()) & (2**64 - 1)
+        assert psum == (n_total * (n_total - 1) // 2) & (2**64 - 1), "probe row ids are not a permutation of 0..N-1"
+        verify["probe_id_sum_ok"] = True
+
+    stats = ctx.stats()
+    # ---- roofline of the dominant kernel (by accumulated device time) -------------------------
+    kern = {k: v for k, v in stats.items() if v["launches"] and k != "scan_offsets"}
+    dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+    roof = None
+    if dom:
+        s = kern[dom]
+        per_launch_bytes = s["bytes"] / s["launches"]
+        avg_ms = s["total_ms"] / s["launches"]
+        ach = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                e = tj.get(f"{dom}@{n_total}x{world}")
+                traffic = e["hbm_bytes_per_launch"] if e else None
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 4), "launches": s["launches"]}
+    # whole-join algorithmic bytes, SURVEY 8(d): 40*(Nb+Np) + 8*M
+    alg_join = 40 * 2 * n_total + 8 * n_total
+    join_gbps = alg_join / (ms_per_step * 1e-3) / 1e9
+    line = {
+        "metric": "join rows/sec, 1Bx1B int64 radix hash join",
+        "value": round(2 * n_total / (ms_per_step * 1e-3), 1),
+        "unit": "rows/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": f"C5 radix hash join {n_total} x {n_total} int64 keys, 256 radix partitions, unique build keys, M = N_probe",
+                   "n_build": n_total, "n_probe": n_total, "rows_per_gpu_per_side": n_local,
+                   "parallelism": f"partition-sharded x{world}" + (" + RCCL all_to_all" if world > 1 else ""),
+                   "plan": ctx.join_plan(n_total if world == 1 else max(1, n_total // world))},
+        "probe_rows_per_s": round(n_total / (ms_per_step * 1e-3), 1),
+        "join_alg_GBps": round(join_gbps, 1),
+        "join_roofline_frac": round(join_gbps / (HBM_PEAK_GBPS * world), 4),
+        "roofline": roof,
+        "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in stats.items()},
+        "verify": verify,
+        "device": {"name": info["name"], "arch": info["gcn_arch"], "cus": info["compute_units"],
+                   "hbm_bus_bits": info["memory_bus_bits"], "mem_clock_mhz": info["memory_clock_mhz"]},
+    }
+    cb = cpu_baseline(args.cpu_sample, rank) if world == 1 else None
+    if cb:
+        line["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

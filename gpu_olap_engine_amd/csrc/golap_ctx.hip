@@ -235,7 +235,7 @@ int32_t ws_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st) {
     if (ctx->ws.size < bytes) {
         if (ctx->ws.base) {
             // the old slab may still be in use by queued kernels
-            if (ctx->ws_stream) (void)hipStreamSynchronize(ctx->ws_stream);
+            if (ctx->ws_done) (void)hipStreamSynchronize(ctx->ws_stream);
             GOLAP_TRY(ctx->slabs.release(ctx, ctx->ws.base, ctx->ws.cls));
             ctx->ws = Workspace();
         }
@@ -246,7 +246,7 @@ int32_t ws_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st) {
         ctx->ws.cls = cls;
         ctx->ws.size = ctx->slabs.classes[cls].size;
     }
-    if (ctx->ws_stream && ctx->ws_stream != st && ctx->ws_done)
+    if (ctx->ws_done && ctx->ws_stream != st)
         GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ws_done, 0));
     ctx->ws.used = 0;
     return GOLAP_OK;
@@ -320,8 +320,6 @@ int32_t golap_ctx_create(const golap_engine_config* cfg, golap_ctx** out_ctx) {
     if (e != hipSuccess) { delete ctx; return fail(nullptr, GOLAP_ERR_HIP, "selecting device failed: %s", hipGetErrorString(e)); }
     e = hipGetDeviceProperties(&ctx->prop, ctx->device);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, GOLAP_ERR_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e)); }
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete ctx; return fail(nullptr, GOLAP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ctx->slabs.init(c.max_gpu_memory, 8);
     int32_t s = ctx->xfer.init(ctx, c.num_streams);
     if (s != GOLAP_OK) { golap_ctx_destroy(ctx); return s; }
@@ -340,7 +338,6 @@ void golap_ctx_destroy(golap_ctx* ctx) {
     ctx->slabs.destroy();
     for (void* p : ctx->pinned_small) (void)hipHostFree(p);
     if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 

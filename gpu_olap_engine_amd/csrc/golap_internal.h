@@ -107,7 +107,6 @@ struct golap_ctx {
     golap_engine_config cfg;
     int device = 0;
     hipDeviceProp_t prop;
-    hipStream_t stream = nullptr;     // the context's own stream
     std::mutex mu;                    // serialises compute calls on one context (SURVEY 8(b) threading)
     std::string err;
     golap::SlabAllocator slabs;
@@ -143,7 +142,9 @@ struct KernelTimer {
     }
 };
 
-inline hipStream_t pick_stream(golap_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+// NULL is the HIP null (legacy default) stream, exactly as in every HIP API -- it is also what
+// torch.cuda.current_stream().cuda_stream returns for torch's default stream.
+inline hipStream_t pick_stream(golap_ctx* ctx, void* stream) { (void)ctx; return (hipStream_t)stream; }
 
 // workspace helpers (call with ctx->mu held)
 int32_t ws_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st);

@@ -14,8 +14,8 @@
  *     anyhow::Result everywhere).
  *   - the caller owns input and output buffers; the library owns only its
  *     context, slabs and scratch.
- *   - `stream` is a hipStream_t passed as void* (NULL = the context's own stream).
- *     Calls are asynchronous on that stream unless stated otherwise.
+ *   - `stream` is a hipStream_t passed as void*; NULL is the HIP null stream, as in
+ *     every HIP API.  Calls are asynchronous on that stream unless stated otherwise.
  *   - there is NO CPU fallback: without a HIP device every compute call fails
  *     with GOLAP_ERR_NO_DEVICE.
  */

@@ -1,0 +1,164 @@
+"""GPU parity tests for GpuFilter / GpuAggregate / widening vs the CPU oracle (bit-exact:
+integer work exactly; f64 sums on integer-valued data are order-independent and exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import oracle  # noqa: E402
+from gpu_olap_engine_amd import _native as N  # noqa: E402
+
+OPS = ["=", "==", "!=", "<>", ">", ">=", "<", "<=", "AND", "like"]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_reference_known_answer_mask(ctx):
+    """executor.rs:553-570: [5,15,25] > 10 -> [false,true,true]."""
+    m = ctx.filter_mask(dev(np.array([5, 15, 25], np.int64)), ">", 10).cpu().numpy()
+    assert m.tolist() == [0, 1, 1]
+
+
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 255, 4096, 4097, 100_003])
+def test_filter_mask_and_compact(ctx, op, n):
+    rng = np.random.default_rng(n + len(op))
+    col = rng.integers(-50, 50, n).astype(np.int64)
+    lit = 7
+    exp = oracle.eval_filter_mask(col, op, lit)
+    d = dev(col) if n else torch.empty(0, dtype=torch.int64, device="cuda")
+    got = ctx.filter_mask(d, op, lit).cpu().numpy()
+    assert np.array_equal(got, exp)
+    idx, cnt = ctx.filter_compact(d, op, lit)
+    torch.cuda.synchronize()
+    c = int(cnt.item())
+    eidx = oracle.mask_to_indices(exp)
+    assert c == eidx.size
+    assert np.array_equal(idx[:c].cpu().numpy().view(np.uint32), eidx)   # original row order (executor.rs:479-484)
+    if c:
+        f = rng.random(n)
+        taken = ctx.take(dev(f), idx, cnt, n_max=n)[:c].cpu().numpy()
+        assert np.array_equal(taken, oracle.take_8byte(f, eidx))
+        taken_i = ctx.take(d, idx, cnt, n_max=n)[:c].cpu().numpy()
+        assert np.array_equal(taken_i, col[eidx.astype(np.int64)])
+
+
+def test_filter_mask_unaligned_views(ctx):
+    col = np.arange(-500, 1500, dtype=np.int64)
+    d = dev(col)
+    for off in (1, 2, 3):
+        got = ctx.filter_mask(d[off:], "<", 100).cpu().numpy()
+        assert np.array_equal(got, oracle.eval_filter_mask(col[off:], "<", 100))
+
+
+def test_extreme_literals(ctx):
+    col = np.array([-(2**63), -1, 0, 1, 2**63 - 1], np.int64)
+    for op in ("<", "<=", ">", ">=", "=", "!="):
+        for lit in (-(2**63), 0, 2**63 - 1):
+            assert np.array_equal(ctx.filter_mask(dev(col), op, lit).cpu().numpy(), oracle.eval_filter_mask(col, op, lit))
+
+
+def test_config1_filter_sum(ctx):
+    """BASELINE config 1: SELECT sum(v) FROM t WHERE k<c on a 1M-row batch."""
+    n = 1_000_000
+    k = oracle.gen_sm64_mod(1, 0, n, 1000)
+    v = oracle.gen_sm64_mod(2, 0, n, 1024)
+    es, ek = oracle.filter_sum(k, v, "<", 500)
+    got = ctx.filter_sum(dev(k), dev(v), "<", 500).cpu().numpy()
+    assert got[0] == es and got[1] == ek
+    # the unfused route: compact -> take -> ungrouped Sum gives the same scalar
+    idx, cnt = ctx.filter_compact(dev(k), "<", 500)
+    taken = ctx.take(dev(v), idx, cnt, n_max=n)
+    c = int(cnt.item())
+    s = ctx.aggregate([(N.AGG_SUM, 0)], [taken[:c].contiguous()]).cpu().numpy()
+    assert s[0, 0] == es
+    gf = ctx.filter_sum(dev(k), dev(v.astype(np.float64)), "<", 500).cpu().numpy()
+    assert gf[0] == es and gf[1] == ek
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.float64])
+@pytest.mark.parametrize("n", [0, 1, 1000, 1_000_003])
+def test_ungrouped_aggregate_all_funcs(ctx, dtype, n):
+    """execute_aggregate (executor.rs:297-355): SUM, COUNT, MIN, MAX, AVG as f64; empty input keeps the seeds."""
+    rng = np.random.default_rng(n)
+    v = rng.integers(-1000, 1000, n).astype(dtype)
+    exp = oracle.execute_aggregate(v)
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0)]
+    d = dev(v) if n else torch.empty(0, dtype=torch.from_numpy(v).dtype, device="cuda")
+    got = ctx.aggregate(specs, [d]).cpu().numpy()[:, 0]
+    assert got.tolist() == [exp["sum"], exp["count"], exp["min"], exp["max"], exp["avg"]]
+
+
+@pytest.mark.parametrize("key_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("G", [1, 7, 1024, 2048, 5000, 100_000])
+def test_grouped_aggregate(ctx, key_dtype, G):
+    """GROUP BY dense key -> SUM/COUNT/MIN/MAX/AVG per group, sorted by key (= slot index)."""
+    n = 400_000
+    keys = oracle.gen_sm64_mod(7, 0, n, G, key_dtype)
+    vals = oracle.gen_sm64_mod(8, 0, n, 1024, np.float64)
+    ok, ost = oracle.group_aggregate(keys.astype(np.int64), vals)
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0)]
+    out, counts = ctx.aggregate(specs, [dev(vals)], group_keys=dev(keys), n_groups=G, want_counts=True)
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    present = counts > 0
+    assert np.array_equal(np.nonzero(present)[0], ok)
+    assert np.array_equal(out[:, present].T, ost)
+    # absent groups keep the identities: sum 0, count 0, min f64::MAX, max f64::MIN, avg 0 (executor.rs:308-311, :339-345)
+    if (~present).any():
+        a = out[:, ~present]
+        assert (a[0] == 0).all() and (a[1] == 0).all() and (a[2] == np.finfo(np.float64).max).all() and (a[3] == -np.finfo(np.float64).max).all() and (a[4] == 0).all()
+
+
+def test_grouped_two_value_columns_int_and_float(ctx):
+    n, G = 200_000, 300
+    keys = oracle.gen_sm64_mod(3, 0, n, G, np.int64)
+    vi = oracle.gen_sm64_mod(4, 0, n, 5000, np.int64) - 2500
+    vf = oracle.gen_sm64_mod(5, 0, n, 64, np.float64)
+    out = ctx.aggregate([(N.AGG_SUM, 0), (N.AGG_MAX, 1), (N.AGG_MIN, 0), (N.AGG_AVG, 1)], [dev(vi), dev(vf)], group_keys=dev(keys), n_groups=G).cpu().numpy()
+    _, si = oracle.group_aggregate(keys, vi.astype(np.float64))
+    _, sf = oracle.group_aggregate(keys, vf)
+    assert np.array_equal(out[0], si[:, 0]) and np.array_equal(out[1], sf[:, 3]) and np.array_equal(out[2], si[:, 2]) and np.array_equal(out[3], sf[:, 4])
+
+
+def test_reference_kernel_mod_semantics(ctx):
+    """keys outside [0, n_groups) fold with key % n_groups exactly like join_kernels.cuh:230 (documented defect)."""
+    n, G = 50_000, 97
+    keys = oracle.gen_sm64_mod(9, 0, n, 10_000, np.int32)
+    vi = oracle.gen_sm64_mod(10, 0, n, 100, np.int64)
+    exp = np.zeros(G, np.int64)
+    oracle.lib().orc_hash_aggregate_kernel_i64(keys.view(np.uint32).ctypes.data_as(oracle.C.POINTER(oracle.C.c_uint32)),
+                                               vi.ctypes.data_as(oracle.C.POINTER(oracle.C.c_int64)), n,
+                                               exp.ctypes.data_as(oracle.C.POINTER(oracle.C.c_int64)), G)
+    out = ctx.aggregate([(N.AGG_SUM, 0)], [dev(vi)], group_keys=dev(keys), n_groups=G).cpu().numpy()[0]
+    assert np.array_equal(out, exp.astype(np.float64))
+
+
+def test_widen_matches_arrow_interop(ctx):
+    """record_batch_convert.rs:211-217: Int32 1 widens to i64 1; nulls -> 0 (:102-110)."""
+    a = np.array([1, 2, 3, 4, 5], np.int32)
+    assert ctx.widen(dev(a)).cpu().numpy().tolist() == [1, 2, 3, 4, 5]
+    rng = np.random.default_rng(0)
+    n = 100_001
+    valid = (rng.random(n) > 0.3).astype(np.uint8)
+    for dt in (np.int8, np.int16, np.int32, np.int64, np.uint8):
+        x = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, n, dtype=dt)
+        got = ctx.widen(dev(x), validity=dev(valid)).cpu().numpy()
+        assert np.array_equal(got, np.where(valid == 1, x.astype(np.int64), 0))
+    f = rng.random(n).astype(np.float32)
+    got = ctx.widen(dev(f), validity=dev(valid)).cpu().numpy()
+    assert np.array_equal(got, np.where(valid == 1, f.astype(np.float64), 0.0))
+    for code, dt in ((N.WIDEN_U16, np.uint16), (N.WIDEN_U32, np.uint32)):
+        x = rng.integers(0, np.iinfo(dt).max, n, dtype=dt)
+        raw = torch.from_numpy(x.view(np.int16 if dt == np.uint16 else np.int32)).cuda()
+        got = ctx.widen(raw, in_dtype=code).cpu().numpy()
+        assert np.array_equal(got, x.astype(np.int64))
+
+
+def test_api_constants(ctx):
+    from gpu_olap_engine_amd import engine as E
+    assert E.choose_strategy(500_000) == N.JOIN_BROADCAST_HASH and E.choose_strategy(5_000_000) == N.JOIN_RADIX_HASH   # join_kernel.rs:85-87
+    assert E.compute_launch_params(1024) == (4, 256) and E.compute_launch_params(1) == (1, 256)                     # filter_kernel.rs:87-94
+    assert E.agg_identity_value(N.AGG_SUM) == 0 and E.agg_identity_value(N.AGG_MIN) == 2**63 - 1 and E.agg_identity_value(N.AGG_MAX) == -2**63

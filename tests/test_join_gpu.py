@@ -26,8 +26,8 @@ def run_join(ctx, b, p, strategy, max_pairs=None, **kw):
     return canonical(got), m
 
 
-def check(ctx, b, p, strategy, **kw):
-    got, m = run_join(ctx, b, p, strategy, **kw)
+def check(ctx, b, p, strategy, max_pairs=None, **kw):
+    got, m = run_join(ctx, b, p, strategy, max_pairs=max_pairs, **kw)
     exp, me = oracle.hash_join(b, p, kw.get("build_rid_base", 0), kw.get("probe_rid_base", 0))
     assert m == me, f"match count {m} != oracle {me}"
     assert np.array_equal(got, exp)
@@ -81,14 +81,28 @@ def test_negative_and_extreme_keys(ctx, strategy):
 
 @pytest.mark.parametrize("strategy", STRATS)
 def test_fold_collision_keys(ctx, strategy):
-    """keys i<<32 all fold to the same hash_int64: one radix partition gets everything,
-    full-key compare must still separate them."""
+    """hash_int64 folds hi^lo (join_kernels.cuh:39): key i<<32 hashes like key i.  Every probe key
+    i meets a build key i<<32 with the SAME hash but a different value: only the full-key compare
+    (join_kernels.cuh:152-153) keeps them apart."""
     n = 20_000
-    b = (np.arange(n, dtype=np.int64) << 32)
-    p = (np.arange(0, 2 * n, 2, dtype=np.int64) << 32)
+    b = np.concatenate([np.arange(n, dtype=np.int64) << 32, np.arange(0, n, 2, dtype=np.int64)])
+    p = np.arange(n, dtype=np.int64)
+    assert np.array_equal(oracle.hash_int64_array(b[:n]), oracle.hash_int64_array(p))
     m = check(ctx, b, p, strategy)
-    assert m == n // 2
-    assert len(set(oracle.hash_int64_array(b).tolist())) <= 2
+    assert m == n // 2 + 1   # key 0 is both 0<<32 and 0
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+def test_same_hash_distinct_keys(ctx, strategy):
+    """keys (i<<32)|(i^c) all fold to c: ONE hash value, so one sub-partition holds the whole build side
+    (20000 distinct keys > the 4096-row LDS table -> chunked build) and chains are told apart by key only."""
+    n = 20_000
+    i = np.arange(n, dtype=np.int64)
+    b = (i << 32) | (i ^ 0x5A5A)
+    assert len(set(oracle.hash_int64_array(b).tolist())) == 1
+    p = np.concatenate([b[::3], (i[:500] << 32) | (i[:500] ^ 0x5A5B)])
+    m = check(ctx, b, p, strategy)
+    assert m == len(b[::3])
 
 
 @pytest.mark.parametrize("strategy", STRATS)
@@ -96,7 +110,7 @@ def test_heavy_skew_single_key(ctx, strategy):
     """one hot key on both sides: M = nb_hot * np_hot, overflows the LDS table chunk and the probe batch."""
     b = np.concatenate([np.full(5000, 7, np.int64), np.arange(100, 3100, dtype=np.int64)])
     p = np.concatenate([np.full(300, 7, np.int64), np.arange(0, 2000, dtype=np.int64)])
-    m = check(ctx, b, p, strategy)
+    m = check(ctx, b, p, strategy, max_pairs=2_000_000)
     assert m >= 5000 * 300
 
 
