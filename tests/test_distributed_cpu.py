@@ -1,0 +1,132 @@
+"""world_size-2 (and 4) gloo tests of the N>1 path on CPU: the SAME ShardedJoin class the GPU bench uses
+(sharding, owner-major slots, split sizes, all_to_all_single exchange, segment tables, global row ids),
+with an oracle-backed stand-in for the two device compute steps (tests may use the oracle; the product
+backend is HipBackend)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """CPU stand-in with the semantics of golap_radix_partition / golap_join_partitioned."""
+
+    def radix_partition(self, keys, rid_base, n_owners):
+        import oracle
+        k = keys.numpy()
+        ok, orr, off = oracle.radix_partition(k)                       # partition-id order, stable
+        per = 256 // n_owners
+        order = sorted(range(256), key=lambda p: (p % n_owners) * per + p // n_owners)   # owner-major slots
+        ks, rs, offs = [], [], [0]
+        for p in order:
+            lo, hi = int(off[p]), int(off[p + 1])
+            ks.append(ok[lo:hi]); rs.append(orr[lo:hi].astype(np.int64) + rid_base)
+            offs.append(offs[-1] + hi - lo)
+        kk = np.concatenate(ks) if k.size else np.empty(0, np.int64)
+        rr = (np.concatenate(rs) if k.size else np.empty(0, np.int64)).astype(np.uint32).view(np.int32)
+        return torch.from_numpy(kk.copy()), torch.from_numpy(rr.copy()), torch.tensor(offs, dtype=torch.int32)
+
+    def join_partitioned(self, bk, br, bso, bsl, pk, pr, pso, psl, n_slots, n_sources, out_pairs, hint):
+        import oracle
+        bk, pk = bk.numpy(), pk.numpy()
+        br, pr = br.numpy().view(np.uint32), pr.numpy().view(np.uint32)
+        allp = []
+        for s in range(n_slots):
+            bi = np.concatenate([np.arange(bso[s * n_sources + r], bso[s * n_sources + r] + bsl[s * n_sources + r]) for r in range(n_sources)]).astype(np.int64)
+            pi = np.concatenate([np.arange(pso[s * n_sources + r], pso[s * n_sources + r] + psl[s * n_sources + r]) for r in range(n_sources)]).astype(np.int64)
+            if bi.size == 0 or pi.size == 0:
+                continue
+            pairs, m = oracle.hash_join(bk[bi], pk[pi])
+            if m:
+                allp.append(np.stack([br[bi][pairs[:, 0]], pr[pi][pairs[:, 1]]], axis=1))
+        got = np.concatenate(allp) if allp else np.empty((0, 2), np.uint32)
+        m = got.shape[0]
+        out_pairs[:min(m, out_pairs.shape[0])] = torch.from_numpy(got[:out_pairs.shape[0]].view(np.int32).copy())
+        return out_pairs, torch.tensor([m], dtype=torch.int64)
+
+    def empty(self, n, dtype, like):
+        return torch.empty(n, dtype=dtype)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, variant, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from gpu_olap_engine_amd.distributed import ShardedJoin, shard_range
+        lo, hi = shard_range(n, rank, world)
+        if variant == "unique":
+            b = oracle.gen_build_keys(lo, hi - lo, n)
+            p = oracle.gen_probe_keys(lo, hi - lo, n)
+        else:   # duplicates on both sides + rank 1 holds an empty-ish tail
+            b = oracle.gen_sm64_mod(11, lo, hi - lo, n // 2)
+            p = oracle.gen_sm64_mod(12, lo, hi - lo, n // 2)
+        sj = ShardedJoin(OracleBackend())
+        out = torch.empty((4 * n, 2), dtype=torch.int32)
+        pairs, cnt, nb, npr = sj.join(torch.from_numpy(b), torch.from_numpy(p), lo, lo, n, out_pairs=out)
+        m = int(cnt.item())
+        # every build/probe row this rank received belongs to a partition it owns (p % world == rank)
+        q.put((rank, pairs[:m].numpy().view(np.uint32).copy(), nb, npr))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,variant", [(2, "unique"), (2, "dups"), (4, "unique")])
+def test_sharded_join_gloo(world, variant):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from np_twin import canonical
+    n = 40_000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, variant, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if variant == "unique":
+        b, pr = oracle.gen_build_keys(0, n, n), oracle.gen_probe_keys(0, n, n)
+    else:
+        b, pr = oracle.gen_sm64_mod(11, 0, n, n // 2), oracle.gen_sm64_mod(12, 0, n, n // 2)
+    exp, me = oracle.hash_join(b, pr)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+    # ownership: each pair's key hashes to a partition owned by the rank that produced it
+    for rank, pairs, nb, npr in res:
+        if pairs.shape[0]:
+            pid = oracle.hash_int64_array(b[pairs[:, 0].astype(np.int64)]) & 255
+            assert ((pid % world) == rank).all()
+    assert sum(r[2] for r in res) == n and sum(r[3] for r in res) == n     # the exchange neither lost nor duplicated rows
+
+
+def test_slot_mapping_is_a_bijection():
+    from gpu_olap_engine_amd.distributed import owner_of_partition, shard_range, slot_of_partition
+    for world in (1, 2, 4, 8):
+        slots = [slot_of_partition(p, world) for p in range(256)]
+        assert sorted(slots) == list(range(256))
+        per = 256 // world
+        for p in range(256):
+            assert slots[p] // per == owner_of_partition(p, world) == p % world
+    assert shard_range(10, 0, 4) == (0, 2) and shard_range(10, 3, 4) == (6, 10)
