@@ -31,6 +31,7 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per side of the WHOLE job (default: config C5, 1B)")
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="rows per side of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (ShardedJoin) even with 1 rank")
     return ap.parse_args()
 
 
@@ -73,9 +74,10 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n_total = args.rows
     ctx = Context(profiling=True, max_gpu_memory=0)
@@ -89,7 +91,7 @@ def main():
     pkeys = ctx.generate(N.GEN_SM64_MOD_I64, n_local, modulus=n_total, seed=43, first=lo)
     torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not args.sharded:
         cap = n_total
         out_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
         out_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -207,7 +209,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or args.sharded:
         dist.destroy_process_group()
 
 

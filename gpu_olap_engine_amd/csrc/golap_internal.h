@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -136,9 +137,16 @@ struct KernelTimer {
         (void)hipEventRecord(ev.start, st);
     }
     ~KernelTimer() {
-        if (!on) return;
-        (void)hipEventRecord(ev.stop, st);
-        ctx->prof.pending.push_back(ev);
+        if (on) {
+            (void)hipEventRecord(ev.stop, st);
+            ctx->prof.pending.push_back(ev);
+        }
+        static const bool dbg = getenv("GOLAP_DEBUG_SYNC") != nullptr;   // debugging aid: serialise + name every phase
+        if (dbg) {
+            hipError_t e = hipStreamSynchronize(st);
+            fprintf(stderr, "[golap] %s finished: %s\n", on ? ctx->prof.stats[ev.stat].name : "kernel", hipGetErrorString(e));
+            fflush(stderr);
+        }
     }
 };
 

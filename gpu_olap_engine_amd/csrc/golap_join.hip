@@ -102,6 +102,7 @@ __global__ void k_setup_from_segments(const uint32_t* __restrict__ seg_off, cons
 // bucket-major so that ONE flat exclusive scan yields every output position.
 //   hist[(g*F + f)*S + s]
 // ---------------------------------------------------------------------------
+template <int PASS_TAG>   // only gives each pass its own kernel name in profiles
 __global__ __launch_bounds__(PT_THREADS) void k_hist(const long long* __restrict__ in_keys, const uint32_t* __restrict__ chunk_off,
                                                      const uint32_t* __restrict__ chunk_len, uint32_t* __restrict__ hist, PassCfg cfg) {
     __shared__ uint32_t s_cnt[PT_MAX_F];
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_down(uint32_t* __restrict__
 //   write each bucket's run contiguously at its running global cursor.
 // Replaces join_kernels.cuh:72-75 (per-row global atomicAdd + scattered 8/4-byte stores).
 // ---------------------------------------------------------------------------
+template <int PASS_TAG>
 __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restrict__ in_keys, const uint32_t* __restrict__ in_rids,
                                                         uint32_t rid_base, const uint32_t* __restrict__ chunk_off,
                                                         const uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ scanned,
@@ -308,6 +310,184 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
         // s_cnt is read here by the same thread that zeroes it (same f stride), so no hazard.
     }
 }
+
+
+// ---------------------------------------------------------------------------
+// scatter v2: line-aligned write combining.
+// rocprofv3 on v1 (profiles/r01a): WRITE_SIZE = 1.54 x the bytes written, because a
+// tile's run for one bucket (8-16 rows at fan-out 256-512) starts and ends inside a
+// 128-byte line that the NEXT tile completes ~10 us later, after the L2 has already
+// evicted it.  Here every bucket keeps its unfinished line in LDS: a tile only emits
+// rows up to the last 16-row (128-byte key line / 64-byte row-id segment) boundary of
+// the bucket's global cursor and carries the remaining < 16 rows into the next tile, so
+// each line is written exactly once, whole, by one 16-lane group.  Only the first and
+// last line of a (chunk, bucket) run can be partial.
+//   LDS: staging for carry + new rows (8192 x 12 B) + 6 per-bucket words  ~ 108 KiB,
+//   one 1024-thread work-group per CU; the next tile's keys are prefetched into
+//   registers while the current tile is written out.
+// ---------------------------------------------------------------------------
+constexpr int WC_THREADS = 1024;
+constexpr int WC_WAVES = WC_THREADS / 64;
+constexpr int WC_RPT = 4;
+constexpr int WC_NEW = WC_THREADS * WC_RPT;   // new rows per tile (max)
+constexpr int WC_CAP = 8192;                  // staging rows (carry + new)
+constexpr int WC_MAX_F = 512;                 // carry <= 15 * F = 7680 rows, leaves >= 512 new rows per tile
+constexpr int WC_CARRY_PT = 16 * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
+
+template <int PASS_TAG>
+__global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __restrict__ in_keys, const uint32_t* __restrict__ in_rids,
+                                                           uint32_t rid_base, const uint32_t* __restrict__ chunk_off,
+                                                           const uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ scanned,
+                                                           long long* __restrict__ out_keys, uint32_t* __restrict__ out_rids, PassCfg cfg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [WC_CAP]
+    uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + WC_CAP * 8);      // [WC_CAP]
+    const uint32_t F = cfg.F;
+    uint32_t* s_cnt = s_rids + WC_CAP;     // rows of bucket in staging this tile (carry + new)
+    uint32_t* s_start = s_cnt + F;         // staging offset of the bucket
+    uint32_t* s_gpos = s_start + F;        // global cursor of the bucket (index of its first staged row)
+    uint32_t* s_carry = s_gpos + F;        // rows carried into this tile
+    uint32_t* s_csrc = s_carry + F;        // staging offset where those carried rows sit (previous layout)
+    uint32_t* s_emit = s_csrc + F;         // rows written out this tile
+    uint32_t* s_w = s_emit + F;            // [WC_WAVES]
+    uint32_t* s_misc = s_w + WC_WAVES;     // [0] carry total of the next tile
+
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t len = chunk_len[chunk];
+    if (len == 0) return;
+    const uint32_t off = chunk_off[chunk];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
+        if (tid < F) {
+            s_gpos[tid] = scanned[((size_t)g * F + tid) * cfg.S + s];
+            s_carry[tid] = 0;
+            s_csrc[tid] = 0;
+        }
+    }
+    uint32_t consumed = 0;
+    uint32_t t_eff = len < (uint32_t)WC_NEW ? len : (uint32_t)WC_NEW;
+    long long key[WC_RPT];
+    uint32_t rid[WC_RPT];
+#pragma unroll
+    for (int r = 0; r < WC_RPT; ++r) {
+        const uint32_t i = r * WC_THREADS + tid;
+        key[r] = i < t_eff ? in_keys[off + i] : 0;
+        rid[r] = in_rids ? (i < t_eff ? in_rids[off + i] : 0u) : rid_base + off + i;   // join_kernels.cuh:75
+    }
+    for (;;) {
+        consumed += t_eff;
+        const bool last = consumed >= len;
+        if (tid < F) s_cnt[tid] = s_carry[tid];
+        if (tid == 0) s_misc[0] = 0;
+        __syncthreads();
+        uint32_t br[WC_RPT];
+#pragma unroll
+        for (int r = 0; r < WC_RPT; ++r) {
+            const uint32_t i = r * WC_THREADS + tid;
+            if (i < t_eff) {
+                const uint32_t b = bucket_of(hash_int64(key[r]), cfg);
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // rank continues after the carried rows
+            }
+        }
+        __syncthreads();
+        {   // staging offsets + how much of every bucket can leave as whole lines
+            const uint32_t c = tid < F ? s_cnt[tid] : 0u;
+            const uint32_t inc = wave_inclusive_scan(c);
+            if (lane == 63) s_w[wv] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < WC_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            uint32_t nc = 0;
+            if (tid < F) {
+                s_start[tid] = base + inc - c;
+                const uint32_t gp = s_gpos[tid], end = gp + c;
+                const uint32_t ae = last ? end : (end & ~15u);
+                const uint32_t e = ae > gp ? ae - gp : 0u;
+                s_emit[tid] = e;
+                nc = c - e;
+            }
+            nc = wave_reduce_add(nc);
+            if (lane == 0 && nc) atomicAdd(&s_misc[0], nc);
+        }
+        __syncthreads();
+        // carried rows: old staging position -> registers -> new staging position
+        long long ck[WC_CARRY_PT];
+        uint32_t cr[WC_CARRY_PT], cdst[WC_CARRY_PT];
+#pragma unroll
+        for (int c8 = 0; c8 < WC_CARRY_PT; ++c8) {
+            const uint32_t j = c8 * WC_THREADS + tid, b = j >> 4, k = j & 15u;
+            cdst[c8] = 0xFFFFFFFFu;
+            if (b < F && k < s_carry[b]) {
+                const uint32_t src = s_csrc[b] + k;
+                ck[c8] = s_keys[src];
+                cr[c8] = s_rids[src];
+                cdst[c8] = s_start[b] + k;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c8 = 0; c8 < WC_CARRY_PT; ++c8) {
+            if (cdst[c8] != 0xFFFFFFFFu) {
+                s_keys[cdst[c8]] = ck[c8];
+                s_rids[cdst[c8]] = cr[c8];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < WC_RPT; ++r) {
+            const uint32_t i = r * WC_THREADS + tid;
+            if (i < t_eff) {
+                const uint32_t pos = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
+                s_keys[pos] = key[r];
+                s_rids[pos] = rid[r];
+            }
+        }
+        __syncthreads();
+        // prefetch the next tile while this one is written out
+        const uint32_t room = (uint32_t)WC_CAP - s_misc[0];
+        uint32_t t_next = 0;
+        if (!last) {
+            t_next = len - consumed;
+            if (t_next > (uint32_t)WC_NEW) t_next = WC_NEW;
+            if (t_next > room) t_next = room;
+        }
+        {
+            const uint32_t nb = off + consumed;
+#pragma unroll
+            for (int r = 0; r < WC_RPT; ++r) {
+                const uint32_t i = r * WC_THREADS + tid;
+                key[r] = i < t_next ? in_keys[nb + i] : 0;
+                rid[r] = in_rids ? (i < t_next ? in_rids[nb + i] : 0u) : rid_base + nb + i;
+            }
+        }
+        // write out: one 16-lane group per 128-byte key line
+        {
+            const uint32_t q = tid >> 4, l = tid & 15u;
+            const uint32_t gpb = F >= 64u ? 1u : 64u / F;   // groups per bucket when the fan-out is small
+            for (uint32_t b = q / gpb; b < F; b += 64u / gpb) {
+                const uint32_t e = s_emit[b];
+                if (e == 0) continue;
+                const uint32_t sb = s_start[b], gp = s_gpos[b];
+                for (uint32_t k = ((l - gp) & 15u) + 16u * (q % gpb); k < e; k += 16u * gpb) {   // lane l owns global index == l (mod 16)
+                    out_keys[gp + k] = s_keys[sb + k];
+                    out_rids[gp + k] = s_rids[sb + k];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < F) {
+            const uint32_t e = s_emit[tid];
+            s_csrc[tid] = s_start[tid] + e;
+            s_carry[tid] = s_cnt[tid] - e;
+            s_gpos[tid] += e;
+        }
+        if (last) break;
+        t_eff = t_next;
+    }
+}
+static_assert(WC_CAP - 15 * WC_MAX_F >= 512, "a tile must always have room for new rows");
+static_assert(WC_CARRY_PT * WC_THREADS == 16 * WC_MAX_F, "carry slots per thread");
 
 // ---------------------------------------------------------------------------
 // join of one sub-partition per work-group, table in LDS.
@@ -551,7 +731,7 @@ static void split_bits(uint32_t total_bits, uint32_t max_per_pass, std::vector<u
             if (v) { out.push_back(v); sum += v; }
             if (*p == ',') ++p; else if (*p) break;
         }
-        if (!out.empty() && out[0] >= 8 && sum >= total_bits) {
+        if (!out.empty() && sum >= total_bits) {   // first entry < 8: experiment only (plain low-bit digits, see make_plan)
             bool ok = true;
             for (uint32_t v : out) ok = ok && v <= 10;
             if (ok) return;
@@ -594,7 +774,7 @@ static void make_plan(uint64_t n_build, uint32_t owners_log2, bool first_pass_is
         pp.bits = bits[k];
         pp.cfg.F = 1u << bits[k];
         pp.cfg.shift = shift;
-        if (k == 0 && first_pass_is_reference_partition) {
+        if (k == 0 && first_pass_is_reference_partition && bits[k] >= 8) {
             pp.cfg.mode = 1;
             pp.cfg.e1 = bits[k] - 8;
             pp.cfg.owners_log2 = owners_log2;
@@ -630,6 +810,44 @@ struct SegTable {
 };
 
 static size_t scatter_lds_bytes(uint32_t F) { return (size_t)PT_TILE * 12 + (size_t)F * 12 + PT_WAVES * 4 + 16; }
+static size_t scatter_wc_lds_bytes(uint32_t F) { return (size_t)WC_CAP * 12 + (size_t)F * 24 + WC_WAVES * 4 + 64; }
+
+// write-combining scatter for fan-outs where a tile's runs are short; the plain tile scatter otherwise
+// Measured on MI355X (1B rows, fan-out 512): the write-combining scatter wins when a work-group's
+// bucket streams stay inside one group's output window (passes >= 2: 21.3 -> 15.3 ms), and loses
+// on the global first pass whose 2 x F streams per work-group span the whole output (18.1 -> 21.5 ms).
+static bool use_wc_scatter(uint32_t F, bool local_pass) {
+    const char* env = getenv("GOLAP_SCATTER");   // "v1" / "wc": A/B hook
+    if (env && !strcmp(env, "v1")) return false;
+    if (F > (uint32_t)WC_MAX_F) return false;
+    if (env && !strcmp(env, "wc")) return true;
+    return local_pass && F >= 32;
+}
+
+template <int TAG>
+static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids, uint32_t rid_base,
+                                const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys, uint32_t* out_rids,
+                                const PassCfg& cfg) {
+    if (hist) {
+        hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg);
+    } else if (wc) {
+        hipLaunchKernelGGL(k_scatter_wc<TAG>, dim3(n_chunks), dim3(WC_THREADS), scatter_wc_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len,
+                           hist_arr, out_keys, out_rids, cfg);
+    } else {
+        hipLaunchKernelGGL(k_scatter<TAG>, dim3(n_chunks), dim3(PT_THREADS), scatter_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len, hist_arr,
+                           out_keys, out_rids, cfg);
+    }
+}
+
+static void launch_pass_kernel(int tag, bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids,
+                               uint32_t rid_base, const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys,
+                               uint32_t* out_rids, const PassCfg& cfg) {
+    switch (tag) {
+        case 0: launch_hist_scatter<1>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg); break;
+        case 1: launch_hist_scatter<2>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg); break;
+        default: launch_hist_scatter<3>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg); break;
+    }
+}
 
 int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums) {
     const uint32_t n_blocks = (uint32_t)ceil_div(n, SC_ELEMS);
@@ -705,7 +923,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         {
             snprintf(name, sizeof name, "radix_hist_p%zu", k + 1);
             KernelTimer t(ctx, name, st, 8 * n_rows);
-            hipLaunchKernelGGL(k_hist, dim3(n_chunks), dim3(PT_THREADS), 0, st, (const long long*)cur_keys, c_off, c_len, hist, pp.cfg);
+            launch_pass_kernel((int)k, true, false, n_chunks, st, (const long long*)cur_keys, nullptr, 0, c_off, c_len, hist, nullptr, nullptr, pp.cfg);
         }
         GOLAP_TRY(flat_scan(ctx, st, hist, (uint32_t)(L + 1), bsums));
         const bool last = k + 1 == np;
@@ -714,8 +932,8 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         {
             snprintf(name, sizeof name, "radix_scatter_p%zu", k + 1);
             KernelTimer t(ctx, name, st, (cur_rids ? 12 : 8) * n_rows + 12 * n_rows);
-            hipLaunchKernelGGL(k_scatter, dim3(n_chunks), dim3(PT_THREADS), scatter_lds_bytes(pp.cfg.F), st, (const long long*)cur_keys,
-                               (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg);
+            launch_pass_kernel((int)k, false, use_wc_scatter(pp.cfg.F, pp.G > 1), n_chunks, st, (const long long*)cur_keys, (const uint32_t*)cur_rids, rid_base,
+                               c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg);
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
         cur_keys = out_keys;
@@ -734,8 +952,12 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
 static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     static bool done = false;
     if (done) return GOLAP_OK;
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)scatter_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
     done = true;
     return GOLAP_OK;
 }
@@ -940,6 +1162,10 @@ int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_para
         if (avg + 4.5 * std::sqrt(avg) <= (double)JN_CAP) break;
     }
     if (need == 0) need = 1;   // always run at least one local pass: it also merges the source segments
+    if (const char* env = getenv("GOLAP_LOCAL_BITS")) {   // experiment hook: total local bits
+        uint32_t v = (uint32_t)strtoul(env, nullptr, 10);
+        if (v >= 1 && v <= 20) need = v;
+    }
     JoinPlan plan;
     {
         uint32_t n_pass = (need + 8) / 9;

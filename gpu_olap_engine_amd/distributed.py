@@ -54,9 +54,10 @@ class HipBackend:
 
 
 class ShardedJoin:
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, max_msg_bytes=1 << 30):
         self.backend = backend
         self.group = group
+        self.max_msg_bytes = max_msg_bytes
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         if N_PARTITIONS % self.world or self.world & (self.world - 1):
@@ -65,33 +66,55 @@ class ShardedJoin:
 
     def _exchange_side(self, keys, rids, offs_host):
         """keys/rids are partitioned owner-major; offs_host[257] are the slot offsets.
-        Returns (recv_keys, recv_rids, seg_off, seg_len) with segments indexed [slot][source]."""
+        Returns (recv_keys, recv_rids, n_recv, seg_off, seg_len) with segments indexed [slot][source].
+
+        The exchange runs in `rounds` all-to-all rounds over consecutive slot ranges so that no single
+        peer message exceeds max_msg_bytes (RCCL send/recv of > 4 GiB messages was observed to deliver
+        garbage on this stack; bounded rounds are also what a pipelined exchange needs)."""
         P, per = self.world, self.per
         dev = keys.device
+        offs = [int(v) for v in offs_host]
         # per-slot sizes of what this rank sends to each peer: [peer][slot]
-        sizes = torch.tensor([[int(offs_host[r * per + s + 1] - offs_host[r * per + s]) for s in range(per)] for r in range(P)],
-                             dtype=torch.int64)
-        send_counts = sizes.sum(dim=1).tolist()
+        sizes = torch.tensor([[offs[r * per + s + 1] - offs[r * per + s] for s in range(per)] for r in range(P)], dtype=torch.int64)
         sz_dev = sizes.to(dev).reshape(-1)
         rsz_dev = torch.empty_like(sz_dev)
         dist.all_to_all_single(rsz_dev, sz_dev, group=self.group)           # sizes[src][slot] of what I receive
         rsz = rsz_dev.cpu().reshape(P, per)
-        recv_counts = rsz.sum(dim=1).tolist()
-        n_recv = int(sum(recv_counts))
+        n_recv = int(rsz.sum())
         rk = self.backend.empty(max(n_recv, 1), torch.int64, keys)
         rr = self.backend.empty(max(n_recv, 1), torch.int32, keys)
-        n_send = int(offs_host[N_PARTITIONS])
-        dist.all_to_all_single(rk[:n_recv], keys[:n_send], recv_counts, send_counts, group=self.group)
-        dist.all_to_all_single(rr[:n_recv], rids[:n_send], recv_counts, send_counts, group=self.group)
-        seg_off, seg_len = [], []
-        src_base = [0] * P
-        for r in range(1, P):
-            src_base[r] = src_base[r - 1] + recv_counts[r - 1]
-        within = torch.cumsum(rsz, dim=1) - rsz                             # exclusive prefix over slots, per source
-        for s in range(per):
+        # rounds: every rank must agree -> derive from the global maximum message (rows)
+        biggest = torch.tensor([max(int(sizes.sum(dim=1).max()), int(rsz.sum(dim=1).max()))], dtype=torch.int64, device=dev)
+        dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=self.group)
+        rounds = max(1, min(per, -(-int(biggest.item()) * 8 // self.max_msg_bytes)))
+        bounds = [per * j // rounds for j in range(rounds + 1)]
+        seg_off = [0] * (per * P)
+        seg_len = [0] * (per * P)
+        pos = 0
+        for j in range(rounds):
+            s0, s1 = bounds[j], bounds[j + 1]
+            if s1 == s0:
+                continue
+            send_counts = sizes[:, s0:s1].sum(dim=1).tolist()
+            recv_counts = rsz[:, s0:s1].sum(dim=1).tolist()
+            n_r = int(sum(recv_counts))
+            if rounds == 1:
+                sk, sr = keys[:offs[N_PARTITIONS]], rids[:offs[N_PARTITIONS]]
+            else:   # gather this round's slot range of every owner into one contiguous send buffer
+                idx = [(offs[r * per + s0], offs[r * per + s1]) for r in range(P)]
+                sk = torch.cat([keys[a:b] for a, b in idx])
+                sr = torch.cat([rids[a:b] for a, b in idx])
+            dist.all_to_all_single(rk[pos:pos + n_r], sk, recv_counts, send_counts, group=self.group)
+            dist.all_to_all_single(rr[pos:pos + n_r], sr, recv_counts, send_counts, group=self.group)
+            src_base = pos
             for r in range(P):
-                seg_off.append(int(src_base[r] + within[r, s]))
-                seg_len.append(int(rsz[r, s]))
+                within = 0
+                for s in range(s0, s1):
+                    seg_off[s * P + r] = src_base + within
+                    seg_len[s * P + r] = int(rsz[r, s])
+                    within += int(rsz[r, s])
+                src_base += recv_counts[r]
+            pos += n_r
         return rk, rr, n_recv, seg_off, seg_len
 
     def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs=None, max_pairs=None):

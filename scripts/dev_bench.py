@@ -37,10 +37,15 @@ def main():
     print(f"copy_bw_GBps {2 * 8 * x.numel() / dt / 1e9:.1f}", flush=True)
     del x
     for v in variants:
-        if v == "default":
+        mode, _, bits = v.partition(":") if ":" in v else ("", "", v)
+        if mode:
+            os.environ["GOLAP_SCATTER"] = mode
+        else:
+            os.environ.pop("GOLAP_SCATTER", None)
+        if bits == "default" or not bits:
             os.environ.pop("GOLAP_PASS_BITS", None)
         else:
-            os.environ["GOLAP_PASS_BITS"] = v
+            os.environ["GOLAP_PASS_BITS"] = bits
         for it in range(3):
             ctx.stats_reset()
             torch.cuda.synchronize()

@@ -63,7 +63,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, variant, q):
+def _worker(rank, world, port, n, variant, q, max_msg=1 << 30):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -79,7 +79,7 @@ def _worker(rank, world, port, n, variant, q):
         else:   # duplicates on both sides + rank 1 holds an empty-ish tail
             b = oracle.gen_sm64_mod(11, lo, hi - lo, n // 2)
             p = oracle.gen_sm64_mod(12, lo, hi - lo, n // 2)
-        sj = ShardedJoin(OracleBackend())
+        sj = ShardedJoin(OracleBackend(), max_msg_bytes=max_msg)
         out = torch.empty((4 * n, 2), dtype=torch.int32)
         pairs, cnt, nb, npr = sj.join(torch.from_numpy(b), torch.from_numpy(p), lo, lo, n, out_pairs=out)
         m = int(cnt.item())
@@ -90,8 +90,9 @@ def _worker(rank, world, port, n, variant, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,variant", [(2, "unique"), (2, "dups"), (4, "unique")])
-def test_sharded_join_gloo(world, variant):
+@pytest.mark.parametrize("world,variant,max_msg", [(2, "unique", 1 << 30), (2, "dups", 1 << 30), (4, "unique", 1 << 30), (2, "unique", 20_000), (4, "dups", 7_000)])
+def test_sharded_join_gloo(world, variant, max_msg):
+    """max_msg small -> the exchange runs in several bounded rounds over slot ranges."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     from np_twin import canonical
@@ -99,7 +100,7 @@ def test_sharded_join_gloo(world, variant):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, variant, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, variant, q, max_msg)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
