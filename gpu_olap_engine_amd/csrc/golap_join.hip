@@ -312,6 +312,110 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
 }
 
 
+
+// ---------------------------------------------------------------------------
+// scatter v3 (global first pass, implicit row ids): register-resident big tile.
+// A tile is 512 threads x BT_RPT keys held in registers; buckets are ranked once for the
+// whole tile, then the tile is pushed through a 4096-row LDS window in BT_NWIN rounds, so a
+// bucket's run per tile is BT_NWIN x longer than in v1 for the same LDS (fan-out 512: 24 rows =
+// 1.5 key lines instead of 8 rows = half a line).  24 keys/thread keep the kernel at 128 VGPRs
+// (two work-groups per CU).  Measured at 1B rows, fan-out 512: 18.0 -> 13.8 ms.  No row-id array is read (join_kernels.cuh:75:
+// row id = position), so the registers go to keys.
+// ---------------------------------------------------------------------------
+constexpr int BT_RPT = 24;
+constexpr int BT_NWIN = 3;
+constexpr int BT_TILE = PT_THREADS * BT_RPT;   // 16384 rows
+constexpr int BT_WIN = BT_TILE / BT_NWIN;      // 4096 rows staged at a time
+
+template <int PASS_TAG>
+__global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* __restrict__ in_keys, uint32_t rid_base,
+                                                            const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
+                                                            const uint32_t* __restrict__ scanned, long long* __restrict__ out_keys,
+                                                            uint32_t* __restrict__ out_rids, PassCfg cfg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [BT_WIN]
+    uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + BT_WIN * 8);      // [BT_WIN]
+    uint32_t* s_cnt = s_rids + BT_WIN;
+    uint32_t* s_start = s_cnt + cfg.F;
+    uint32_t* s_gpos = s_start + cfg.F;
+    uint32_t* s_w = s_gpos + cfg.F;
+
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t len = chunk_len[chunk];
+    if (len == 0) return;
+    const uint32_t off = chunk_off[chunk];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t F = cfg.F;
+    {
+        const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
+        for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] = scanned[((size_t)g * F + f) * cfg.S + s];
+    }
+    for (uint32_t t0 = 0; t0 < len; t0 += BT_TILE) {
+        const uint32_t tn = len - t0 < (uint32_t)BT_TILE ? len - t0 : (uint32_t)BT_TILE;
+        const uint32_t rbase = off + t0;
+        for (uint32_t f = tid; f < F; f += PT_THREADS) s_cnt[f] = 0;
+        long long key[BT_RPT];
+        uint32_t br[BT_RPT];
+#pragma unroll
+        for (int r = 0; r < BT_RPT; ++r) {
+            const uint32_t i = r * PT_THREADS + tid;
+            key[r] = i < tn ? in_keys[rbase + i] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BT_RPT; ++r) {
+            const uint32_t i = r * PT_THREADS + tid;
+            br[r] = 0xFFFFFFFFu;
+            if (i < tn) {
+                const uint32_t b = bucket_of(hash_int64(key[r]), cfg);
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 16384
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
+            const uint32_t c0 = f0 < F ? s_cnt[f0] : 0u, c1 = f1 < F ? s_cnt[f1] : 0u;
+            const uint32_t inc = wave_inclusive_scan(c0 + c1);
+            if (lane == 63) s_w[wv] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < PT_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            const uint32_t e0 = base + inc - (c0 + c1);
+            if (f0 < F) s_start[f0] = e0;
+            if (f1 < F) s_start[f1] = e0 + c0;
+        }
+        __syncthreads();
+        for (uint32_t w0 = 0; w0 < tn; w0 += BT_WIN) {
+#pragma unroll
+            for (int r = 0; r < BT_RPT; ++r) {
+                if (br[r] != 0xFFFFFFFFu) {
+                    const uint32_t pos = s_start[br[r] >> 16] + (br[r] & 0xFFFFu) - w0;   // wraps below the window
+                    if (pos < (uint32_t)BT_WIN) {
+                        s_keys[pos] = key[r];
+                        s_rids[pos] = rid_base + rbase + r * PT_THREADS + tid;          // join_kernels.cuh:75
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t wn = tn - w0 < (uint32_t)BT_WIN ? tn - w0 : (uint32_t)BT_WIN;
+#pragma unroll
+            for (int j = 0; j < BT_WIN / PT_THREADS; ++j) {
+                const uint32_t i = j * PT_THREADS + tid;
+                if (i < wn) {
+                    const long long k = s_keys[i];
+                    const uint32_t b = bucket_of(hash_int64(k), cfg);
+                    const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
+                    out_keys[gp] = k;
+                    out_rids[gp] = s_rids[i];
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] += s_cnt[f];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // scatter v2: line-aligned write combining.
 // rocprofv3 on v1 (profiles/r01a): WRITE_SIZE = 1.54 x the bytes written, because a
@@ -322,15 +426,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
 // the bucket's global cursor and carries the remaining < 16 rows into the next tile, so
 // each line is written exactly once, whole, by one 16-lane group.  Only the first and
 // last line of a (chunk, bucket) run can be partial.
-//   LDS: staging for carry + new rows (8192 x 12 B) + 6 per-bucket words  ~ 108 KiB,
+//   LDS: staging for carry + new rows (12288 x 12 B) + 6 per-bucket words  ~ 156 KiB,
 //   one 1024-thread work-group per CU; the next tile's keys are prefetched into
 //   registers while the current tile is written out.
 // ---------------------------------------------------------------------------
 constexpr int WC_THREADS = 1024;
 constexpr int WC_WAVES = WC_THREADS / 64;
-constexpr int WC_RPT = 4;
+constexpr int WC_RPT = 8;
 constexpr int WC_NEW = WC_THREADS * WC_RPT;   // new rows per tile (max)
-constexpr int WC_CAP = 8192;                  // staging rows (carry + new)
+constexpr int WC_CAP = 12288;                 // staging rows (carry + new): 144 KiB
 constexpr int WC_MAX_F = 512;                 // carry <= 15 * F = 7680 rows, leaves >= 512 new rows per tile
 constexpr int WC_CARRY_PT = 16 * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
 
@@ -517,6 +621,15 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
     if (b1 == b0 || p1 == p0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
+    // the first probe batch is fetched before the table is built: its HBM latency hides behind the build
+    long long pk[JN_R];
+    uint32_t prid[JN_R];
+#pragma unroll
+    for (int r = 0; r < JN_R; ++r) {
+        const uint32_t i = p0 + r * JN_THREADS + tid;
+        pk[r] = i < p1 ? P.keys[i] : 0;
+        prid[r] = i < p1 ? P.rids[i] : 0u;
+    }
     for (uint32_t bc = b0; bc < b1; bc += JN_CAP) {
         const uint32_t nb = b1 - bc < (uint32_t)JN_CAP ? b1 - bc : (uint32_t)JN_CAP;
         for (uint32_t h = tid; h < (1u << JN_LOG2_SLOTS); h += JN_THREADS) heads[h] = JN_EMPTY;
@@ -531,14 +644,16 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
         __syncthreads();
 
         for (uint32_t pc = p0; pc < p1; pc += JN_THREADS * JN_R) {
-            long long pk[JN_R];
-            uint32_t prid[JN_R], cnt[JN_R], first[JN_R], lp[JN_R];
+            uint32_t cnt[JN_R], first[JN_R], lp[JN_R];
+            const bool reload = pc != p0 || (bc != b0 && p1 - p0 > (uint32_t)(JN_THREADS * JN_R));   // registers still hold batch 0 otherwise
 #pragma unroll
             for (int r = 0; r < JN_R; ++r) {
                 const uint32_t i = pc + r * JN_THREADS + tid;
                 const bool ok = i < p1;
-                pk[r] = ok ? P.keys[i] : 0;
-                prid[r] = ok ? P.rids[i] : 0u;
+                if (reload) {
+                    pk[r] = ok ? P.keys[i] : 0;
+                    prid[r] = ok ? P.rids[i] : 0u;
+                }
                 first[r] = ok ? 0u : JN_EMPTY;   // marks invalid rows until the head is read
             }
             // phase A: count matches per probe row (walk the chain, join_kernels.cuh:146-165)
@@ -824,12 +939,27 @@ static bool use_wc_scatter(uint32_t F, bool local_pass) {
     return local_pass && F >= 32;
 }
 
+static size_t scatter_big_lds_bytes(uint32_t F) { return (size_t)BT_WIN * 12 + (size_t)F * 12 + PT_WAVES * 4 + 16; }
+
+// big-tile scatter: global first pass with implicit row ids and a fan-out whose v1 runs would be < 1 line
+static bool use_big_scatter(uint32_t F, bool local_pass, bool has_rids) {
+    const char* env = getenv("GOLAP_SCATTER");
+    if (env && !strcmp(env, "v1")) return false;
+    if (has_rids || local_pass) return false;
+    if (env && !strcmp(env, "big")) return true;
+    if (env && !strcmp(env, "wc")) return false;
+    return F >= 128;
+}
+
 template <int TAG>
 static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids, uint32_t rid_base,
                                 const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys, uint32_t* out_rids,
                                 const PassCfg& cfg) {
     if (hist) {
         hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg);
+    } else if (!wc && use_big_scatter(cfg.F, false, rids != nullptr) && TAG == 1) {
+        hipLaunchKernelGGL(k_scatter_big<1>, dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
+                           out_keys, out_rids, cfg);
     } else if (wc) {
         hipLaunchKernelGGL(k_scatter_wc<TAG>, dim3(n_chunks), dim3(WC_THREADS), scatter_wc_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len,
                            hist_arr, out_keys, out_rids, cfg);
@@ -955,6 +1085,7 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
