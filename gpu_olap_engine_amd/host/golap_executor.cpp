@@ -1,0 +1,772 @@
+// golap_executor.cpp -- GpuExecutor: the reference's operator API over Arrow RecordBatches,
+// written in C++ on top of the C ABI (include/golap.h) only.  No HIP calls here: device
+// memory comes from the SlabAllocator entry points, copies go through the TransferQueue.
+//
+// Mirrors gpu-olap-core/src/executor.rs:
+//   execute            :15-24, dispatch :37-104
+//   execute_table_scan :110-155   (empty batch, as the reference)
+//   execute_filter     :161-178   -> golap_filter_compact + golap_take_8byte
+//   execute_projection :184-214   (column references and literals)
+//   execute_hash_join  :220-265   -> golap_join; unlike the reference (which returns an empty
+//                                    batch at :255-264) the pairs are materialised
+//   execute_aggregate  :297-355   -> golap_aggregate (ungrouped = reference; grouped = dense keys)
+//   execute_sort       :361-370   (pass-through, as the reference)
+//   eval_expr          :377-409   (column by name first, then by index)
+#include <algorithm>
+#include <cerrno>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/golap_host.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// host RecordBatch
+// ---------------------------------------------------------------------------
+enum class DType { Int64, Float64, Int32, Other };
+
+struct Column {
+    std::string name;
+    DType dtype = DType::Other;
+    std::vector<uint8_t> data;   // packed little-endian values, nulls -> 0 (record_batch_convert.rs:102-110)
+    uint64_t rows = 0;
+    size_t width() const { return dtype == DType::Int32 ? 4 : 8; }
+};
+
+struct RecordBatch {
+    std::vector<Column> cols;
+    uint64_t num_rows = 0;
+    int index_of(const std::string& name) const {
+        for (size_t i = 0; i < cols.size(); ++i)
+            if (cols[i].name == name) return (int)i;
+        return -1;
+    }
+};
+
+thread_local std::string g_err;
+int32_t herr(int32_t code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+DType dtype_of_format(const char* f) {
+    if (!f) return DType::Other;
+    if (!strcmp(f, "l")) return DType::Int64;
+    if (!strcmp(f, "g")) return DType::Float64;
+    if (!strcmp(f, "i")) return DType::Int32;
+    return DType::Other;
+}
+const char* format_of_dtype(DType d) { return d == DType::Int64 ? "l" : d == DType::Float64 ? "g" : d == DType::Int32 ? "i" : "n"; }
+
+bool import_batch(ArrowArray* arr, ArrowSchema* sch, RecordBatch& out, std::string& err) {
+    if (!arr || !sch || !sch->format || strcmp(sch->format, "+s")) { err = "expected an Arrow struct array (format +s)"; return false; }
+    if (arr->n_children != sch->n_children) { err = "array/schema children mismatch"; return false; }
+    out.num_rows = (uint64_t)arr->length;
+    for (int64_t c = 0; c < sch->n_children; ++c) {
+        ArrowSchema* cs = sch->children[c];
+        ArrowArray* ca = arr->children[c];
+        Column col;
+        col.name = cs->name ? cs->name : "";
+        col.dtype = dtype_of_format(cs->format);
+        col.rows = out.num_rows;
+        if (col.dtype != DType::Other) {
+            const size_t w = col.width();
+            col.data.resize((size_t)out.num_rows * w);
+            const uint8_t* src = ca->n_buffers >= 2 ? (const uint8_t*)ca->buffers[1] : nullptr;
+            const uint8_t* valid = ca->n_buffers >= 1 ? (const uint8_t*)ca->buffers[0] : nullptr;
+            const int64_t off = ca->offset + arr->offset;
+            if (out.num_rows && !src) { err = "column '" + col.name + "' has no data buffer"; return false; }
+            if (out.num_rows) memcpy(col.data.data(), src + (size_t)off * w, (size_t)out.num_rows * w);
+            if (valid && ca->null_count != 0) {
+                for (uint64_t i = 0; i < out.num_rows; ++i) {
+                    const int64_t j = off + (int64_t)i;
+                    if (!((valid[j >> 3] >> (j & 7)) & 1)) memset(col.data.data() + i * w, 0, w);   // null -> 0
+                }
+            }
+        }
+        out.cols.push_back(std::move(col));
+    }
+    return true;
+}
+
+// ---- export (the exported arrays own copies of the column data) ----
+struct ExportPriv {
+    std::vector<std::vector<uint8_t>> data;
+    std::vector<const void*> bufs;   // 2 per child + 1 for the struct
+    std::vector<ArrowArray> child_arrays;
+    std::vector<ArrowArray*> child_ptrs;
+    std::vector<ArrowSchema> child_schemas;
+    std::vector<ArrowSchema*> child_sptrs;
+    std::vector<std::string> names;
+};
+void release_child_array(ArrowArray* a) { a->release = nullptr; }
+void release_child_schema(ArrowSchema* s) { s->release = nullptr; }
+void release_array(ArrowArray* a) {
+    if (!a || !a->release) return;
+    for (int64_t i = 0; i < a->n_children; ++i)
+        if (a->children[i]->release) a->children[i]->release(a->children[i]);
+    delete (std::shared_ptr<ExportPriv>*)a->private_data;
+    a->release = nullptr;
+}
+void release_schema(ArrowSchema* s) {
+    if (!s || !s->release) return;
+    for (int64_t i = 0; i < s->n_children; ++i)
+        if (s->children[i]->release) s->children[i]->release(s->children[i]);
+    delete (std::shared_ptr<ExportPriv>*)s->private_data;
+    s->release = nullptr;
+}
+
+void export_batch(RecordBatch&& b, ArrowArray* oa, ArrowSchema* os) {
+    auto priv = std::make_shared<ExportPriv>();
+    const size_t nc = b.cols.size();
+    priv->data.resize(nc);
+    priv->bufs.resize(2 * nc + 1, nullptr);
+    priv->child_arrays.resize(nc);
+    priv->child_schemas.resize(nc);
+    priv->names.resize(nc);
+    for (size_t c = 0; c < nc; ++c) {
+        priv->data[c] = std::move(b.cols[c].data);
+        priv->names[c] = b.cols[c].name;
+        priv->bufs[2 * c] = nullptr;
+        priv->bufs[2 * c + 1] = priv->data[c].empty() ? (const void*)"" : (const void*)priv->data[c].data();
+        ArrowArray& ca = priv->child_arrays[c];
+        memset(&ca, 0, sizeof ca);
+        ca.length = (int64_t)b.num_rows;
+        ca.n_buffers = 2;
+        ca.buffers = &priv->bufs[2 * c];
+        ca.release = release_child_array;
+        ArrowSchema& cs = priv->child_schemas[c];
+        memset(&cs, 0, sizeof cs);
+        cs.format = format_of_dtype(b.cols[c].dtype);
+        cs.name = priv->names[c].c_str();
+        cs.flags = 0;
+        cs.release = release_child_schema;
+        priv->child_ptrs.push_back(&ca);
+        priv->child_sptrs.push_back(&cs);
+    }
+    memset(oa, 0, sizeof *oa);
+    oa->length = (int64_t)b.num_rows;
+    oa->n_buffers = 1;
+    oa->buffers = &priv->bufs[2 * nc];
+    oa->n_children = (int64_t)nc;
+    oa->children = priv->child_ptrs.data();
+    oa->release = release_array;
+    oa->private_data = new std::shared_ptr<ExportPriv>(priv);
+    memset(os, 0, sizeof *os);
+    os->format = "+s";
+    os->name = "";
+    os->n_children = (int64_t)nc;
+    os->children = priv->child_sptrs.data();
+    os->release = release_schema;
+    os->private_data = new std::shared_ptr<ExportPriv>(priv);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// plan / expr nodes
+// ---------------------------------------------------------------------------
+struct golap_expr {
+    enum Kind { Column, Literal, Binary } kind;
+    uint64_t index = 0;
+    std::string name, value, op;
+    std::unique_ptr<golap_expr> left, right;
+};
+
+struct golap_plan {
+    enum Kind { Batches, TableScan, Filter, Projection, HashJoin, Aggregate, Sort } kind;
+    std::vector<RecordBatch> batches;              // Batches / TableScan (one empty batch)
+    std::unique_ptr<golap_plan> input, right;      // input = left for joins
+    std::unique_ptr<golap_expr> predicate;
+    std::vector<std::unique_ptr<golap_expr>> exprs, left_keys, right_keys, group_by, aggr_inputs;
+    std::vector<int32_t> aggr_funcs;
+    golap_join_type join_type = GOLAP_JOIN_INNER;
+};
+
+struct golap_result {
+    std::vector<RecordBatch> batches;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// device helpers (slabs + transfer queue)
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    golap_ctx* ctx = nullptr;
+    uint64_t ptr = 0;
+    uint32_t cls = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), ptr(o.ptr), cls(o.cls) { o.ptr = 0; }
+    ~DevBuf() { if (ptr) golap_slab_free(ctx, ptr, cls); }
+    int32_t alloc(golap_ctx* c, uint64_t bytes) {
+        ctx = c;
+        return golap_slab_alloc(c, std::max<uint64_t>(bytes, 8), &ptr, &cls);
+    }
+};
+
+#define H_TRY(expr)                      \
+    do {                                 \
+        int32_t _s = (expr);             \
+        if (_s != GOLAP_OK) return _s;   \
+    } while (0)
+
+struct Exec {
+    golap_ctx* ctx;
+    uint32_t next_stream = 0;
+
+    int32_t h2d(const void* src, uint64_t dst, uint64_t bytes) {
+        // split large columns over the transfer streams (transfer_queue.rs:72 round-robin)
+        const uint64_t piece = 64ull << 20;
+        for (uint64_t o = 0; o < bytes; o += piece)
+            H_TRY(golap_xfer_enqueue(ctx, GOLAP_HOST_TO_DEVICE, (uint64_t)(uintptr_t)src + o, dst + o, std::min(piece, bytes - o), next_stream++));
+        return GOLAP_OK;
+    }
+    int32_t d2h(uint64_t src, void* dst, uint64_t bytes) {
+        const uint64_t piece = 64ull << 20;
+        for (uint64_t o = 0; o < bytes; o += piece)
+            H_TRY(golap_xfer_enqueue(ctx, GOLAP_DEVICE_TO_HOST, src + o, (uint64_t)(uintptr_t)dst + o, std::min(piece, bytes - o), next_stream++));
+        return GOLAP_OK;
+    }
+    int32_t xsync() { return golap_xfer_synchronize(ctx); }
+    int32_t ksync() { return golap_ctx_synchronize(ctx, nullptr); }
+
+    // eval_expr, executor.rs:377-409: column by NAME first, then by index
+    static int resolve_column(const golap_expr& e, const RecordBatch& b) {
+        int i = b.index_of(e.name);
+        if (i >= 0) return i;
+        if (e.index < b.cols.size()) return (int)e.index;
+        return -1;
+    }
+
+    int32_t run(golap_plan& p, std::vector<RecordBatch>& out);
+    int32_t filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::vector<RecordBatch>& out);
+    int32_t projection(std::vector<RecordBatch>& in, const std::vector<std::unique_ptr<golap_expr>>& exprs, std::vector<RecordBatch>& out);
+    int32_t hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out);
+    int32_t aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
+};
+
+bool parse_i64(const std::string& s, int64_t& v) {
+    if (s.empty()) return false;
+    char* end = nullptr;
+    errno = 0;
+    long long x = strtoll(s.c_str(), &end, 10);
+    if (errno || *end) return false;
+    v = x;
+    return true;
+}
+
+golap_cmp_op flip(golap_cmp_op op) {
+    switch (op) {
+        case GOLAP_CMP_LT: return GOLAP_CMP_GT;
+        case GOLAP_CMP_LE: return GOLAP_CMP_GE;
+        case GOLAP_CMP_GT: return GOLAP_CMP_LT;
+        case GOLAP_CMP_GE: return GOLAP_CMP_LE;
+        default: return op;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// execute_filter, executor.rs:161-178 / eval_filter_mask :443-476 / filter_record_batch :478-494
+// ---------------------------------------------------------------------------
+int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::vector<RecordBatch>& out) {
+    for (RecordBatch& b : in) {
+        // non-binary predicate => every row passes (:474)
+        if (pred.kind != golap_expr::Binary) { out.push_back(std::move(b)); continue; }
+        const golap_expr *l = pred.left.get(), *r = pred.right.get();
+        golap_cmp_op op = golap_parse_cmp_op(pred.op.c_str());
+        const golap_expr *colx = nullptr, *litx = nullptr;
+        if (l->kind == golap_expr::Column && r->kind == golap_expr::Literal) { colx = l; litx = r; }
+        else if (l->kind == golap_expr::Literal && r->kind == golap_expr::Column) { colx = r; litx = l; op = flip(op); }
+        else return herr(GOLAP_ERR_UNSUPPORTED, "GpuFilter: only <column> <op> <literal> predicates run on the device");
+        const int ci = resolve_column(*colx, b);
+        if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + colx->name + "' not found in batch");   // :386
+        int64_t lit;
+        // operands that are not both Int64 => every row passes (:449-452, :471-472)
+        if (b.cols[ci].dtype != DType::Int64 || !parse_i64(litx->value, lit)) { out.push_back(std::move(b)); continue; }
+        const uint64_t n = b.num_rows;
+        if (n == 0) continue;   // empty batches are dropped (:173)
+        DevBuf dkey, didx, dcnt;
+        H_TRY(dkey.alloc(ctx, n * 8));
+        H_TRY(didx.alloc(ctx, n * 4));
+        H_TRY(dcnt.alloc(ctx, 8));
+        H_TRY(h2d(b.cols[ci].data.data(), dkey.ptr, n * 8));
+        H_TRY(xsync());
+        golap_filter_predicate fp{(uint64_t)ci, (int32_t)op, lit};
+        H_TRY(golap_filter_compact(ctx, &fp, dkey.ptr, n, didx.ptr, dcnt.ptr, nullptr));
+        H_TRY(ksync());
+        uint64_t kept = 0;
+        H_TRY(d2h(dcnt.ptr, &kept, 8));
+        H_TRY(xsync());
+        if (kept == 0) continue;
+        RecordBatch ob;
+        ob.num_rows = kept;
+        for (Column& c : b.cols) {
+            if (c.dtype != DType::Int64 && c.dtype != DType::Float64)
+                return herr(GOLAP_ERR_UNSUPPORTED, "GpuFilter: column '" + c.name + "' is neither Int64 nor Float64 (take_int64, executor.rs:496-507)");
+            DevBuf dcol, dout;
+            H_TRY(dcol.alloc(ctx, n * 8));
+            H_TRY(dout.alloc(ctx, kept * 8));
+            H_TRY(h2d(c.data.data(), dcol.ptr, n * 8));
+            H_TRY(xsync());
+            H_TRY(golap_take_8byte(ctx, dcol.ptr, didx.ptr, 0, kept, dout.ptr, nullptr));
+            H_TRY(ksync());
+            Column oc;
+            oc.name = c.name; oc.dtype = c.dtype; oc.rows = kept;
+            oc.data.resize(kept * 8);
+            H_TRY(d2h(dout.ptr, oc.data.data(), kept * 8));
+            H_TRY(xsync());
+            ob.cols.push_back(std::move(oc));
+        }
+        out.push_back(std::move(ob));
+    }
+    return GOLAP_OK;
+}
+
+// execute_projection, executor.rs:184-214 (column references and literals; arithmetic stays on the planner's CPU side)
+int32_t Exec::projection(std::vector<RecordBatch>& in, const std::vector<std::unique_ptr<golap_expr>>& exprs, std::vector<RecordBatch>& out) {
+    for (RecordBatch& b : in) {
+        RecordBatch ob;
+        ob.num_rows = b.num_rows;
+        for (const auto& e : exprs) {
+            if (e->kind == golap_expr::Column) {
+                const int ci = resolve_column(*e, b);
+                if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + e->name + "' not found in batch");
+                Column c = b.cols[ci];
+                c.name = e->name;                      // expr_name, :531
+                ob.cols.push_back(std::move(c));
+            } else if (e->kind == golap_expr::Literal) {
+                int64_t v;
+                if (!parse_i64(e->value, v)) return herr(GOLAP_ERR_UNSUPPORTED, "Cannot parse literal '" + e->value + "'");   // :400
+                Column c;
+                c.name = "lit(" + e->value + ")";      // :532
+                c.dtype = DType::Int64; c.rows = b.num_rows;
+                c.data.resize(b.num_rows * 8);
+                for (uint64_t i = 0; i < b.num_rows; ++i) memcpy(c.data.data() + i * 8, &v, 8);
+                ob.cols.push_back(std::move(c));
+            } else {
+                return herr(GOLAP_ERR_UNSUPPORTED, "GpuProjection: arithmetic expressions are outside the accelerated path");
+            }
+        }
+        out.push_back(std::move(ob));
+    }
+    return GOLAP_OK;
+}
+
+// concatenates column `ci(b)` of every batch; returns false if any batch's column is not Int64
+static bool concat_i64(const std::vector<RecordBatch>& bs, const golap_expr& key, std::vector<int64_t>& out, std::string& err) {
+    for (const RecordBatch& b : bs) {
+        const int ci = Exec::resolve_column(key, b);
+        if (ci < 0) { err = "Column '" + key.name + "' not found in batch"; return false; }
+        if (b.cols[ci].dtype != DType::Int64) { err = "join key '" + key.name + "' must be Int64 (executor.rs:246)"; return false; }
+        const size_t o = out.size();
+        out.resize(o + b.num_rows);
+        if (b.num_rows) memcpy(out.data() + o, b.cols[ci].data.data(), b.num_rows * 8);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// execute_hash_join, executor.rs:220-265
+// ---------------------------------------------------------------------------
+int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out) {
+    if (left.empty() || right.empty()) return GOLAP_OK;                 // :231-233 -> vec![]
+    if (p.join_type != GOLAP_JOIN_INNER) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: only JoinType::Inner is implemented (join_kernels.cuh:115-166 is inner)");
+    if (p.left_keys.empty() || p.right_keys.empty()) return herr(GOLAP_ERR_INVALID_ARG, "GpuHashJoin needs one key per side");
+    // FIRST key expression only (:245)
+    const golap_expr &lk = *p.left_keys[0], &rk = *p.right_keys[0];
+    if (lk.kind != golap_expr::Column || rk.kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: key expressions must be column references");
+    std::vector<int64_t> bkeys, pkeys;
+    std::string err;
+    if (!concat_i64(left, lk, bkeys, err) || !concat_i64(right, rk, pkeys, err)) return herr(GOLAP_ERR_INVALID_ARG, err);
+    const uint64_t nb = bkeys.size(), np = pkeys.size();   // global row index = running offset over batches (:249, :252)
+    RecordBatch ob;
+    // output schema: left fields then right fields
+    for (const Column& c : left[0].cols) { Column oc; oc.name = c.name; oc.dtype = c.dtype; ob.cols.push_back(oc); }
+    const size_t n_left_cols = ob.cols.size();
+    for (const Column& c : right[0].cols) { Column oc; oc.name = c.name; oc.dtype = c.dtype; ob.cols.push_back(oc); }
+    for (const Column& c : ob.cols)
+        if (c.dtype != DType::Int64 && c.dtype != DType::Float64) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: payload column '" + c.name + "' is neither Int64 nor Float64");
+    uint64_t m = 0;
+    DevBuf dpairs;
+    if (nb && np) {
+        DevBuf db, dp, dcnt;
+        H_TRY(db.alloc(ctx, nb * 8));
+        H_TRY(dp.alloc(ctx, np * 8));
+        H_TRY(dcnt.alloc(ctx, 8));
+        H_TRY(h2d(bkeys.data(), db.ptr, nb * 8));
+        H_TRY(h2d(pkeys.data(), dp.ptr, np * 8));
+        H_TRY(xsync());
+        uint64_t cap = np;   // first guess: one match per probe row; the count is the TRUE total (join_kernels.cuh:155-160)
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            H_TRY(dpairs.alloc(ctx, cap * 8));
+            golap_join_params jp;
+            memset(&jp, 0, sizeof jp);
+            jp.build_key_ptr = db.ptr; jp.probe_key_ptr = dp.ptr; jp.n_build = nb; jp.n_probe = np;
+            jp.out_pairs_ptr = dpairs.ptr; jp.out_count_ptr = dcnt.ptr; jp.max_pairs = cap;
+            H_TRY(golap_join(ctx, golap_choose_strategy(nb), &jp, nullptr));   // JoinKernel::choose_strategy, join_kernel.rs:71-77
+            H_TRY(ksync());
+            H_TRY(d2h(dcnt.ptr, &m, 8));
+            H_TRY(xsync());
+            if (m <= cap) break;
+            DevBuf old = std::move(dpairs);   // too small: release, then retry with the exact size
+            cap = m;
+        }
+    }
+    ob.num_rows = m;
+    if (m) {
+        // split the interleaved pairs into two index vectors on the host, then gather every payload column on the device
+        std::vector<uint32_t> pairs(2 * m), lidx(m), ridx(m);
+        H_TRY(d2h(dpairs.ptr, pairs.data(), m * 8));
+        H_TRY(xsync());
+        // canonical order (probe_rid, build_rid): the device order is unspecified (join_kernels.cuh:155)
+        std::vector<uint64_t> keyed(m);
+        for (uint64_t i = 0; i < m; ++i) keyed[i] = ((uint64_t)pairs[2 * i + 1] << 32) | pairs[2 * i];
+        std::sort(keyed.begin(), keyed.end());
+        for (uint64_t i = 0; i < m; ++i) { lidx[i] = (uint32_t)keyed[i]; ridx[i] = (uint32_t)(keyed[i] >> 32); }
+        DevBuf dl, dr;
+        H_TRY(dl.alloc(ctx, m * 4));
+        H_TRY(dr.alloc(ctx, m * 4));
+        H_TRY(h2d(lidx.data(), dl.ptr, m * 4));
+        H_TRY(h2d(ridx.data(), dr.ptr, m * 4));
+        H_TRY(xsync());
+        for (size_t c = 0; c < ob.cols.size(); ++c) {
+            const bool is_left = c < n_left_cols;
+            const std::vector<RecordBatch>& side = is_left ? left : right;
+            const size_t sc = is_left ? c : c - n_left_cols;
+            const uint64_t rows = is_left ? nb : np;
+            std::vector<uint8_t> whole(rows * 8);
+            size_t o = 0;
+            for (const RecordBatch& b : side) {
+                if (sc >= b.cols.size() || b.cols[sc].dtype != ob.cols[c].dtype) return herr(GOLAP_ERR_INVALID_ARG, "batches of one side differ in schema");
+                if (b.num_rows) memcpy(whole.data() + o, b.cols[sc].data.data(), b.num_rows * 8);
+                o += b.num_rows * 8;
+            }
+            DevBuf dcol, dout;
+            H_TRY(dcol.alloc(ctx, rows * 8));
+            H_TRY(dout.alloc(ctx, m * 8));
+            H_TRY(h2d(whole.data(), dcol.ptr, rows * 8));
+            H_TRY(xsync());
+            H_TRY(golap_take_8byte(ctx, dcol.ptr, is_left ? dl.ptr : dr.ptr, 0, m, dout.ptr, nullptr));
+            H_TRY(ksync());
+            ob.cols[c].rows = m;
+            ob.cols[c].data.resize(m * 8);
+            H_TRY(d2h(dout.ptr, ob.cols[c].data.data(), m * 8));
+            H_TRY(xsync());
+        }
+    }
+    out.push_back(std::move(ob));   // one batch, like the reference's single output batch (:262-264)
+    return GOLAP_OK;
+}
+
+static const char* agg_name(int32_t f) {
+    switch (f) { case GOLAP_AGG_SUM: return "sum"; case GOLAP_AGG_COUNT: return "count"; case GOLAP_AGG_MIN: return "min"; case GOLAP_AGG_MAX: return "max"; default: return "avg"; }
+}
+
+// ---------------------------------------------------------------------------
+// execute_aggregate, executor.rs:297-355 (+ eval_agg_input :509-527)
+// ---------------------------------------------------------------------------
+int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out) {
+    const uint32_t na = (uint32_t)p.aggr_inputs.size();
+    // gather the distinct value columns the aggregates read
+    std::vector<std::string> val_names;
+    std::vector<uint64_t> spec_col(na);
+    for (uint32_t i = 0; i < na; ++i) {
+        const golap_expr& e = *p.aggr_inputs[i];
+        if (e.kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: aggregate inputs must be column references");
+        auto it = std::find(val_names.begin(), val_names.end(), e.name);
+        if (it == val_names.end()) { val_names.push_back(e.name); spec_col[i] = val_names.size() - 1; }
+        else spec_col[i] = (uint64_t)(it - val_names.begin());
+    }
+    uint64_t n = 0;
+    for (const RecordBatch& b : in) n += b.num_rows;
+    const uint32_t nv = (uint32_t)val_names.size();
+    std::vector<DevBuf> dvals(nv);
+    std::vector<uint64_t> vptrs(nv);
+    std::vector<int32_t> vdt(nv, GOLAP_DT_INT64);
+    for (uint32_t v = 0; v < nv; ++v) {
+        H_TRY(dvals[v].alloc(ctx, n * 8));
+        vptrs[v] = dvals[v].ptr;
+        uint64_t o = 0;
+        for (const RecordBatch& b : in) {
+            golap_expr e; e.kind = golap_expr::Column; e.name = val_names[v];
+            for (uint32_t i = 0; i < na; ++i) if (p.aggr_inputs[i]->name == val_names[v]) { e.index = p.aggr_inputs[i]->index; break; }
+            const int ci = resolve_column(e, b);
+            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + val_names[v] + "' not found in batch");
+            const Column& c = b.cols[ci];
+            if (c.dtype != DType::Int64 && c.dtype != DType::Float64)
+                return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: input '" + c.name + "' must be Int64 or Float64 (executor.rs:520-526)");
+            vdt[v] = c.dtype == DType::Float64 ? GOLAP_DT_FLOAT64 : GOLAP_DT_INT64;
+            if (b.num_rows) H_TRY(h2d(c.data.data(), dvals[v].ptr + o, b.num_rows * 8));
+            o += b.num_rows * 8;
+        }
+    }
+    std::vector<golap_aggregate_spec> specs(na);
+    for (uint32_t i = 0; i < na; ++i) specs[i] = golap_aggregate_spec{p.aggr_funcs[i], spec_col[i], i};
+    RecordBatch ob;
+    if (p.group_by.empty()) {
+        // the reference's single-group result: one Float64 scalar per aggregate (:330-349)
+        DevBuf dout;
+        H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * 8));
+        H_TRY(xsync());
+        golap_aggregate_params ap;
+        memset(&ap, 0, sizeof ap);
+        ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = 1; ap.out_ptr = dout.ptr;
+        ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data();
+        H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
+        H_TRY(ksync());
+        std::vector<double> res(std::max<uint32_t>(na, 1));
+        H_TRY(d2h(dout.ptr, res.data(), (uint64_t)na * 8));
+        H_TRY(xsync());
+        ob.num_rows = 1;
+        for (uint32_t i = 0; i < na; ++i) {
+            Column c;
+            c.name = std::string(agg_name(p.aggr_funcs[i])) + "(" + p.aggr_inputs[i]->name + ")";
+            c.dtype = DType::Float64; c.rows = 1;
+            c.data.resize(8);
+            memcpy(c.data.data(), &res[i], 8);
+            ob.cols.push_back(std::move(c));
+        }
+        out.push_back(std::move(ob));
+        return GOLAP_OK;
+    }
+    // GROUP BY one Int64/Int32 key with dense non-negative values: slot = key % n_groups (join_kernels.cuh:230)
+    if (p.group_by.size() != 1 || p.group_by[0]->kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: one group-by column is supported");
+    std::vector<int64_t> keys;
+    {
+        keys.reserve(n);
+        for (const RecordBatch& b : in) {
+            const int ci = resolve_column(*p.group_by[0], b);
+            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + p.group_by[0]->name + "' not found in batch");
+            const Column& c = b.cols[ci];
+            if (c.dtype == DType::Int64) { const int64_t* k = (const int64_t*)c.data.data(); keys.insert(keys.end(), k, k + b.num_rows); }
+            else if (c.dtype == DType::Int32) { const int32_t* k = (const int32_t*)c.data.data(); for (uint64_t i = 0; i < b.num_rows; ++i) keys.push_back(k[i]); }
+            else return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group key must be Int64 or Int32");
+        }
+    }
+    ob.num_rows = 0;
+    Column kc; kc.name = p.group_by[0]->name; kc.dtype = DType::Int64;
+    std::vector<Column> acs(na);
+    for (uint32_t i = 0; i < na; ++i) { acs[i].name = std::string(agg_name(p.aggr_funcs[i])) + "(" + p.aggr_inputs[i]->name + ")"; acs[i].dtype = DType::Float64; }
+    if (n) {
+        DevBuf dk, dmm;
+        H_TRY(dk.alloc(ctx, n * 8));
+        H_TRY(dmm.alloc(ctx, 16));
+        H_TRY(h2d(keys.data(), dk.ptr, n * 8));
+        H_TRY(xsync());
+        // key range on the device: ungrouped MIN / MAX of the key column
+        golap_aggregate_spec mm[2] = {{GOLAP_AGG_MIN, 0, 0}, {GOLAP_AGG_MAX, 0, 1}};
+        uint64_t kp = dk.ptr; int32_t kd = GOLAP_DT_INT64;
+        golap_aggregate_params ap;
+        memset(&ap, 0, sizeof ap);
+        ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.n_rows = n; ap.n_groups = 1; ap.out_ptr = dmm.ptr; ap.value_dtypes = &kd;
+        H_TRY(golap_aggregate(ctx, mm, 2, &ap, nullptr));
+        H_TRY(ksync());
+        double mmv[2];
+        H_TRY(d2h(dmm.ptr, mmv, 16));
+        H_TRY(xsync());
+        if (mmv[0] < 0 || mmv[1] > 9e15) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group keys must be non-negative and dense");
+        const int64_t kmin = (int64_t)mmv[0], kmax = (int64_t)mmv[1];
+        const uint64_t G = (uint64_t)(kmax - kmin) + 1;
+        if (G > (64ull << 20)) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: key range too wide for the dense group table");
+        DevBuf dout, dcnt;
+        H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * G * 8));
+        H_TRY(dcnt.alloc(ctx, G * 8));
+        memset(&ap, 0, sizeof ap);
+        ap.group_key_ptr = dk.ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)G;
+        ap.out_ptr = dout.ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt.ptr;
+        if (na == 0) {   // GROUP BY without aggregates: count only, to find the present groups
+            golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
+            ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd;
+            H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
+        } else {
+            H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
+        }
+        H_TRY(ksync());
+        std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * G);
+        std::vector<uint64_t> cnt(G);
+        H_TRY(d2h(dout.ptr, res.data(), res.size() * 8));
+        H_TRY(d2h(dcnt.ptr, cnt.data(), G * 8));
+        H_TRY(xsync());
+        for (int64_t k = kmin; k <= kmax; ++k) {           // rows sorted by key
+            const uint64_t slot = (uint64_t)k % G;
+            if (!cnt[slot]) continue;
+            kc.data.insert(kc.data.end(), (const uint8_t*)&k, (const uint8_t*)&k + 8);
+            for (uint32_t i = 0; i < na; ++i) {
+                const double v = res[(size_t)i * G + slot];
+                acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&v, (const uint8_t*)&v + 8);
+            }
+            ob.num_rows++;
+        }
+    }
+    kc.rows = ob.num_rows;
+    ob.cols.push_back(std::move(kc));
+    for (auto& c : acs) { c.rows = ob.num_rows; ob.cols.push_back(std::move(c)); }
+    out.push_back(std::move(ob));
+    return GOLAP_OK;
+}
+
+// GpuExecutor::execute, executor.rs:37-104: children fully materialised before the parent runs
+int32_t Exec::run(golap_plan& p, std::vector<RecordBatch>& out) {
+    switch (p.kind) {
+        case golap_plan::Batches:
+        case golap_plan::TableScan:
+            out = std::move(p.batches);
+            return GOLAP_OK;
+        case golap_plan::Filter: {
+            std::vector<RecordBatch> in;
+            H_TRY(run(*p.input, in));
+            return filter(in, *p.predicate, out);
+        }
+        case golap_plan::Projection: {
+            std::vector<RecordBatch> in;
+            H_TRY(run(*p.input, in));
+            return projection(in, p.exprs, out);
+        }
+        case golap_plan::HashJoin: {
+            std::vector<RecordBatch> l, r;
+            H_TRY(run(*p.input, l));
+            H_TRY(run(*p.right, r));
+            return hash_join(l, r, p, out);
+        }
+        case golap_plan::Aggregate: {
+            std::vector<RecordBatch> in;
+            H_TRY(run(*p.input, in));
+            return aggregate(in, p, out);
+        }
+        case golap_plan::Sort:
+            return run(*p.input, out);   // executor.rs:361-370: pass-through
+    }
+    return herr(GOLAP_ERR_INVALID_ARG, "unknown plan node");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+golap_expr* golap_expr_column(uint64_t index, const char* name) {
+    auto* e = new golap_expr();
+    e->kind = golap_expr::Column; e->index = index; e->name = name ? name : "";
+    return e;
+}
+golap_expr* golap_expr_literal(const char* value) {
+    auto* e = new golap_expr();
+    e->kind = golap_expr::Literal; e->value = value ? value : "";
+    return e;
+}
+golap_expr* golap_expr_binary(golap_expr* left, const char* op, golap_expr* right) {
+    auto* e = new golap_expr();
+    e->kind = golap_expr::Binary; e->op = op ? op : "";
+    e->left.reset(left); e->right.reset(right);
+    return e;
+}
+void golap_expr_free(golap_expr* e) { delete e; }
+
+golap_plan* golap_plan_batches(ArrowArray** arrays, ArrowSchema** schemas, uint32_t n_batches) {
+    auto p = std::make_unique<golap_plan>();
+    p->kind = golap_plan::Batches;
+    bool ok = true;
+    std::string err;
+    for (uint32_t i = 0; i < n_batches; ++i) {
+        RecordBatch b;
+        if (ok && !import_batch(arrays[i], schemas[i], b, err)) ok = false;
+        if (ok) p->batches.push_back(std::move(b));
+        if (arrays[i] && arrays[i]->release) arrays[i]->release(arrays[i]);      // moved in
+        if (schemas[i] && schemas[i]->release) schemas[i]->release(schemas[i]);
+    }
+    if (!ok) { g_err = err; return nullptr; }
+    return p.release();
+}
+
+golap_plan* golap_plan_table_scan(const char* table_name, ArrowSchema* schema) {
+    (void)table_name;
+    auto p = std::make_unique<golap_plan>();
+    p->kind = golap_plan::TableScan;
+    RecordBatch b;   // executor.rs:138-154: one empty batch; Float32/Float64 fields -> Float64, everything else -> Int64
+    if (schema && schema->format && !strcmp(schema->format, "+s")) {
+        for (int64_t c = 0; c < schema->n_children; ++c) {
+            Column col;
+            col.name = schema->children[c]->name ? schema->children[c]->name : "";
+            const char* f = schema->children[c]->format;
+            col.dtype = (f && (!strcmp(f, "g") || !strcmp(f, "f"))) ? DType::Float64 : DType::Int64;
+            b.cols.push_back(col);
+        }
+    }
+    if (schema && schema->release) schema->release(schema);
+    p->batches.push_back(std::move(b));
+    return p.release();
+}
+
+golap_plan* golap_plan_filter(golap_plan* input, golap_expr* predicate) {
+    auto* p = new golap_plan();
+    p->kind = golap_plan::Filter; p->input.reset(input); p->predicate.reset(predicate);
+    return p;
+}
+golap_plan* golap_plan_projection(golap_plan* input, golap_expr** exprs, uint32_t n) {
+    auto* p = new golap_plan();
+    p->kind = golap_plan::Projection; p->input.reset(input);
+    for (uint32_t i = 0; i < n; ++i) p->exprs.emplace_back(exprs[i]);
+    return p;
+}
+golap_plan* golap_plan_hash_join(golap_plan* left, golap_plan* right, golap_expr** lk, uint32_t nl, golap_expr** rk, uint32_t nr, golap_join_type jt) {
+    auto* p = new golap_plan();
+    p->kind = golap_plan::HashJoin; p->input.reset(left); p->right.reset(right); p->join_type = jt;
+    for (uint32_t i = 0; i < nl; ++i) p->left_keys.emplace_back(lk[i]);
+    for (uint32_t i = 0; i < nr; ++i) p->right_keys.emplace_back(rk[i]);
+    return p;
+}
+golap_plan* golap_plan_aggregate(golap_plan* input, golap_expr** group_by, uint32_t ng, const int32_t* funcs, golap_expr** inputs, uint32_t na) {
+    auto* p = new golap_plan();
+    p->kind = golap_plan::Aggregate; p->input.reset(input);
+    for (uint32_t i = 0; i < ng; ++i) p->group_by.emplace_back(group_by[i]);
+    for (uint32_t i = 0; i < na; ++i) { p->aggr_inputs.emplace_back(inputs[i]); p->aggr_funcs.push_back(funcs[i]); }
+    return p;
+}
+golap_plan* golap_plan_sort(golap_plan* input, golap_expr** exprs, uint32_t n) {
+    auto* p = new golap_plan();
+    p->kind = golap_plan::Sort; p->input.reset(input);
+    for (uint32_t i = 0; i < n; ++i) p->exprs.emplace_back(exprs[i]);
+    return p;
+}
+void golap_plan_free(golap_plan* p) { delete p; }
+
+// golap_last_error(ctx) reads ctx->err first; host-layer errors are reported through this helper instead
+const char* golap_host_last_error(void) { return g_err.c_str(); }
+
+int32_t golap_execute(golap_ctx* ctx, golap_plan* plan, golap_result** out_result, uint32_t* out_n) {
+    std::unique_ptr<golap_plan> owned(plan);
+    // ctx may be NULL for plans that never touch the device (Batches / TableScan / Sort / Projection);
+    // any device step then fails inside the C ABI with its own "null ctx" error.
+    if (!plan || !out_result || !out_n) return herr(GOLAP_ERR_INVALID_ARG, "null argument");
+    g_err.clear();
+    Exec ex{ctx};
+    auto res = std::make_unique<golap_result>();
+    int32_t s = ex.run(*plan, res->batches);
+    if (s != GOLAP_OK) {
+        if (g_err.empty()) g_err = golap_last_error(ctx);
+        if (g_err.empty()) g_err = golap_last_error(nullptr);
+        return s;
+    }
+    *out_n = (uint32_t)res->batches.size();
+    *out_result = res.release();
+    return GOLAP_OK;
+}
+
+int32_t golap_result_export(golap_result* r, uint32_t i, ArrowArray* oa, ArrowSchema* os) {
+    if (!r || !oa || !os || i >= r->batches.size()) return herr(GOLAP_ERR_INVALID_ARG, "bad result index");
+    export_batch(std::move(r->batches[i]), oa, os);
+    return GOLAP_OK;
+}
+void golap_result_free(golap_result* r) { delete r; }
+
+}  // extern "C"

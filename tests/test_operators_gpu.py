@@ -1,0 +1,154 @@
+"""Operator-level parity: the C++ GpuExecutor (libgolap_host.so) driven through the PhysicalPlan API over
+pyarrow RecordBatches, read like the reference's own executor tests (executor.rs:543-570)."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import oracle  # noqa: E402
+from gpu_olap_engine_amd import operators as O  # noqa: E402
+
+
+def rb(**cols):
+    return pa.RecordBatch.from_arrays([pa.array(v) for v in cols.values()], names=list(cols.keys()))
+
+
+def test_filter_reference_known_answer(ctx):
+    """executor.rs:553-570: a=[5,15,25], a > 10 keeps rows 1,2."""
+    batch = rb(a=np.array([5, 15, 25], np.int64))
+    pred = O.BinaryExpr(O.Column(0, "a"), ">", O.Literal("10"))
+    out = O.execute(O.GpuFilter(O.Batches([batch]), pred), ctx)
+    assert len(out) == 1 and out[0].column(0).to_pylist() == [15, 25]
+
+
+def test_filter_multi_batch_multi_column(ctx):
+    rng = np.random.default_rng(0)
+    batches, exp_k, exp_v, exp_f = [], [], [], []
+    for n in (1000, 0, 70_001, 5):
+        k = rng.integers(0, 1000, n).astype(np.int64)
+        v = rng.integers(-5, 5, n).astype(np.int64)
+        f = rng.random(n)
+        batches.append(rb(k=k, v=v, f=f))
+        m = oracle.eval_filter_mask(k, "<", 500).astype(bool)
+        exp_k.append(k[m]); exp_v.append(v[m]); exp_f.append(f[m])
+    # column resolved by NAME first even when the index is wrong (executor.rs:379-388)
+    out = O.execute(O.GpuFilter(O.Batches(batches), O.BinaryExpr(O.Column(7, "k"), "<", O.Literal("500"))), ctx)
+    kept = [(a, b, c) for a, b, c in zip(exp_k, exp_v, exp_f) if len(a)]        # empty results are dropped (:173)
+    assert len(out) == len(kept)
+    for o, (a, b, c) in zip(out, kept):
+        assert o.schema.names == ["k", "v", "f"]
+        assert np.array_equal(o.column(0).to_numpy(), a) and np.array_equal(o.column(1).to_numpy(), b) and np.array_equal(o.column(2).to_numpy(), c)
+
+
+def test_filter_edge_semantics(ctx):
+    batch = rb(a=np.arange(10, dtype=np.int64), f=np.arange(10, dtype=np.float64))
+    # unknown operator selects no row (executor.rs:464) -> batch dropped
+    assert O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(0, "a"), "AND", O.Literal("3"))), ctx) == []
+    # non-binary predicate -> all rows pass (:474)
+    out = O.execute(O.GpuFilter(O.Batches([batch]), O.Column(0, "a")), ctx)
+    assert out[0].num_rows == 10
+    # Float64 operand -> not (Int64, Int64) -> all rows pass (:471-472)
+    out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(1, "f"), ">", O.Literal("3"))), ctx)
+    assert out[0].num_rows == 10
+    # literal on the left: 3 < a  ==  a > 3
+    out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Literal("3"), "<", O.Column(0, "a"))), ctx)
+    assert out[0].column(0).to_pylist() == [4, 5, 6, 7, 8, 9]
+    with pytest.raises(O.OperatorError):   # unknown column (:386)
+        O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(9, "zz"), ">", O.Literal("3"))), ctx)
+
+
+def test_config1_filter_then_sum_plan(ctx):
+    """BASELINE config 1 as the hand-built plan of SURVEY 3.1: GpuAggregate{ GpuFilter{ batch, k < 500 }, [], [Sum(v)] }."""
+    n = 1_000_000
+    k = oracle.gen_sm64_mod(1, 0, n, 1000)
+    v = oracle.gen_sm64_mod(2, 0, n, 1024)
+    plan = O.GpuAggregate(O.GpuFilter(O.Batches([rb(k=k, v=v)]), O.BinaryExpr(O.Column(0, "k"), "<", O.Literal("500"))), [], [O.Sum(O.Column(0, "v"))])
+    out = O.execute(plan, ctx)
+    es, _ = oracle.filter_sum(k, v, "<", 500)
+    assert len(out) == 1 and out[0].num_rows == 1 and out[0].column(0).to_pylist() == [es]
+    assert out[0].schema.field(0).type == pa.float64()         # executor.rs:347
+
+
+def test_hash_join_materialises_pairs(ctx):
+    """Build side = left, first key only, global row index = running offset over batches (executor.rs:238-253);
+    output rows in canonical (probe_rid, build_rid) order, left columns then right columns."""
+    rng = np.random.default_rng(1)
+    lk = [rng.integers(0, 300, 700).astype(np.int64), rng.integers(0, 300, 301).astype(np.int64)]
+    lp = [rng.random(700), rng.random(301)]
+    rk = [rng.integers(0, 400, 500).astype(np.int64), rng.integers(0, 400, 99).astype(np.int64), np.empty(0, np.int64)]
+    rp = [rng.integers(0, 10**9, 500).astype(np.int64), rng.integers(0, 10**9, 99).astype(np.int64), np.empty(0, np.int64)]
+    left = O.Batches([rb(id=a, lpay=b) for a, b in zip(lk, lp)])
+    right = O.Batches([rb(fk=a, rpay=b) for a, b in zip(rk, rp)])
+    out = O.execute(O.GpuHashJoin(left, right, [O.Column(0, "id")], [O.Column(0, "fk")]), ctx)
+    pairs, m = oracle.execute_hash_join(lk, rk)
+    L, LP, R, RP = np.concatenate(lk), np.concatenate(lp), np.concatenate(rk), np.concatenate(rp)
+    assert len(out) == 1 and out[0].num_rows == m and out[0].schema.names == ["id", "lpay", "fk", "rpay"]
+    bi, pi = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    assert np.array_equal(out[0].column(0).to_numpy(), L[bi]) and np.array_equal(out[0].column(1).to_numpy(), LP[bi])
+    assert np.array_equal(out[0].column(2).to_numpy(), R[pi]) and np.array_equal(out[0].column(3).to_numpy(), RP[pi])
+    assert np.array_equal(out[0].column(0).to_numpy(), out[0].column(2).to_numpy())
+
+
+def test_hash_join_edge_cases(ctx):
+    one = rb(id=np.array([1, 2, 3], np.int64))
+    assert O.execute(O.GpuHashJoin(O.Batches([]), O.Batches([one]), [O.Column(0, "id")], [O.Column(0, "id")]), ctx) == []   # executor.rs:231-233
+    assert O.execute(O.GpuHashJoin(O.Batches([one]), O.Batches([]), [O.Column(0, "id")], [O.Column(0, "id")]), ctx) == []
+    out = O.execute(O.GpuHashJoin(O.Batches([one]), O.Batches([rb(id=np.array([9], np.int64))]), [O.Column(0, "id")], [O.Column(0, "id")]), ctx)
+    assert len(out) == 1 and out[0].num_rows == 0 and out[0].num_columns == 2
+    # many-to-many: more pairs than probe rows -> the executor re-runs with the true count (join_kernels.cuh:155-160)
+    l = rb(id=np.zeros(50, np.int64), x=np.arange(50, dtype=np.int64))
+    r = rb(id=np.zeros(40, np.int64), y=np.arange(40, dtype=np.float64))
+    out = O.execute(O.GpuHashJoin(O.Batches([l]), O.Batches([r]), [O.Column(0, "id")], [O.Column(0, "id")]), ctx)
+    assert out[0].num_rows == 2000
+    assert np.array_equal(out[0].column(1).to_numpy(), np.tile(np.arange(50), 40)) and np.array_equal(out[0].column(3).to_numpy(), np.repeat(np.arange(40.0), 50))
+    with pytest.raises(O.OperatorError):
+        O.execute(O.GpuHashJoin(O.Batches([l]), O.Batches([r]), [O.Column(0, "id")], [O.Column(0, "id")], join_type="Left"), ctx)
+
+
+def test_aggregate_ungrouped_all_funcs(ctx):
+    """execute_aggregate (executor.rs:297-355): one Float64 scalar per AggregateExpr, Int64 `as f64`, over all batches."""
+    rng = np.random.default_rng(2)
+    vi = [rng.integers(-100, 100, 1000).astype(np.int64), rng.integers(-100, 100, 3).astype(np.int64)]
+    vf = [rng.integers(0, 1 << 20, 1000) / 64.0, rng.integers(0, 1 << 20, 3) / 64.0]
+    inp = O.Batches([rb(i=a, f=b) for a, b in zip(vi, vf)])
+    aggs = [O.Sum(O.Column(0, "i")), O.Count(O.Column(0, "i")), O.Min(O.Column(1, "f")), O.Max(O.Column(1, "f")), O.Avg(O.Column(0, "i"))]
+    out = O.execute(O.GpuAggregate(inp, [], aggs), ctx)
+    ei, ef = oracle.execute_aggregate(np.concatenate(vi)), oracle.execute_aggregate(np.concatenate(vf))
+    assert [c.to_pylist()[0] for c in out[0].columns] == [ei["sum"], ei["count"], ef["min"], ef["max"], ei["avg"]]
+    # empty input: sum 0, count 0, min f64::MAX, max f64::MIN, avg 0 (:308-311, :339-345)
+    out = O.execute(O.GpuAggregate(O.Batches([rb(i=np.empty(0, np.int64))]), [], [O.Sum(O.Column(0, "i")), O.Min(O.Column(0, "i")), O.Avg(O.Column(0, "i"))]), ctx)
+    assert [c.to_pylist()[0] for c in out[0].columns] == [0.0, np.finfo(np.float64).max, 0.0]
+
+
+def test_aggregate_group_by(ctx):
+    """GROUP BY (ignored by the reference executor, executor.rs:307): key column + one Float64 column per aggregate, sorted by key."""
+    n = 300_000
+    k32 = oracle.gen_sm64_mod(7, 0, n, 1024, np.int32) + 5
+    v = oracle.gen_sm64_mod(8, 0, n, 1024, np.float64)
+    batches = [rb(g=k32[:100_000], v=v[:100_000]), rb(g=k32[100_000:], v=v[100_000:])]
+    out = O.execute(O.GpuAggregate(O.Batches(batches), [O.Column(0, "g")], [O.Sum(O.Column(1, "v")), O.Count(O.Column(1, "v")), O.Max(O.Column(1, "v"))]), ctx)
+    ks, st = oracle.group_aggregate(k32.astype(np.int64), v)
+    assert out[0].schema.names == ["g", "sum(v)", "count(v)", "max(v)"]
+    assert np.array_equal(out[0].column(0).to_numpy(), ks)
+    assert np.array_equal(out[0].column(1).to_numpy(), st[:, 0]) and np.array_equal(out[0].column(2).to_numpy(), st[:, 1]) and np.array_equal(out[0].column(3).to_numpy(), st[:, 3])
+
+
+def test_scan_sort_projection_passthrough(ctx):
+    sch = pa.schema([("a", pa.int64()), ("b", pa.float32()), ("c", pa.float64())])
+    out = O.execute(O.GpuTableScan("t", sch), ctx)          # executor.rs:118-154: one empty batch
+    assert len(out) == 1 and out[0].num_rows == 0 and out[0].schema.names == ["a", "b", "c"]
+    assert [f.type for f in out[0].schema] == [pa.int64(), pa.float64(), pa.float64()]
+    batch = rb(a=np.array([3, 1, 2], np.int64), b=np.array([1.0, 2.0, 3.0]))
+    out = O.execute(O.GpuSort(O.Batches([batch]), [O.Column(0, "a")]), ctx)   # pass-through (:361-370)
+    assert out[0].column(0).to_pylist() == [3, 1, 2]
+    out = O.execute(O.GpuProjection(O.Batches([batch]), [O.Column(1, "b"), O.Literal("7")]), ctx)
+    assert out[0].schema.names == ["b", "lit(7)"] and out[0].column(1).to_pylist() == [7, 7, 7]
+
+
+def test_null_values_become_zero(ctx):
+    """record_batch_convert.rs:102-110: nulls are replaced by 0 on the way to the device."""
+    batch = pa.RecordBatch.from_arrays([pa.array([5, None, 25], pa.int64())], names=["a"])
+    out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(0, "a"), "<", O.Literal("10"))), ctx)
+    assert out[0].column(0).to_pylist() == [5, 0]
