@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -117,6 +118,7 @@ struct golap_ctx {
     hipEvent_t ws_done = nullptr;     // last use of the workspace (cross-stream ordering)
     hipStream_t ws_stream = nullptr;
     std::vector<void*> pinned_small;  // small pinned host staging buffers for table uploads
+    std::shared_ptr<void> pjs;        // golap::PartJoinState (golap_join.hip)
 };
 
 namespace golap {

@@ -1224,72 +1224,88 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
     return GOLAP_OK;
 }
 
-// radix_partition_kernel as a stand-alone step: exactly 256 partitions (join_kernels.cuh:22-23, :69).
+// radix_partition_kernel as a stand-alone step: the reference's 256 partitions (join_kernels.cuh:22-23, :69),
+// optionally refined by `extra_bits` more hash bits so the receiving rank needs one local pass less.
 int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* p, void* stream) {
     if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (!p->out_offsets_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_offsets_ptr is null");
     if (p->n_rows && (!p->key_ptr || !p->out_key_ptr || !p->out_row_id_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
     if (p->n_owners == 0 || (p->n_owners & (p->n_owners - 1)) || p->n_owners > 256)
         return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_owners must be a power of two <= 256");
+    if (p->extra_bits > 2) return fail(ctx, GOLAP_ERR_INVALID_ARG, "extra_bits must be 0..2");
     if (p->n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32: at most 2^32-16 rows");
     std::lock_guard<std::mutex> lk(ctx->mu);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     GOLAP_TRY(ensure_scatter_lds(ctx));
+    const uint32_t F = 256u << p->extra_bits;
     JoinPlan plan;
     PassPlan pp;
     memset(&pp, 0, sizeof pp);
-    pp.bits = 8;
-    pp.cfg.F = 256;
+    pp.bits = 8 + p->extra_bits;
+    pp.cfg.F = F;
     pp.cfg.mode = 1;
-    pp.cfg.e1 = 0;
+    pp.cfg.e1 = p->extra_bits;
     pp.cfg.owners_log2 = ilog2(p->n_owners);
     pp.G = 1;
     plan.passes.push_back(pp);
-    plan.total_bits = 8;
-    plan.n_sub = 256;
+    plan.total_bits = pp.bits;
+    plan.n_sub = F;
+    if (p->n_rows == 0) {
+        GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_offsets_ptr, 0, (size_t)(F + 1) * 4, st));
+        return GOLAP_OK;
+    }
     GOLAP_TRY(ws_begin(ctx, side_small_bytes(plan, p->n_rows, 1, false) + 4096, st));
     SideBuffers buf;
     buf.final_keys = p->out_key_ptr;
     buf.final_rids = p->out_row_id_ptr;
     SideResult res;
-    if (p->n_rows == 0) {
-        GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_offsets_ptr, 0, 257 * 4, st));
-        return GOLAP_OK;
-    }
     GOLAP_TRY(run_side(ctx, st, "part", plan, p->key_ptr, p->row_id_ptr, p->rid_base, p->n_rows, nullptr, buf, res));
-    // offsets[s] = scanned[s * S] for s in 0..256 (the scan carries the total in its last slot)
-    GOLAP_HIP_TRY(ctx, hipMemcpy2DAsync((void*)p->out_offsets_ptr, 4, res.off, (size_t)res.stride * 4, 4, 257, hipMemcpyDeviceToDevice, st));
+    // offsets[s] = scanned[s * S] for s in 0..F (the scan carries the total in its last slot)
+    GOLAP_HIP_TRY(ctx, hipMemcpy2DAsync((void*)p->out_offsets_ptr, 4, res.off, (size_t)res.stride * 4, 4, F + 1, hipMemcpyDeviceToDevice, st));
     ws_end(ctx, st);
     return GOLAP_OK;
 }
 
-// Join of radix-partitioned inputs: groups = local partition slots fed by per-source segments.
-int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_params* p, void* stream) {
-    if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
-    if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
-    if (p->n_slots == 0 || p->n_slots > 256 || (p->n_slots & (p->n_slots - 1))) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_slots must be a power of two <= 256");
+}  // extern "C"
+
+namespace golap {
+
+// State of a partitioned (post-exchange) join between begin / side / finish.
+struct PartJoinState {
+    bool active = false;
+    JoinPlan plan;
+    uint32_t n_groups = 0, n_sources = 0;
+    uint64_t rows[2] = {0, 0};
+    SideBuffers buf[2];
+    SideResult res[2];
+    bool done[2] = {false, false};
+};
+
+static PartJoinState& pjs_of(golap_ctx* ctx) {
+    if (!ctx->pjs) ctx->pjs = std::shared_ptr<void>(new PartJoinState(), [](void* q) { delete (PartJoinState*)q; });
+    return *(PartJoinState*)ctx->pjs.get();
+}
+
+static int32_t part_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, hipStream_t st) {
+    if (p->n_groups == 0 || p->n_groups > 1024 || (p->n_groups & (p->n_groups - 1))) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_groups must be a power of two <= 1024");
     if (p->n_sources == 0 || p->n_sources > 64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_sources must be in 1..64");
-    if (!p->build.seg_off || !p->build.seg_len || !p->probe.seg_off || !p->probe.seg_len) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null segment table");
-    if (p->build.n_rows >= 0xFFFFFFF0ull || p->probe.n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "too many rows for u32 offsets");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = pick_stream(ctx, stream);
-    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_count_ptr, 0, 8, st));
-    if (p->build.n_rows == 0 || p->probe.n_rows == 0) return GOLAP_OK;
+    if (p->pre_bits < 8 || p->pre_bits > 12) return fail(ctx, GOLAP_ERR_INVALID_ARG, "pre_bits must be in 8..12");
+    if (p->build_rows >= 0xFFFFFFF0ull || p->probe_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "too many rows for u32 offsets");
+    PartJoinState& S = pjs_of(ctx);
+    S = PartJoinState();
+    S.n_groups = p->n_groups;
+    S.n_sources = p->n_sources;
+    S.rows[0] = p->build_rows;
+    S.rows[1] = p->probe_rows;
     GOLAP_TRY(ensure_scatter_lds(ctx));
-    const uint32_t nseg = p->n_slots * p->n_sources;
-    for (uint32_t i = 0; i < nseg; ++i) {
-        if (p->build.seg_off[i] + p->build.seg_len[i] > p->build.n_rows || p->probe.seg_off[i] + p->probe.seg_len[i] > p->probe.n_rows)
-            return fail(ctx, GOLAP_ERR_INVALID_ARG, "segment %u exceeds its buffer", i);
-    }
-    // Sub-partition fan-out: the rows of one slot already share 8 hash bits (the
-    // exchange-time radix partition), so the remaining passes start at shift 8.
-    const uint64_t hint = p->total_build_rows_hint ? p->total_build_rows_hint : p->build.n_rows;
-    const uint64_t per_slot = ceil_div(hint, p->n_slots);
+    // Sub-partition fan-out: the rows of one group already share pre_bits hash bits (the exchange-time
+    // radix partition), so the local passes start at shift pre_bits.
+    const uint64_t hint = p->total_build_rows_hint ? p->total_build_rows_hint : std::max<uint64_t>(1, p->build_rows);
+    const uint64_t per_group = ceil_div(hint, p->n_groups);
     uint32_t need = 0;
     for (; need < 22; ++need) {
-        double avg = (double)per_slot / (double)(1ull << need);
+        double avg = (double)per_group / (double)(1ull << need);
         if (avg + 4.5 * std::sqrt(avg) <= (double)JN_CAP) break;
     }
     if (need == 0) need = 1;   // always run at least one local pass: it also merges the source segments
@@ -1297,10 +1313,9 @@ int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_para
         uint32_t v = (uint32_t)strtoul(env, nullptr, 10);
         if (v >= 1 && v <= 20) need = v;
     }
-    JoinPlan plan;
     {
         uint32_t n_pass = (need + 8) / 9;
-        uint32_t shift = 8, G = p->n_slots, rest = need;
+        uint32_t shift = p->pre_bits, G = p->n_groups, rest = need;
         for (uint32_t k = 0; k < n_pass; ++k) {
             uint32_t b = (rest + (n_pass - k) - 1) / (n_pass - k);
             PassPlan pp;
@@ -1310,49 +1325,117 @@ int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_para
             pp.cfg.shift = shift;
             pp.cfg.mode = 0;
             pp.G = G;
-            plan.passes.push_back(pp);
+            S.plan.passes.push_back(pp);
             shift += b;
             G *= pp.cfg.F;
             rest -= b;
         }
-        plan.total_bits = shift;
-        plan.n_sub = G;
+        S.plan.total_bits = shift;
+        S.plan.n_sub = G;
     }
-    const size_t np = plan.passes.size();
-    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->build.n_rows, p->probe.n_rows, p->n_sources, true), st));
-    const uint64_t nmax = std::max(p->build.n_rows, p->probe.n_rows);
-    SideBuffers bb, pb;
-    bb.final_keys = ws_take(ctx, p->build.n_rows * 8);
-    bb.final_rids = ws_take(ctx, p->build.n_rows * 4);
-    pb.final_keys = ws_take(ctx, p->probe.n_rows * 8);
-    pb.final_rids = ws_take(ctx, p->probe.n_rows * 4);
+    const size_t np = S.plan.passes.size();
+    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(S.plan, std::max<uint64_t>(1, p->build_rows), std::max<uint64_t>(1, p->probe_rows), p->n_sources, true) +
+                                (uint64_t)p->n_groups * p->n_sources * 32 + 4096, st));
+    const uint64_t nmax = std::max<uint64_t>(1, std::max(p->build_rows, p->probe_rows));
+    for (int side = 0; side < 2; ++side) {
+        S.buf[side].final_keys = ws_take(ctx, std::max<uint64_t>(1, S.rows[side]) * 8);
+        S.buf[side].final_rids = ws_take(ctx, std::max<uint64_t>(1, S.rows[side]) * 4);
+        if (!S.buf[side].final_keys || !S.buf[side].final_rids) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    }
+    // both sides run on the caller's stream one after the other, so they share the ping-pong temporaries
     const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
     for (size_t i = 0; i < n_tmp; ++i) {
-        bb.tmp_keys[i] = pb.tmp_keys[i] = ws_take(ctx, nmax * 8);
-        bb.tmp_rids[i] = pb.tmp_rids[i] = ws_take(ctx, nmax * 4);
-        if (!bb.tmp_keys[i] || !bb.tmp_rids[i]) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+        const uint64_t tk = ws_take(ctx, nmax * 8), tr = ws_take(ctx, nmax * 4);
+        if (!tk || !tr) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+        S.buf[0].tmp_keys[i] = S.buf[1].tmp_keys[i] = tk;
+        S.buf[0].tmp_rids[i] = S.buf[1].tmp_rids[i] = tr;
     }
-    if (!bb.final_keys || !bb.final_rids || !pb.final_keys || !pb.final_rids) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
-    // upload the segment tables (u32)
-    std::vector<uint32_t> h_stage_v((size_t)nseg * 4);   // pageable: hipMemcpyAsync stages it before returning
-    uint32_t* h_stage = h_stage_v.data();
+    S.active = true;
+    return GOLAP_OK;
+}
+
+static int32_t part_side(golap_ctx* ctx, int32_t which, const golap_partitioned_side* side, hipStream_t st) {
+    PartJoinState& S = pjs_of(ctx);
+    if (!S.active) return fail(ctx, GOLAP_ERR_INVALID_ARG, "golap_join_partitioned_side without golap_join_partitioned_begin");
+    if (which != 0 && which != 1) return fail(ctx, GOLAP_ERR_INVALID_ARG, "which must be 0 (build) or 1 (probe)");
+    if (!side->seg_off || !side->seg_len) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null segment table");
+    if (side->n_rows != S.rows[which]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "side row count differs from the plan given to begin");
+    const uint32_t nseg = S.n_groups * S.n_sources;
+    for (uint32_t i = 0; i < nseg; ++i)
+        if (side->seg_off[i] + side->seg_len[i] > side->n_rows) return fail(ctx, GOLAP_ERR_INVALID_ARG, "segment %u exceeds its buffer", i);
+    S.done[which] = true;
+    if (side->n_rows == 0) return GOLAP_OK;
+    std::vector<uint32_t> h_stage((size_t)nseg * 2);   // pageable: hipMemcpyAsync stages it before returning
     for (uint32_t i = 0; i < nseg; ++i) {
-        h_stage[i] = (uint32_t)p->build.seg_off[i];
-        h_stage[nseg + i] = (uint32_t)p->build.seg_len[i];
-        h_stage[2 * nseg + i] = (uint32_t)p->probe.seg_off[i];
-        h_stage[3 * nseg + i] = (uint32_t)p->probe.seg_len[i];
+        h_stage[i] = (uint32_t)side->seg_off[i];
+        h_stage[nseg + i] = (uint32_t)side->seg_len[i];
     }
-    uint64_t d_seg = ws_take(ctx, (uint64_t)nseg * 16);
+    uint64_t d_seg = ws_take(ctx, (uint64_t)nseg * 8);
     if (!d_seg) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
-    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)d_seg, h_stage, (size_t)nseg * 16, hipMemcpyHostToDevice, st));
-    SegTable sb{d_seg, d_seg + (uint64_t)nseg * 4, p->n_sources}, sp{d_seg + (uint64_t)nseg * 8, d_seg + (uint64_t)nseg * 12, p->n_sources};
-    JoinPlan plan_b = plan, plan_p = plan;
-    SideResult rb, rp;
-    GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build.key_ptr, p->build.row_id_ptr, 0, p->build.n_rows, &sb, bb, rb));
-    GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe.key_ptr, p->probe.row_id_ptr, 0, p->probe.n_rows, &sp, pb, rp));
-    GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->build.n_rows, p->probe.n_rows, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs));
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)d_seg, h_stage.data(), (size_t)nseg * 8, hipMemcpyHostToDevice, st));
+    SegTable seg{d_seg, d_seg + (uint64_t)nseg * 4, S.n_sources};
+    JoinPlan plan_side = S.plan;
+    GOLAP_TRY(run_side(ctx, st, which ? "probe" : "build", plan_side, side->key_ptr, side->row_id_ptr, 0, side->n_rows, &seg, S.buf[which], S.res[which]));
+    return GOLAP_OK;
+}
+
+static int32_t part_finish(golap_ctx* ctx, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, hipStream_t st) {
+    PartJoinState& S = pjs_of(ctx);
+    if (!S.active || !S.done[0] || !S.done[1]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "golap_join_partitioned_finish needs begin + both sides");
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)out_count, 0, 8, st));
+    S.active = false;
+    if (S.rows[0] == 0 || S.rows[1] == 0) return GOLAP_OK;
+    GOLAP_TRY(launch_lds_join(ctx, st, S.plan, S.res[0], S.res[1], S.rows[0], S.rows[1], out_pairs, out_count, max_pairs));
     ws_end(ctx, st);
     return GOLAP_OK;
+}
+
+}  // namespace golap
+
+extern "C" {
+
+int32_t golap_join_partitioned_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, void* stream) {
+    if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return part_begin(ctx, p, pick_stream(ctx, stream));
+}
+
+int32_t golap_join_partitioned_side(golap_ctx* ctx, int32_t which, const golap_partitioned_side* side, void* stream) {
+    if (!ctx || !side) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return part_side(ctx, which, side, pick_stream(ctx, stream));
+}
+
+int32_t golap_join_partitioned_finish(golap_ctx* ctx, uint64_t out_pairs_ptr, uint64_t out_count_ptr, uint64_t max_pairs, void* stream) {
+    if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
+    if (!out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+    if (max_pairs && !out_pairs_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_pairs_ptr is null but max_pairs > 0");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return part_finish(ctx, out_pairs_ptr, out_count_ptr, max_pairs, pick_stream(ctx, stream));
+}
+
+// Join of radix-partitioned inputs in one call: begin + build side + probe side + finish.
+int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_params* p, void* stream) {
+    if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    golap_join_partitioned_plan pl;
+    memset(&pl, 0, sizeof pl);
+    pl.n_groups = p->n_slots;
+    pl.n_sources = p->n_sources;
+    pl.pre_bits = p->pre_bits ? p->pre_bits : 8;
+    pl.total_build_rows_hint = p->total_build_rows_hint;
+    pl.build_rows = p->build.n_rows;
+    pl.probe_rows = p->probe.n_rows;
+    GOLAP_TRY(part_begin(ctx, &pl, st));
+    GOLAP_TRY(part_side(ctx, 0, &p->build, st));
+    GOLAP_TRY(part_side(ctx, 1, &p->probe, st));
+    return part_finish(ctx, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, st);
 }
 
 }  // extern "C"

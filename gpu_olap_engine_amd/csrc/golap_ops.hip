@@ -210,7 +210,7 @@ __global__ void k_counts_from_stats(const double* __restrict__ stats4, uint32_t 
 // group in work-group order (reproducible; no global float atomics).
 // slot = key % n_groups (join_kernels.cuh:230).
 // ---------------------------------------------------------------------------
-template <typename KeyT, bool VAL_F64>
+template <typename KeyT, bool VAL_F64, bool NEED_MM>
 __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n, uint32_t n_groups,
                                                     unsigned long long rows_per_block, double* __restrict__ slab /*[grid][4][n_groups]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -230,8 +230,10 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
         const double x = VAL_F64 ? vf[i] : (double)vi[i];
         atomicAdd(&s_sum[g], x);
         atomicAdd(&s_cnt[g], 1u);
-        __hip_atomic_fetch_min(&s_mn[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&s_mx[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (NEED_MM) {   // MIN / MAX requested by some spec: two more LDS atomics per row
+            __hip_atomic_fetch_min(&s_mn[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&s_mx[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     __syncthreads();
     double* row = slab + (size_t)blockIdx.x * 4 * n_groups;
@@ -268,14 +270,14 @@ __global__ void k_group_init(double* __restrict__ stats4, uint32_t n_groups) {
 
 template <typename KeyT, bool VAL_F64>
 __global__ __launch_bounds__(OP_THREADS) void k_group_global(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
-                                                             uint32_t n_groups, double* __restrict__ stats4, int need_minmax) {
+                                                             uint32_t n_groups, double* __restrict__ stats4, int need_minmax, int need_cnt) {
     const long long* vi = (const long long*)val;
     const double* vf = (const double*)val;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t g = (uint32_t)((unsigned long long)keys[i] % n_groups);
         const double x = VAL_F64 ? vf[i] : (double)vi[i];
         unsafeAtomicAdd(&stats4[g * 4 + 0], x);
-        unsafeAtomicAdd(&stats4[g * 4 + 1], 1.0);
+        if (need_cnt) unsafeAtomicAdd(&stats4[g * 4 + 1], 1.0);
         if (need_minmax) {
             __hip_atomic_fetch_min(&stats4[g * 4 + 2], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_max(&stats4[g * 4 + 3], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -490,18 +492,23 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     if (lds_path) {
         static bool attr_done = false;
         if (!attr_done) {
-            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<int, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<int, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<long long, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_group_lds<long long, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            const void* fns[] = {(const void*)k_group_lds<int, true, true>,        (const void*)k_group_lds<int, true, false>,
+                                 (const void*)k_group_lds<int, false, true>,       (const void*)k_group_lds<int, false, false>,
+                                 (const void*)k_group_lds<long long, true, true>,  (const void*)k_group_lds<long long, true, false>,
+                                 (const void*)k_group_lds<long long, false, true>, (const void*)k_group_lds<long long, false, false>};
+            for (const void* f : fns) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             attr_done = true;
         }
     }
     // one pass per distinct value column; every spec on that column is finalised from the same stats
     for (uint32_t col = 0; col < p->n_value_cols; ++col) {
-        bool used = false, need_minmax = false;
+        bool used = false, need_minmax = false, need_cnt = p->out_count_ptr != 0;
         for (uint32_t i = 0; i < n_specs; ++i)
-            if (specs[i].value_col_index == col) { used = true; need_minmax = need_minmax || specs[i].func == GOLAP_AGG_MIN || specs[i].func == GOLAP_AGG_MAX; }
+            if (specs[i].value_col_index == col) {
+                used = true;
+                need_minmax = need_minmax || specs[i].func == GOLAP_AGG_MIN || specs[i].func == GOLAP_AGG_MAX;
+                need_cnt = need_cnt || specs[i].func == GOLAP_AGG_COUNT || specs[i].func == GOLAP_AGG_AVG;
+            }
         if (!used) continue;
         const int32_t vdt = p->value_dtypes ? p->value_dtypes[col] : GOLAP_DT_INT64;
         if (vdt != GOLAP_DT_INT64 && vdt != GOLAP_DT_FLOAT64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "value column %u: dtype must be INT64 or FLOAT64", col);
@@ -520,17 +527,17 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
             const size_t lds = (size_t)G * 28 + 16;
             {
                 KernelTimer t(ctx, "hash_aggregate_lds", st, (key_bytes + 8) * p->n_rows + 12ull * G);
+#define GOLAP_LAUNCH_LDS(KT, VF, MM)                                                                                              \
+    hipLaunchKernelGGL((k_group_lds<KT, VF, MM>), dim3(lds_grid), dim3(512), lds, st, (const KT*)p->group_key_ptr, val,          \
+                       (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab)
                 if (p->key_dtype == GOLAP_DT_INT32) {
-                    if (vf) hipLaunchKernelGGL((k_group_lds<int, true>), dim3(lds_grid), dim3(512), lds, st, (const int*)p->group_key_ptr, val,
-                                               (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
-                    else hipLaunchKernelGGL((k_group_lds<int, false>), dim3(lds_grid), dim3(512), lds, st, (const int*)p->group_key_ptr, val,
-                                            (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
+                    if (vf) { if (need_minmax) GOLAP_LAUNCH_LDS(int, true, true); else GOLAP_LAUNCH_LDS(int, true, false); }
+                    else { if (need_minmax) GOLAP_LAUNCH_LDS(int, false, true); else GOLAP_LAUNCH_LDS(int, false, false); }
                 } else {
-                    if (vf) hipLaunchKernelGGL((k_group_lds<long long, true>), dim3(lds_grid), dim3(512), lds, st, (const long long*)p->group_key_ptr, val,
-                                               (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
-                    else hipLaunchKernelGGL((k_group_lds<long long, false>), dim3(lds_grid), dim3(512), lds, st, (const long long*)p->group_key_ptr, val,
-                                            (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab);
+                    if (vf) { if (need_minmax) GOLAP_LAUNCH_LDS(long long, true, true); else GOLAP_LAUNCH_LDS(long long, true, false); }
+                    else { if (need_minmax) GOLAP_LAUNCH_LDS(long long, false, true); else GOLAP_LAUNCH_LDS(long long, false, false); }
                 }
+#undef GOLAP_LAUNCH_LDS
             }
             {
                 KernelTimer t(ctx, "hash_aggregate_fold", st, 0);
@@ -542,14 +549,14 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
             const uint32_t grid = stream_grid(ctx, p->n_rows, OP_THREADS * 4);
             if (p->key_dtype == GOLAP_DT_INT32) {
                 if (vf) hipLaunchKernelGGL((k_group_global<int, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, val,
-                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
                 else hipLaunchKernelGGL((k_group_global<int, false>), dim3(grid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, val,
-                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
             } else {
                 if (vf) hipLaunchKernelGGL((k_group_global<long long, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, val,
-                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
                 else hipLaunchKernelGGL((k_group_global<long long, false>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, val,
-                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax);
+                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
             }
         }
         const uint32_t fg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS)));

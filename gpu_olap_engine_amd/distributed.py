@@ -42,54 +42,88 @@ class HipBackend:
     def __init__(self, ctx):
         self.ctx = ctx
 
-    def radix_partition(self, keys, rid_base, n_owners):
-        return self.ctx.radix_partition(keys, rid_base=rid_base, n_owners=n_owners)
+    def total_bits(self, n_build_total):
+        pl = self.ctx.join_plan(max(1, n_build_total))
+        return pl["bits1"] + pl["bits2"]
 
-    def join_partitioned(self, bk, br, bso, bsl, pk, pr, pso, psl, n_slots, n_sources, out_pairs, hint):
-        return self.ctx.join_partitioned(bk, br, bso, bsl, pk, pr, pso, psl, n_slots, n_sources, out_pairs,
-                                         total_build_rows_hint=hint)
+    def radix_partition(self, keys, rid_base, n_owners, extra_bits):
+        return self.ctx.radix_partition(keys, rid_base=rid_base, n_owners=n_owners, extra_bits=extra_bits)
+
+    def join_begin(self, n_groups, n_sources, pre_bits, hint, build_rows, probe_rows):
+        self.ctx.join_partitioned_begin(n_groups, n_sources, pre_bits, hint, build_rows, probe_rows)
+
+    def join_side(self, which, keys, rids, seg_off, seg_len, rows):
+        self.ctx.join_partitioned_side(which, keys, rids, seg_off, seg_len, rows)
+
+    def join_finish(self, out_pairs):
+        return self.ctx.join_partitioned_finish(out_pairs)
 
     def empty(self, n, dtype, like):
         return torch.empty(n, dtype=dtype, device=like.device)
 
 
+class _Exchange:
+    """An in-flight partition exchange of one side (async all-to-all rounds + the resulting segment table)."""
+
+    def __init__(self):
+        self.works, self.keep = [], []
+        self.keys = self.rids = None
+        self.n_recv = 0
+        self.seg_off, self.seg_len = [], []
+
+    def wait(self):
+        for w in self.works:
+            w.wait()          # NCCL: makes the current stream wait; gloo: blocks the host
+        self.works, self.keep = [], []
+
+
 class ShardedJoin:
-    def __init__(self, backend, group=None, max_msg_bytes=1 << 30):
+    def __init__(self, backend, group=None, max_msg_bytes=1 << 30, extra_bits=None):
         self.backend = backend
         self.group = group
         self.max_msg_bytes = max_msg_bytes
+        self.forced_extra_bits = extra_bits
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         if N_PARTITIONS % self.world or self.world & (self.world - 1):
             raise ValueError("world size must be a power of two dividing 256")
-        self.per = N_PARTITIONS // self.world
 
-    def _exchange_side(self, keys, rids, offs_host):
-        """keys/rids are partitioned owner-major; offs_host[257] are the slot offsets.
-        Returns (recv_keys, recv_rids, n_recv, seg_off, seg_len) with segments indexed [slot][source].
+    def extra_bits(self, n_build_total):
+        """Hash bits beyond the reference's 8 that the exchange-time partition already resolves, chosen so that
+        ONE local pass (<= 9 bits) reaches LDS-sized sub-partitions: 1B build rows -> 18 bits -> 8 + 1 | 9."""
+        if self.forced_extra_bits is not None:
+            return self.forced_extra_bits
+        return max(0, min(2, self.backend.total_bits(n_build_total) - 8 - 9))
 
-        The exchange runs in `rounds` all-to-all rounds over consecutive slot ranges so that no single
+    def _exchange_start(self, keys, rids, offs_host, e1):
+        """keys/rids are partitioned owner-major into (256 << e1) buckets; offs_host are the bucket offsets.
+        Starts the all-to-all (async) and returns an _Exchange whose segment table is indexed [group][source],
+        group = local bucket index in [0, (256/P) << e1).
+
+        The exchange runs in `rounds` all-to-all rounds over consecutive bucket ranges so that no single
         peer message exceeds max_msg_bytes (RCCL send/recv of > 4 GiB messages was observed to deliver
-        garbage on this stack; bounded rounds are also what a pipelined exchange needs)."""
-        P, per = self.world, self.per
+        garbage on this stack; bounded rounds are also what lets the rounds pipeline)."""
+        P = self.world
+        per = (N_PARTITIONS // P) << e1
+        nb = N_PARTITIONS << e1
         dev = keys.device
         offs = [int(v) for v in offs_host]
-        # per-slot sizes of what this rank sends to each peer: [peer][slot]
+        x = _Exchange()
         sizes = torch.tensor([[offs[r * per + s + 1] - offs[r * per + s] for s in range(per)] for r in range(P)], dtype=torch.int64)
         sz_dev = sizes.to(dev).reshape(-1)
         rsz_dev = torch.empty_like(sz_dev)
-        dist.all_to_all_single(rsz_dev, sz_dev, group=self.group)           # sizes[src][slot] of what I receive
+        dist.all_to_all_single(rsz_dev, sz_dev, group=self.group)           # sizes[src][bucket] of what I receive
         rsz = rsz_dev.cpu().reshape(P, per)
-        n_recv = int(rsz.sum())
-        rk = self.backend.empty(max(n_recv, 1), torch.int64, keys)
-        rr = self.backend.empty(max(n_recv, 1), torch.int32, keys)
+        x.n_recv = int(rsz.sum())
+        x.keys = self.backend.empty(max(x.n_recv, 1), torch.int64, keys)
+        x.rids = self.backend.empty(max(x.n_recv, 1), torch.int32, keys)
         # rounds: every rank must agree -> derive from the global maximum message (rows)
         biggest = torch.tensor([max(int(sizes.sum(dim=1).max()), int(rsz.sum(dim=1).max()))], dtype=torch.int64, device=dev)
         dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=self.group)
         rounds = max(1, min(per, -(-int(biggest.item()) * 8 // self.max_msg_bytes)))
         bounds = [per * j // rounds for j in range(rounds + 1)]
-        seg_off = [0] * (per * P)
-        seg_len = [0] * (per * P)
+        x.seg_off = [0] * (per * P)
+        x.seg_len = [0] * (per * P)
         pos = 0
         for j in range(rounds):
             s0, s1 = bounds[j], bounds[j + 1]
@@ -99,34 +133,46 @@ class ShardedJoin:
             recv_counts = rsz[:, s0:s1].sum(dim=1).tolist()
             n_r = int(sum(recv_counts))
             if rounds == 1:
-                sk, sr = keys[:offs[N_PARTITIONS]], rids[:offs[N_PARTITIONS]]
-            else:   # gather this round's slot range of every owner into one contiguous send buffer
+                sk, sr = keys[:offs[nb]], rids[:offs[nb]]
+            else:   # gather this round's bucket range of every owner into one contiguous send buffer
                 idx = [(offs[r * per + s0], offs[r * per + s1]) for r in range(P)]
                 sk = torch.cat([keys[a:b] for a, b in idx])
                 sr = torch.cat([rids[a:b] for a, b in idx])
-            dist.all_to_all_single(rk[pos:pos + n_r], sk, recv_counts, send_counts, group=self.group)
-            dist.all_to_all_single(rr[pos:pos + n_r], sr, recv_counts, send_counts, group=self.group)
+            x.keep += [sk, sr, keys, rids]
+            x.works.append(dist.all_to_all_single(x.keys[pos:pos + n_r], sk, recv_counts, send_counts, group=self.group, async_op=True))
+            x.works.append(dist.all_to_all_single(x.rids[pos:pos + n_r], sr, recv_counts, send_counts, group=self.group, async_op=True))
             src_base = pos
             for r in range(P):
                 within = 0
                 for s in range(s0, s1):
-                    seg_off[s * P + r] = src_base + within
-                    seg_len[s * P + r] = int(rsz[r, s])
+                    x.seg_off[s * P + r] = src_base + within
+                    x.seg_len[s * P + r] = int(rsz[r, s])
                     within += int(rsz[r, s])
                 src_base += recv_counts[r]
             pos += n_r
-        return rk, rr, n_recv, seg_off, seg_len
+        return x
 
     def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs=None, max_pairs=None):
-        """-> (pairs [m,2] int32 view of u32 global row ids, count tensor).  Local shard of the global join."""
+        """Local shard of the global join -> (pairs [m,2] int32 view of u32 GLOBAL row ids, count tensor, rows received per side).
+
+        Schedule (one compute stream + the collective's own stream):
+          partition(build) -> exchange(build) starts || partition(probe) -> exchange(probe) starts ||
+          local sub-partitioning(build) -> local sub-partitioning(probe) -> LDS join."""
         P = self.world
-        bk, br, boff = self.backend.radix_partition(build_keys, build_rid_base, P)
-        pk, pr, poff = self.backend.radix_partition(probe_keys, probe_rid_base, P)
-        offs = torch.stack([boff, poff]).cpu().numpy()                      # one small D2H for both sides
-        rbk, rbr, nb, bso, bsl = self._exchange_side(bk, br, offs[0])
-        rpk, rpr, npr, pso, psl = self._exchange_side(pk, pr, offs[1])
+        e1 = self.extra_bits(n_build_total)
+        bk, br, boff = self.backend.radix_partition(build_keys, build_rid_base, P, e1)
+        xb = self._exchange_start(bk, br, boff.cpu().numpy(), e1)
+        pk, pr, poff = self.backend.radix_partition(probe_keys, probe_rid_base, P, e1)
+        xp = self._exchange_start(pk, pr, poff.cpu().numpy(), e1)
+        n_groups = (N_PARTITIONS // P) << e1
+        self.backend.join_begin(n_groups, P, 8 + e1, max(1, n_build_total // P), xb.n_recv, xp.n_recv)
+        xb.wait()
+        self.backend.join_side(0, xb.keys, xb.rids, xb.seg_off, xb.seg_len, xb.n_recv)
+        xp.wait()
+        self.backend.join_side(1, xp.keys, xp.rids, xp.seg_off, xp.seg_len, xp.n_recv)
         if out_pairs is None:
-            cap = max(1, npr if max_pairs is None else max_pairs)
+            cap = max(1, xp.n_recv if max_pairs is None else max_pairs)
             out_pairs = torch.empty((cap, 2), dtype=torch.int32, device=build_keys.device)
-        return self.backend.join_partitioned(rbk[:nb], rbr[:nb], bso, bsl, rpk[:npr], rpr[:npr], pso, psl,
-                                             self.per, P, out_pairs, max(1, n_build_total // P)) + (nb, npr)
+        pairs, cnt = self.backend.join_finish(out_pairs)
+        self._last = (xb, xp)   # keep the received buffers alive until the next call (kernels may still read them)
+        return pairs, cnt, xb.n_recv, xp.n_recv

@@ -213,32 +213,52 @@ class Context:
         self._ck(self._lib.golap_join(self._h, strategy, C.byref(prm), _stream()))
         return out_pairs, out_count
 
-    def radix_partition(self, keys, row_ids=None, rid_base=0, n_owners=1, out_keys=None, out_rids=None):
-        """radix_partition_kernel as a stand-alone step -> (keys, row_ids(int32 view of u32), offsets int32[257] by slot)."""
+    def radix_partition(self, keys, row_ids=None, rid_base=0, n_owners=1, out_keys=None, out_rids=None, extra_bits=0):
+        """radix_partition_kernel as a stand-alone step -> (keys, row_ids(int32 view of u32), offsets int32[(256<<extra_bits)+1] by slot)."""
         _chk_tensor(keys, torch.int64, "keys")
         n = keys.numel()
         if out_keys is None:
             out_keys = torch.empty(max(n, 1), dtype=torch.int64, device=keys.device)
         if out_rids is None:
             out_rids = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device)
-        offs = torch.zeros(257, dtype=torch.int32, device=keys.device)
-        prm = N.PartitionParams(_ptr(keys), _ptr(row_ids), n, rid_base, n_owners, _ptr(out_keys), _ptr(out_rids), _ptr(offs))
+        offs = torch.zeros((256 << extra_bits) + 1, dtype=torch.int32, device=keys.device)
+        prm = N.PartitionParams(_ptr(keys), _ptr(row_ids), n, rid_base, n_owners, extra_bits, _ptr(out_keys), _ptr(out_rids), _ptr(offs))
         self._ck(self._lib.golap_radix_partition(self._h, C.byref(prm), _stream()))
         return out_keys, out_rids, offs
 
-    def join_partitioned(self, b_keys, b_rids, b_seg_off, b_seg_len, p_keys, p_rids, p_seg_off, p_seg_len, n_slots, n_sources,
-                         out_pairs, total_build_rows_hint=0, b_rows=None, p_rows=None, out_count=None):
-        """Join of radix-partitioned (post-exchange) inputs; seg_off/seg_len: host sequences [n_slots*n_sources]."""
-        nseg = n_slots * n_sources
+    @staticmethod
+    def _side(keys, rids, seg_off, seg_len, rows=None):
+        nseg = len(seg_off)
         arr = C.c_uint64 * nseg
-        bo, bl, po, pl = arr(*b_seg_off), arr(*b_seg_len), arr(*p_seg_off), arr(*p_seg_len)
+        so, sl = arr(*seg_off), arr(*seg_len)
+        side = N.PartitionedSide(_ptr(keys), _ptr(rids), keys.numel() if rows is None else rows, so, sl)
+        side._keep = (so, sl)   # keep the host tables alive for the duration of the call
+        return side
+
+    def join_partitioned(self, b_keys, b_rids, b_seg_off, b_seg_len, p_keys, p_rids, p_seg_off, p_seg_len, n_slots, n_sources,
+                         out_pairs, total_build_rows_hint=0, b_rows=None, p_rows=None, out_count=None, pre_bits=8):
+        """Join of radix-partitioned (post-exchange) inputs; seg_off/seg_len: host sequences [n_slots*n_sources]."""
         if out_count is None:
             out_count = torch.zeros(1, dtype=torch.int64, device=b_keys.device)
-        b = N.PartitionedSide(_ptr(b_keys), _ptr(b_rids), b_keys.numel() if b_rows is None else b_rows, bo, bl)
-        p = N.PartitionedSide(_ptr(p_keys), _ptr(p_rids), p_keys.numel() if p_rows is None else p_rows, po, pl)
-        prm = N.JoinPartitionedParams(b, p, n_slots, n_sources, total_build_rows_hint, _ptr(out_pairs), _ptr(out_count),
+        b = self._side(b_keys, b_rids, b_seg_off, b_seg_len, b_rows)
+        p = self._side(p_keys, p_rids, p_seg_off, p_seg_len, p_rows)
+        prm = N.JoinPartitionedParams(b, p, n_slots, n_sources, pre_bits, total_build_rows_hint, _ptr(out_pairs), _ptr(out_count),
                                       out_pairs.numel() // 2)
         self._ck(self._lib.golap_join_partitioned(self._h, C.byref(prm), _stream()))
+        return out_pairs, out_count
+
+    def join_partitioned_begin(self, n_groups, n_sources, pre_bits, total_build_rows_hint, build_rows, probe_rows):
+        pl = N.JoinPartitionedPlan(n_groups, n_sources, pre_bits, total_build_rows_hint, build_rows, probe_rows)
+        self._ck(self._lib.golap_join_partitioned_begin(self._h, C.byref(pl), _stream()))
+
+    def join_partitioned_side(self, which, keys, rids, seg_off, seg_len, rows=None):
+        side = self._side(keys, rids, seg_off, seg_len, rows)
+        self._ck(self._lib.golap_join_partitioned_side(self._h, which, C.byref(side), _stream()))
+
+    def join_partitioned_finish(self, out_pairs, out_count=None):
+        if out_count is None:
+            out_count = torch.zeros(1, dtype=torch.int64, device=out_pairs.device)
+        self._ck(self._lib.golap_join_partitioned_finish(self._h, _ptr(out_pairs), _ptr(out_count), out_pairs.numel() // 2, _stream()))
         return out_pairs, out_count
 
     # ---- GpuAggregate -----------------------------------------------------------

@@ -200,9 +200,11 @@ typedef struct golap_partition_params {
     uint64_t n_rows;
     uint32_t rid_base;
     uint32_t n_owners;         /* 1, 2, 4, 8, ... divides 256 */
+    uint32_t extra_bits;       /* 0..2: refine every partition by this many further hash bits (bucket = slot << extra_bits | bits);
+                                  out_offsets then has (256 << extra_bits) + 1 entries */
     uint64_t out_key_ptr;      /* device int64[n_rows] */
     uint64_t out_row_id_ptr;   /* device u32[n_rows]   */
-    uint64_t out_offsets_ptr;  /* device u32[257]      */
+    uint64_t out_offsets_ptr;  /* device u32[(256 << extra_bits) + 1] */
 } golap_partition_params;
 int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* params, void* stream);
 
@@ -219,12 +221,27 @@ typedef struct golap_partitioned_side {
 } golap_partitioned_side;
 typedef struct golap_join_partitioned_params {
     golap_partitioned_side build, probe;
-    uint32_t n_slots;      /* local partitions (256 / n_owners) */
+    uint32_t n_slots;      /* local groups: (256 / n_owners) << extra_bits */
     uint32_t n_sources;
+    uint32_t pre_bits;     /* hash bits the exchange-time partition consumed: 8 + extra_bits (0 = 8) */
     uint64_t total_build_rows_hint;  /* global build rows / n_owners: sizes the sub-partition fan-out */
     uint64_t out_pairs_ptr, out_count_ptr, max_pairs;
 } golap_join_partitioned_params;
 int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_params* params, void* stream);
+
+/* The same join in three steps, so that the partition exchange of one side can overlap the device work of
+ * the other: begin (plan + workspace), side (local sub-partitioning of the build (0) or probe (1) rows, may be
+ * called as soon as that side's rows have arrived), finish (LDS build/probe, pair output). */
+typedef struct golap_join_partitioned_plan {
+    uint32_t n_groups;     /* (256 / n_owners) << extra_bits */
+    uint32_t n_sources;
+    uint32_t pre_bits;     /* 8 + extra_bits */
+    uint64_t total_build_rows_hint;
+    uint64_t build_rows, probe_rows;   /* rows this rank holds after the exchange */
+} golap_join_partitioned_plan;
+int32_t golap_join_partitioned_begin(golap_ctx* ctx, const golap_join_partitioned_plan* plan, void* stream);
+int32_t golap_join_partitioned_side(golap_ctx* ctx, int32_t which, const golap_partitioned_side* side, void* stream);
+int32_t golap_join_partitioned_finish(golap_ctx* ctx, uint64_t out_pairs_ptr, uint64_t out_count_ptr, uint64_t max_pairs, void* stream);
 
 /* ---- GpuAggregate --------------------------------------------------------
  * AggFunc + identity_value aggregate_kernel.rs:17-34, AggregateSpec :38-44,

@@ -17,18 +17,20 @@ ctx = Context(profiling=True, max_gpu_memory=0)
 b = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n); p = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
 torch.cuda.synchronize(); log("generated")
 sj = ShardedJoin(HipBackend(ctx))
-bk, br, boff = ctx.radix_partition(b, rid_base=0, n_owners=1); torch.cuda.synchronize(); log("partition b done")
-pk, pr, poff = ctx.radix_partition(p, rid_base=0, n_owners=1); torch.cuda.synchronize(); log("partition p done")
-offs = torch.stack([boff, poff]).cpu().numpy(); log("offs on host", offs[0][:3], offs[0][-1])
-if os.environ.get("CHECK_BIG"):
+if os.environ.get("CHECK_BIG"):   # demonstrates the RCCL > 4 GiB single-message problem (world size 1, 8 GB self send)
+    bk, br, boff = ctx.radix_partition(b, rid_base=0, n_owners=1)
     sj.max_msg_bytes = 1 << 40
-    x = sj._exchange_side(bk, br, offs[0]); torch.cuda.synchronize()
-    log("single-round exchange equal to source:", bool(torch.equal(x[0][:n], bk[:n])), bool(torch.equal(x[1][:n], br[:n])))
+    x = sj._exchange_start(bk, br, boff.cpu().numpy(), 0); x.wait(); torch.cuda.synchronize()
+    log("single-round exchange equal to source:", bool(torch.equal(x.keys[:n], bk[:n])), bool(torch.equal(x.rids[:n], br[:n])))
     sj.max_msg_bytes = 1 << 30
-x = sj._exchange_side(bk, br, offs[0]); torch.cuda.synchronize(); log("exchange b done", x[2], "equal:", bool(torch.equal(x[0][:n], bk[:n])))
-y = sj._exchange_side(pk, pr, offs[1]); torch.cuda.synchronize(); log("exchange p done", y[2])
+    x = sj._exchange_start(bk, br, boff.cpu().numpy(), 0); x.wait(); torch.cuda.synchronize()
+    log("bounded-round exchange equal to source:", bool(torch.equal(x.keys[:n], bk[:n])), bool(torch.equal(x.rids[:n], br[:n])))
+    del x, bk, br
 out = torch.empty((n + 1024, 2), dtype=torch.int32, device="cuda")
-pairs, cnt = ctx.join_partitioned(x[0][:x[2]], x[1][:x[2]], x[3], x[4], y[0][:y[2]], y[1][:y[2]], y[3], y[4], 256, 1, out, total_build_rows_hint=n)
-torch.cuda.synchronize(); log("join_partitioned done", int(cnt.item()))
+for it in range(2):
+    torch.cuda.synchronize(); t1 = time.time()
+    pairs, cnt, nb, npr = sj.join(b, p, 0, 0, n, out_pairs=out)
+    torch.cuda.synchronize()
+    log(f"sharded join iter {it}: matches {int(cnt.item())} in {(time.time()-t1)*1e3:.2f} ms (extra_bits={sj.extra_bits(n)})")
 log({k: round(v["total_ms"], 3) for k, v in ctx.stats().items()})
 dist.destroy_process_group(); log("done")

@@ -16,33 +16,46 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleBackend:
-    """CPU stand-in with the semantics of golap_radix_partition / golap_join_partitioned."""
+    """CPU stand-in with the semantics of golap_radix_partition / golap_join_partitioned_{begin,side,finish}."""
 
-    def radix_partition(self, keys, rid_base, n_owners):
+    def total_bits(self, n_build_total):
+        return 17
+
+    def radix_partition(self, keys, rid_base, n_owners, extra_bits):
         import oracle
         k = keys.numpy()
-        ok, orr, off = oracle.radix_partition(k)                       # partition-id order, stable
+        h = oracle.hash_int64_array(k).astype(np.int64)
+        p = h & 255
+        sub = (h >> 8) & ((1 << extra_bits) - 1)
         per = 256 // n_owners
-        order = sorted(range(256), key=lambda p: (p % n_owners) * per + p // n_owners)   # owner-major slots
-        ks, rs, offs = [], [], [0]
-        for p in order:
-            lo, hi = int(off[p]), int(off[p + 1])
-            ks.append(ok[lo:hi]); rs.append(orr[lo:hi].astype(np.int64) + rid_base)
-            offs.append(offs[-1] + hi - lo)
-        kk = np.concatenate(ks) if k.size else np.empty(0, np.int64)
-        rr = (np.concatenate(rs) if k.size else np.empty(0, np.int64)).astype(np.uint32).view(np.int32)
-        return torch.from_numpy(kk.copy()), torch.from_numpy(rr.copy()), torch.tensor(offs, dtype=torch.int32)
+        bucket = (((p % n_owners) * per + p // n_owners) << extra_bits) | sub        # owner-major slot, refined by extra bits
+        order = np.argsort(bucket, kind="stable")
+        nb = 256 << extra_bits
+        offs = np.concatenate([[0], np.cumsum(np.bincount(bucket, minlength=nb))])
+        rr = (order.astype(np.int64) + rid_base).astype(np.uint32).view(np.int32)
+        return torch.from_numpy(k[order].copy()), torch.from_numpy(rr.copy()), torch.tensor(offs, dtype=torch.int32)
 
-    def join_partitioned(self, bk, br, bso, bsl, pk, pr, pso, psl, n_slots, n_sources, out_pairs, hint):
+    def join_begin(self, n_groups, n_sources, pre_bits, hint, build_rows, probe_rows):
+        self.cfg = (n_groups, n_sources, pre_bits)
+        self.sides = {}
+
+    def join_side(self, which, keys, rids, seg_off, seg_len, rows):
+        self.sides[which] = (keys[:rows].numpy().copy(), rids[:rows].numpy().view(np.uint32).copy(), list(seg_off), list(seg_len))
+
+    def join_finish(self, out_pairs):
         import oracle
-        bk, pk = bk.numpy(), pk.numpy()
-        br, pr = br.numpy().view(np.uint32), pr.numpy().view(np.uint32)
+        n_groups, n_sources, pre_bits = self.cfg
+        bk, br, bso, bsl = self.sides[0]
+        pk, pr, pso, psl = self.sides[1]
         allp = []
-        for s in range(n_slots):
+        for s in range(n_groups):
             bi = np.concatenate([np.arange(bso[s * n_sources + r], bso[s * n_sources + r] + bsl[s * n_sources + r]) for r in range(n_sources)]).astype(np.int64)
             pi = np.concatenate([np.arange(pso[s * n_sources + r], pso[s * n_sources + r] + psl[s * n_sources + r]) for r in range(n_sources)]).astype(np.int64)
             if bi.size == 0 or pi.size == 0:
                 continue
+            # every row of a group shares its low pre_bits hash bits
+            hb = oracle.hash_int64_array(bk[bi]) & ((1 << pre_bits) - 1)
+            assert (hb == hb[0]).all()
             pairs, m = oracle.hash_join(bk[bi], pk[pi])
             if m:
                 allp.append(np.stack([br[bi][pairs[:, 0]], pr[pi][pairs[:, 1]]], axis=1))
@@ -63,7 +76,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, variant, q, max_msg=1 << 30):
+def _worker(rank, world, port, n, variant, q, max_msg=1 << 30, e1=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -79,7 +92,7 @@ def _worker(rank, world, port, n, variant, q, max_msg=1 << 30):
         else:   # duplicates on both sides + rank 1 holds an empty-ish tail
             b = oracle.gen_sm64_mod(11, lo, hi - lo, n // 2)
             p = oracle.gen_sm64_mod(12, lo, hi - lo, n // 2)
-        sj = ShardedJoin(OracleBackend(), max_msg_bytes=max_msg)
+        sj = ShardedJoin(OracleBackend(), max_msg_bytes=max_msg, extra_bits=e1)
         out = torch.empty((4 * n, 2), dtype=torch.int32)
         pairs, cnt, nb, npr = sj.join(torch.from_numpy(b), torch.from_numpy(p), lo, lo, n, out_pairs=out)
         m = int(cnt.item())
@@ -90,8 +103,9 @@ def _worker(rank, world, port, n, variant, q, max_msg=1 << 30):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,variant,max_msg", [(2, "unique", 1 << 30), (2, "dups", 1 << 30), (4, "unique", 1 << 30), (2, "unique", 20_000), (4, "dups", 7_000)])
-def test_sharded_join_gloo(world, variant, max_msg):
+@pytest.mark.parametrize("world,variant,max_msg,e1", [(2, "unique", 1 << 30, 0), (2, "dups", 1 << 30, 1), (4, "unique", 1 << 30, 0),
+                                                        (2, "unique", 20_000, 1), (4, "dups", 7_000, 2)])
+def test_sharded_join_gloo(world, variant, max_msg, e1):
     """max_msg small -> the exchange runs in several bounded rounds over slot ranges."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
@@ -100,7 +114,7 @@ def test_sharded_join_gloo(world, variant, max_msg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, variant, q, max_msg)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, variant, q, max_msg, e1)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]

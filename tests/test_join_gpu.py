@@ -214,6 +214,79 @@ def test_radix_partition_owner_major(ctx, n_owners):
     assert np.array_equal(np.diff(off), counts)
 
 
+@pytest.mark.parametrize("extra_bits", [1, 2])
+def test_radix_partition_extra_bits(ctx, extra_bits):
+    """exchange-time partition refined by further hash bits: bucket = slot(p) << e | next e hash bits."""
+    n, P = 300_000, 4
+    keys = oracle.gen_sm64_mod(33, 0, n, 10**10)
+    ok, orr, off = ctx.radix_partition(torch.from_numpy(keys).cuda(), n_owners=P, extra_bits=extra_bits, rid_base=7)
+    torch.cuda.synchronize()
+    off = off.cpu().numpy().astype(np.int64)
+    assert off.size == (256 << extra_bits) + 1 and off[-1] == n
+    gk = ok.cpu().numpy()
+    h = oracle.hash_int64_array(gk).astype(np.int64)
+    p = h & 255
+    bucket = (((p % P) * (256 // P) + p // P) << extra_bits) | ((h >> 8) & ((1 << extra_bits) - 1))
+    assert (np.diff(bucket) >= 0).all()
+    assert np.array_equal(np.diff(off), np.bincount(bucket, minlength=256 << extra_bits))
+    assert np.array_equal(keys[(orr.cpu().numpy().view(np.uint32) - 7).astype(np.int64)], gk)
+
+
+def test_join_partitioned_split_api_with_extra_bits(ctx):
+    """begin / side / side / finish over buckets of 8+1 bits, 2 sources, equals the plain join."""
+    n, P, e1 = 500_000, 2, 1
+    b = oracle.gen_build_keys(0, n, n)
+    p = oracle.gen_probe_keys(0, n, n)
+    exp, me = oracle.hash_join(b, p)
+    per = (256 // P) << e1
+    h = n // P
+    parts = {}
+    for name, keys in (("b", b), ("p", p)):
+        parts[name] = [ctx.radix_partition(torch.from_numpy(keys[r * h:(r + 1) * h]).cuda(), rid_base=r * h, n_owners=P, extra_bits=e1) for r in range(P)]
+    torch.cuda.synchronize()
+    allpairs = []
+    for owner in range(P):
+        sides = {}
+        for name in ("b", "p"):
+            offs = [x[2].cpu().numpy().astype(np.int64) for x in parts[name]]
+            ks, rs, so, sl, pos, srcpos = [], [], [], [], 0, []
+            for r in range(P):
+                lo, hi = offs[r][owner * per], offs[r][(owner + 1) * per]
+                ks.append(parts[name][r][0][lo:hi]); rs.append(parts[name][r][1][lo:hi]); srcpos.append(pos); pos += hi - lo
+            for s_ in range(per):
+                for r in range(P):
+                    so.append(int(srcpos[r] + offs[r][owner * per + s_] - offs[r][owner * per]))
+                    sl.append(int(offs[r][owner * per + s_ + 1] - offs[r][owner * per + s_]))
+            sides[name] = (torch.cat(ks).contiguous(), torch.cat(rs).contiguous(), so, sl)
+        nb_, np_ = sides["b"][0].numel(), sides["p"][0].numel()
+        ctx.join_partitioned_begin(per, P, 8 + e1, n // P, nb_, np_)
+        ctx.join_partitioned_side(1, *sides["p"], rows=np_)     # probe side first: order must not matter
+        ctx.join_partitioned_side(0, *sides["b"], rows=nb_)
+        out = torch.empty((np_ + 16, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt = ctx.join_partitioned_finish(out)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        allpairs.append(pairs[:m].cpu().numpy().view(np.uint32))
+    got = canonical(np.concatenate(allpairs))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+    from gpu_olap_engine_amd.engine import GolapError
+    with pytest.raises(GolapError):
+        ctx.join_partitioned_finish(out)          # finish without begin
+
+
+def test_bench_sharded_path_single_rank():
+    """bench.py --sharded with one rank: the whole partition -> all_to_all (RCCL, self) -> local join path at 20M rows."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "20000000", "--steps", "2", "--warmup", "1", "--sharded", "--cpu-sample", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["verify"]["matches"] == 20_000_000 and d["verify"]["probe_id_sum_ok"] and d["verify"]["equal_key_pairs"] == 20_000_000
+
+
 def test_join_partitioned_two_sources(ctx):
     """post-exchange path: 2 sources x 128 slots on one device must equal the plain join."""
     n = 600_000
