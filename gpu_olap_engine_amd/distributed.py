@@ -3,8 +3,8 @@
 Rows of both tables start range-sharded; every rank radix-partitions its local rows into the
 reference's 256 partitions (join_kernels.cuh:69), laid out owner-major so that the rows bound
 for each peer are one contiguous range; partition p is owned by rank p % P.  The only data-path
-collective is the partition exchange: torch.distributed.all_to_all_single (backend "nccl" = RCCL
-over xGMI; all 7 links of a GPU carry traffic at once).  After the exchange each rank joins its
+collective is the partition exchange: an all-to-all issued as grouped send/recv on slices
+(torch.distributed.batch_isend_irecv; backend "nccl" = RCCL over xGMI, all 7 links of a GPU carry traffic at once).  After the exchange each rank joins its
 own 256/P partitions locally (further LDS-sized sub-partitioning + LDS hash tables); output pairs
 stay sharded and carry GLOBAL u32 row ids.
 
@@ -100,9 +100,12 @@ class ShardedJoin:
         Starts the all-to-all (async) and returns an _Exchange whose segment table is indexed [group][source],
         group = local bucket index in [0, (256/P) << e1).
 
-        The exchange runs in `rounds` all-to-all rounds over consecutive bucket ranges so that no single
-        peer message exceeds max_msg_bytes (RCCL send/recv of > 4 GiB messages was observed to deliver
-        garbage on this stack; bounded rounds are also what lets the rounds pipeline)."""
+        The all-to-all is issued as grouped point-to-point operations on SLICES of the partitioned buffers
+        (dist.batch_isend_irecv = one ncclGroup of ncclSend/ncclRecv over xGMI): the owner-major layout makes
+        every peer's rows one contiguous slice, so nothing is packed; the rank's own partitions are copied on
+        the device.  It runs in `rounds` over consecutive bucket ranges so that no single message exceeds
+        max_msg_bytes (one 8 GB RCCL message was observed to deliver wrong data on this stack; bounded rounds
+        are also what lets rounds pipeline)."""
         P = self.world
         per = (N_PARTITIONS // P) << e1
         nb = N_PARTITIONS << e1
@@ -124,32 +127,41 @@ class ShardedJoin:
         bounds = [per * j // rounds for j in range(rounds + 1)]
         x.seg_off = [0] * (per * P)
         x.seg_len = [0] * (per * P)
+        x.keep += [keys, rids]
         pos = 0
+        me = self.rank
         for j in range(rounds):
             s0, s1 = bounds[j], bounds[j + 1]
             if s1 == s0:
                 continue
-            send_counts = sizes[:, s0:s1].sum(dim=1).tolist()
             recv_counts = rsz[:, s0:s1].sum(dim=1).tolist()
-            n_r = int(sum(recv_counts))
-            if rounds == 1:
-                sk, sr = keys[:offs[nb]], rids[:offs[nb]]
-            else:   # gather this round's bucket range of every owner into one contiguous send buffer
-                idx = [(offs[r * per + s0], offs[r * per + s1]) for r in range(P)]
-                sk = torch.cat([keys[a:b] for a, b in idx])
-                sr = torch.cat([rids[a:b] for a, b in idx])
-            x.keep += [sk, sr, keys, rids]
-            x.works.append(dist.all_to_all_single(x.keys[pos:pos + n_r], sk, recv_counts, send_counts, group=self.group, async_op=True))
-            x.works.append(dist.all_to_all_single(x.rids[pos:pos + n_r], sr, recv_counts, send_counts, group=self.group, async_op=True))
+            ops = []
             src_base = pos
             for r in range(P):
+                a, b = offs[r * per + s0], offs[r * per + s1]          # what I send to r: one contiguous slice, no packing
+                n_from_r = int(recv_counts[r])
+                if r == me:
+                    # own partitions never touch the collective: a plain device copy on the compute stream
+                    if n_from_r:
+                        x.keys[src_base:src_base + n_from_r].copy_(keys[a:b])
+                        x.rids[src_base:src_base + n_from_r].copy_(rids[a:b])
+                else:
+                    peer = r if self.group is None else dist.get_global_rank(self.group, r)
+                    if b > a:
+                        ops.append(dist.P2POp(dist.isend, keys[a:b], peer, self.group))
+                        ops.append(dist.P2POp(dist.isend, rids[a:b], peer, self.group))
+                    if n_from_r:
+                        ops.append(dist.P2POp(dist.irecv, x.keys[src_base:src_base + n_from_r], peer, self.group))
+                        ops.append(dist.P2POp(dist.irecv, x.rids[src_base:src_base + n_from_r], peer, self.group))
                 within = 0
-                for s in range(s0, s1):
-                    x.seg_off[s * P + r] = src_base + within
-                    x.seg_len[s * P + r] = int(rsz[r, s])
-                    within += int(rsz[r, s])
-                src_base += recv_counts[r]
-            pos += n_r
+                for s_ in range(s0, s1):
+                    x.seg_off[s_ * P + r] = src_base + within
+                    x.seg_len[s_ * P + r] = int(rsz[r, s_])
+                    within += int(rsz[r, s_])
+                src_base += n_from_r
+            if ops:
+                x.works += dist.batch_isend_irecv(ops)                 # one grouped ncclSend/ncclRecv batch per round
+            pos += int(sum(recv_counts))
         return x
 
     def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs=None, max_pairs=None):
