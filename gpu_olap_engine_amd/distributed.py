@@ -186,5 +186,6 @@ class ShardedJoin:
             cap = max(1, xp.n_recv if max_pairs is None else max_pairs)
             out_pairs = torch.empty((cap, 2), dtype=torch.int32, device=build_keys.device)
         pairs, cnt = self.backend.join_finish(out_pairs)
-        self._last = (xb, xp)   # keep the received buffers alive until the next call (kernels may still read them)
+        # the received buffers may be released now: every kernel that reads them is already enqueued on this
+        # stream, and torch's caching allocator reuses memory in stream order
         return pairs, cnt, xb.n_recv, xp.n_recv
