@@ -870,10 +870,11 @@ static void split_bits(uint32_t total_bits, uint32_t max_per_pass, std::vector<u
 }
 
 static uint32_t slots_for(uint32_t G, uint64_t n_rows) {
-    // aim at ~4096 work-groups, but never chunks smaller than ~2 tiles on average
+    // aim at ~4096 work-groups, but keep chunks >= 128K rows: every chunk ends with partial lines per bucket
+    // (the write-combining scatter flushes its carries there), so short chunks waste write bandwidth
     uint64_t by_wg = std::max<uint64_t>(1, 4096 / std::max<uint32_t>(1, G));
     uint64_t avg_group = n_rows / std::max<uint32_t>(1, G);
-    uint64_t by_rows = std::max<uint64_t>(1, avg_group / (2 * PT_TILE));
+    uint64_t by_rows = std::max<uint64_t>(1, avg_group / (32 * PT_TILE));
     return (uint32_t)std::max<uint64_t>(1, std::min(by_wg, by_rows));
 }
 
