@@ -104,6 +104,12 @@ __device__ __forceinline__ uint32_t wave_exclusive_count(uint32_t v, uint32_t& t
     return inc - v;
 }
 
+// Work-group barrier for LDS-only hazards.  __syncthreads() also drains vmcnt(0): every in-flight global
+// store and prefetched load would have to complete at each barrier, although the kernels below only hand
+// data over through LDS between barriers (their global stores are write-once, their inputs read-only).
+// Waiting for the wave's own LDS operations is enough (cdna_hip_programming.md: counted waits, not vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- partition pass configuration ------------------------------------------
 struct PassCfg {
     uint32_t shift;        // hash bits consumed by earlier passes

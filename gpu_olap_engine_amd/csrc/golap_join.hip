@@ -112,7 +112,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_hist(const long long* __restrict
     const uint32_t off = chunk_off[chunk];
     const uint32_t tid = threadIdx.x;
     for (uint32_t f = tid; f < cfg.F; f += PT_THREADS) s_cnt[f] = 0;
-    __syncthreads();
+    lds_barrier();
     const long long* __restrict__ k = in_keys + off;
     uint32_t i = tid;
     // 8 independent loads in flight per thread
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_hist(const long long* __restrict
         for (int r = 0; r < 8; ++r) atomicAdd(&s_cnt[bucket_of(hash_int64(v[r]), cfg)], 1u);
     }
     for (; i < len; i += PT_THREADS) atomicAdd(&s_cnt[bucket_of(hash_int64(k[i]), cfg)], 1u);
-    __syncthreads();
+    lds_barrier();
     const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
     for (uint32_t f = tid; f < cfg.F; f += PT_THREADS) hist[((size_t)g * cfg.F + f) * cfg.S + s] = s_cnt[f];
 }
@@ -241,22 +241,24 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
         for (uint32_t f = tid; f < F; f += PT_THREADS) s_cnt[f] = 0;
         long long key[PT_RPT];
         uint32_t rid[PT_RPT], br[PT_RPT];
+        // unconditional loads on clamped indices: a conditional load compiles to branch + s_waitcnt vmcnt(0),
+        // which serialises the tile's loads; clamping keeps all of them in flight together
 #pragma unroll
         for (int r = 0; r < PT_RPT; ++r) {
             const uint32_t i = r * PT_THREADS + tid;
-            key[r] = i < tn ? in_keys[rbase + i] : 0;
+            key[r] = in_keys[rbase + (i < tn ? i : tn - 1)];
         }
         if (in_rids) {
 #pragma unroll
             for (int r = 0; r < PT_RPT; ++r) {
                 const uint32_t i = r * PT_THREADS + tid;
-                rid[r] = i < tn ? in_rids[rbase + i] : 0u;
+                rid[r] = in_rids[rbase + (i < tn ? i : tn - 1)];
             }
         } else {
 #pragma unroll
             for (int r = 0; r < PT_RPT; ++r) rid[r] = rid_base + rbase + r * PT_THREADS + tid;   // join_kernels.cuh:75
         }
-        __syncthreads();   // s_cnt zeroed, s_gpos visible
+        lds_barrier();   // s_cnt zeroed, s_gpos visible
 #pragma unroll
         for (int r = 0; r < PT_RPT; ++r) {
             const uint32_t i = r * PT_THREADS + tid;
@@ -266,14 +268,14 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
                 br[r] = (b << 16) | rank;   // b < 1024, rank < 4096
             }
         }
-        __syncthreads();
+        lds_barrier();
         // exclusive scan of s_cnt[0..F) -> s_start ; F <= 1024 = 2 entries per thread
         {
             const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
             const uint32_t c0 = f0 < F ? s_cnt[f0] : 0u, c1 = f1 < F ? s_cnt[f1] : 0u;
             const uint32_t inc = wave_inclusive_scan(c0 + c1);
             if (lane == 63) s_w[wv] = inc;
-            __syncthreads();
+            lds_barrier();
             uint32_t base = 0;
 #pragma unroll
             for (int i = 0; i < PT_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
             if (f0 < F) s_start[f0] = e0;
             if (f1 < F) s_start[f1] = e0 + c0;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < PT_RPT; ++r) {
             const uint32_t i = r * PT_THREADS + tid;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
                 s_rids[pos] = rid[r];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // contiguous runs out: consecutive threads -> consecutive LDS slots -> (mostly) consecutive addresses
 #pragma unroll
         for (int r = 0; r < PT_RPT; ++r) {
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
                 out_rids[gp] = s_rids[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] += s_cnt[f];
         // the zeroing of s_cnt at the top of the next tile is ordered by the barrier there;
         // s_cnt is read here by the same thread that zeroes it (same f stride), so no hazard.
@@ -357,11 +359,11 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
         long long key[BT_RPT];
         uint32_t br[BT_RPT];
 #pragma unroll
-        for (int r = 0; r < BT_RPT; ++r) {
+        for (int r = 0; r < BT_RPT; ++r) {   // unconditional, clamped: all 24 loads in flight together
             const uint32_t i = r * PT_THREADS + tid;
-            key[r] = i < tn ? in_keys[rbase + i] : 0;
+            key[r] = in_keys[rbase + (i < tn ? i : tn - 1)];
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < BT_RPT; ++r) {
             const uint32_t i = r * PT_THREADS + tid;
@@ -371,13 +373,13 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 16384
             }
         }
-        __syncthreads();
+        lds_barrier();
         {
             const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
             const uint32_t c0 = f0 < F ? s_cnt[f0] : 0u, c1 = f1 < F ? s_cnt[f1] : 0u;
             const uint32_t inc = wave_inclusive_scan(c0 + c1);
             if (lane == 63) s_w[wv] = inc;
-            __syncthreads();
+            lds_barrier();
             uint32_t base = 0;
 #pragma unroll
             for (int i = 0; i < PT_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
             if (f0 < F) s_start[f0] = e0;
             if (f1 < F) s_start[f1] = e0 + c0;
         }
-        __syncthreads();
+        lds_barrier();
         for (uint32_t w0 = 0; w0 < tn; w0 += BT_WIN) {
 #pragma unroll
             for (int r = 0; r < BT_RPT; ++r) {
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             const uint32_t wn = tn - w0 < (uint32_t)BT_WIN ? tn - w0 : (uint32_t)BT_WIN;
 #pragma unroll
             for (int j = 0; j < BT_WIN / PT_THREADS; ++j) {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
                     out_rids[gp] = s_rids[i];
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] += s_cnt[f];
     }
@@ -474,17 +476,26 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
     long long key[WC_RPT];
     uint32_t rid[WC_RPT];
 #pragma unroll
-    for (int r = 0; r < WC_RPT; ++r) {
+    for (int r = 0; r < WC_RPT; ++r) {   // unconditional loads on clamped indices (t_eff >= 1): all in flight together
         const uint32_t i = r * WC_THREADS + tid;
-        key[r] = i < t_eff ? in_keys[off + i] : 0;
-        rid[r] = in_rids ? (i < t_eff ? in_rids[off + i] : 0u) : rid_base + off + i;   // join_kernels.cuh:75
+        key[r] = in_keys[off + (i < t_eff ? i : t_eff - 1)];
+    }
+    if (in_rids) {
+#pragma unroll
+        for (int r = 0; r < WC_RPT; ++r) {
+            const uint32_t i = r * WC_THREADS + tid;
+            rid[r] = in_rids[off + (i < t_eff ? i : t_eff - 1)];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < WC_RPT; ++r) rid[r] = rid_base + off + r * WC_THREADS + tid;   // join_kernels.cuh:75
     }
     for (;;) {
         consumed += t_eff;
         const bool last = consumed >= len;
         if (tid < F) s_cnt[tid] = s_carry[tid];
         if (tid == 0) s_misc[0] = 0;
-        __syncthreads();
+        lds_barrier();
         uint32_t br[WC_RPT];
 #pragma unroll
         for (int r = 0; r < WC_RPT; ++r) {
@@ -494,12 +505,12 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // rank continues after the carried rows
             }
         }
-        __syncthreads();
+        lds_barrier();
         {   // staging offsets + how much of every bucket can leave as whole lines
             const uint32_t c = tid < F ? s_cnt[tid] : 0u;
             const uint32_t inc = wave_inclusive_scan(c);
             if (lane == 63) s_w[wv] = inc;
-            __syncthreads();
+            lds_barrier();
             uint32_t base = 0;
 #pragma unroll
             for (int i = 0; i < WC_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
@@ -515,7 +526,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
             nc = wave_reduce_add(nc);
             if (lane == 0 && nc) atomicAdd(&s_misc[0], nc);
         }
-        __syncthreads();
+        lds_barrier();
         // carried rows: old staging position -> registers -> new staging position
         long long ck[WC_CARRY_PT];
         uint32_t cr[WC_CARRY_PT], cdst[WC_CARRY_PT];
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
                 cdst[c8] = s_start[b] + k;
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int c8 = 0; c8 < WC_CARRY_PT; ++c8) {
             if (cdst[c8] != 0xFFFFFFFFu) {
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
                 s_rids[pos] = rid[r];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // prefetch the next tile while this one is written out
         const uint32_t room = (uint32_t)WC_CAP - s_misc[0];
         uint32_t t_next = 0;
@@ -556,13 +567,22 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
             if (t_next > (uint32_t)WC_NEW) t_next = WC_NEW;
             if (t_next > room) t_next = room;
         }
-        {
+        if (t_next) {   // wave-uniform
             const uint32_t nb = off + consumed;
 #pragma unroll
             for (int r = 0; r < WC_RPT; ++r) {
                 const uint32_t i = r * WC_THREADS + tid;
-                key[r] = i < t_next ? in_keys[nb + i] : 0;
-                rid[r] = in_rids ? (i < t_next ? in_rids[nb + i] : 0u) : rid_base + nb + i;
+                key[r] = in_keys[nb + (i < t_next ? i : t_next - 1)];
+            }
+            if (in_rids) {
+#pragma unroll
+                for (int r = 0; r < WC_RPT; ++r) {
+                    const uint32_t i = r * WC_THREADS + tid;
+                    rid[r] = in_rids[nb + (i < t_next ? i : t_next - 1)];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < WC_RPT; ++r) rid[r] = rid_base + nb + r * WC_THREADS + tid;
             }
         }
         // write out: one 16-lane group per 128-byte key line
@@ -579,7 +599,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < F) {
             const uint32_t e = s_emit[tid];
             s_csrc[tid] = s_start[tid] + e;
@@ -625,23 +645,38 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
     long long pk[JN_R];
     uint32_t prid[JN_R];
 #pragma unroll
-    for (int r = 0; r < JN_R; ++r) {
+    for (int r = 0; r < JN_R; ++r) {   // unconditional loads on clamped indices (p1 > p0): all in flight together
         const uint32_t i = p0 + r * JN_THREADS + tid;
-        pk[r] = i < p1 ? P.keys[i] : 0;
-        prid[r] = i < p1 ? P.rids[i] : 0u;
+        const uint32_t ic = i < p1 ? i : p1 - 1;
+        pk[r] = P.keys[ic];
+        prid[r] = P.rids[ic];
     }
     for (uint32_t bc = b0; bc < b1; bc += JN_CAP) {
         const uint32_t nb = b1 - bc < (uint32_t)JN_CAP ? b1 - bc : (uint32_t)JN_CAP;
         for (uint32_t h = tid; h < (1u << JN_LOG2_SLOTS); h += JN_THREADS) heads[h] = JN_EMPTY;
-        __syncthreads();
-        for (uint32_t i = tid; i < nb; i += JN_THREADS) {
-            const long long k = B.keys[bc + i];
-            t_keys[i] = k;
-            t_rids[i] = B.rids[bc + i];
-            const uint32_t old = atomicExch(&heads[slot_hash(k, JN_LOG2_SLOTS)], i);   // join_kernels.cuh:109
-            t_next[i] = (uint16_t)old;                                                 // :110 (0xFFFFFFFF -> 0xFFFF)
+        lds_barrier();
+        {
+            long long bk[JN_CAP / JN_THREADS];
+            uint32_t brd[JN_CAP / JN_THREADS];
+#pragma unroll
+            for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {   // the whole table chunk is requested before the first insert
+                const uint32_t i = r * JN_THREADS + tid;
+                const uint32_t ic = bc + (i < nb ? i : nb - 1);
+                bk[r] = B.keys[ic];
+                brd[r] = B.rids[ic];
+            }
+#pragma unroll
+            for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {
+                const uint32_t i = r * JN_THREADS + tid;
+                if (i < nb) {
+                    t_keys[i] = bk[r];
+                    t_rids[i] = brd[r];
+                    const uint32_t old = atomicExch(&heads[slot_hash(bk[r], JN_LOG2_SLOTS)], i);   // join_kernels.cuh:109
+                    t_next[i] = (uint16_t)old;                                                     // :110 (0xFFFFFFFF -> 0xFFFF)
+                }
+            }
         }
-        __syncthreads();
+        lds_barrier();
 
         for (uint32_t pc = p0; pc < p1; pc += JN_THREADS * JN_R) {
             uint32_t cnt[JN_R], first[JN_R], lp[JN_R];
@@ -650,9 +685,10 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
             for (int r = 0; r < JN_R; ++r) {
                 const uint32_t i = pc + r * JN_THREADS + tid;
                 const bool ok = i < p1;
-                if (reload) {
-                    pk[r] = ok ? P.keys[i] : 0;
-                    prid[r] = ok ? P.rids[i] : 0u;
+                if (reload) {   // wave-uniform; clamped like the preload
+                    const uint32_t ic = ok ? i : p1 - 1;
+                    pk[r] = P.keys[ic];
+                    prid[r] = P.rids[ic];
                 }
                 first[r] = ok ? 0u : JN_EMPTY;   // marks invalid rows until the head is read
             }
@@ -680,7 +716,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 lp[r] = wave_exclusive_count(cnt[r], tot);
                 if (lane == 0) s_wt[r * JN_WAVES + wv] = tot;
             }
-            __syncthreads();
+            lds_barrier();
             if (wv == 0) {
                 // 64 lanes <-> JN_R*JN_WAVES = 64 (slice, wave) totals, slice-major
                 const uint32_t v = s_wt[lane];
@@ -689,7 +725,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 s_wt[lane] = inc - v;
                 if (lane == 0) s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;   // ONE atomic per batch
             }
-            __syncthreads();
+            lds_barrier();
             const unsigned long long base = s_base;
             // phase B: emit.  Slice r of the batch is contiguous across the whole work-group.
 #pragma unroll
@@ -708,7 +744,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                     }
                 }
             }
-            __syncthreads();   // s_wt / s_base reused by the next batch
+            lds_barrier();   // s_wt / s_base reused by the next batch
         }
     }
 }
@@ -751,7 +787,7 @@ __global__ __launch_bounds__(BC_THREADS) void k_bcast_probe(const long long* __r
 #pragma unroll
         for (int r = 0; r < BC_R; ++r) {
             const uint32_t i = pc + r * BC_THREADS + tid;
-            pk[r] = i < n_probe ? probe_keys[i] : 0;
+            pk[r] = probe_keys[i < n_probe ? i : n_probe - 1];
         }
 #pragma unroll
         for (int r = 0; r < BC_R; ++r) {
