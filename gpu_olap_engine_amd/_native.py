@@ -14,6 +14,8 @@ GOLAP_OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY = 1, 2, 3, 4, 5, 6
 
 JOIN_RADIX_HASH, JOIN_SORT_MERGE, JOIN_BROADCAST_HASH = 0, 1, 2
+JT_INNER, JT_LEFT, JT_RIGHT, JT_FULL = 0, 1, 2, 3
+NULL_ROW_ID = 0xFFFFFFFF
 CMP_EQ, CMP_NE, CMP_LT, CMP_LE, CMP_GT, CMP_GE, CMP_NEVER = range(7)
 AGG_SUM, AGG_COUNT, AGG_MIN, AGG_MAX, AGG_AVG = range(5)
 DT_INT64, DT_FLOAT64, DT_INT32 = 0, 1, 2
@@ -64,7 +66,7 @@ class JoinParams(C.Structure):
     """join_kernel.rs:20-27 + extensions."""
     _fields_ = [("build_key_ptr", C.c_uint64), ("probe_key_ptr", C.c_uint64), ("n_build", C.c_uint64),
                 ("n_probe", C.c_uint64), ("out_pairs_ptr", C.c_uint64), ("out_count_ptr", C.c_uint64),
-                ("max_pairs", C.c_uint64), ("build_rid_base", C.c_uint32), ("probe_rid_base", C.c_uint32)]
+                ("max_pairs", C.c_uint64), ("build_rid_base", C.c_uint32), ("probe_rid_base", C.c_uint32), ("join_type", C.c_int32)]
 
 
 class PartitionParams(C.Structure):

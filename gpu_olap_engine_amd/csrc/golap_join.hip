@@ -388,11 +388,15 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
             if (f1 < F) s_start[f1] = e0 + c0;
         }
         lds_barrier();
+        // tile-local slot of every row, computed once (the window rounds below only compare it)
+#pragma unroll
+        for (int r = 0; r < BT_RPT; ++r)
+            if (br[r] != 0xFFFFFFFFu) br[r] = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
         for (uint32_t w0 = 0; w0 < tn; w0 += BT_WIN) {
 #pragma unroll
             for (int r = 0; r < BT_RPT; ++r) {
-                if (br[r] != 0xFFFFFFFFu) {
-                    const uint32_t pos = s_start[br[r] >> 16] + (br[r] & 0xFFFFu) - w0;   // wraps below the window
+                {
+                    const uint32_t pos = br[r] - w0;   // invalid rows (0xFFFFFFFF) and rows of other windows fall outside
                     if (pos < (uint32_t)BT_WIN) {
                         s_keys[pos] = key[r];
                         s_rids[pos] = rid_base + rbase + r * PT_THREADS + tid;          // join_kernels.cuh:75
@@ -626,20 +630,76 @@ struct JoinSide {
     uint32_t stride;
 };
 
+constexpr uint32_t JN_NULL = 0xFFFFFFFFu;   // row id of the missing side of an unmatched row (outer joins)
+
+// work-group-wide reservation of the output range for one batch: per-slice wave totals are already in
+// s_wt[slice * JN_WAVES + wave]; after the call s_wt holds their exclusive offsets and the return value is the
+// batch's base position (ONE global atomic per batch).  All threads must call it.
+__device__ __forceinline__ unsigned long long jn_reserve(uint32_t* s_wt, unsigned long long* s_base, unsigned long long* out_count) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    lds_barrier();
+    if (wv == 0) {
+        // 64 lanes <-> JN_R*JN_WAVES = 64 (slice, wave) totals, slice-major
+        const uint32_t v = s_wt[lane];
+        const uint32_t inc = wave_inclusive_scan(v);
+        const uint32_t total = __shfl(inc, 63, 64);
+        s_wt[lane] = inc - v;
+        if (lane == 0) *s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
+    }
+    lds_barrier();
+    return *s_base;
+}
+
+// JT: golap_join_type (0 Inner, 1 Left = keep unmatched build rows, 2 Right = keep unmatched probe rows, 3 Full).
+// probe_hit: global bitmap over probe positions, only touched when a sub-partition's build side needs more
+// than one table chunk (then "unmatched" is only known after the last chunk).
+template <int JT>
 __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
-                                                         unsigned long long* __restrict__ out_count, unsigned long long max_pairs) {
+                                                         unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
+                                                         uint32_t* __restrict__ probe_hit) {
+    constexpr bool KEEP_B = (JT & 1) != 0, KEEP_P = (JT & 2) != 0;
     __shared__ long long t_keys[JN_CAP];
     __shared__ uint32_t t_rids[JN_CAP];
     __shared__ uint32_t heads[1 << JN_LOG2_SLOTS];
     __shared__ uint16_t t_next[JN_CAP];
+    __shared__ uint8_t t_hit[KEEP_B ? JN_CAP : 4];
     __shared__ uint32_t s_wt[JN_R * JN_WAVES];
     __shared__ unsigned long long s_base;
 
     const uint32_t sp = blockIdx.x;
     const uint32_t b0 = B.off[(size_t)sp * B.stride], b1 = B.off[(size_t)(sp + 1) * B.stride];
     const uint32_t p0 = P.off[(size_t)sp * P.stride], p1 = P.off[(size_t)(sp + 1) * P.stride];
-    if (b1 == b0 || p1 == p0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (b1 == b0 || p1 == p0) {
+        // one side empty: nothing matches; an outer join still keeps the other side's rows
+        const bool keep = (b1 == b0) ? (KEEP_P && p1 != p0) : KEEP_B;
+        if (!keep) return;
+        const JoinSide& S = (b1 == b0) ? P : B;
+        const uint32_t s0 = (b1 == b0) ? p0 : b0, s1 = (b1 == b0) ? p1 : b1;
+        for (uint32_t c = s0; c < s1; c += JN_THREADS * JN_R) {
+            uint32_t v[JN_R];
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                const uint32_t i = c + r * JN_THREADS + tid;
+                v[r] = i < s1 ? 1u : 0u;
+                const unsigned long long m = __ballot(v[r]);
+                if (lane == 0) s_wt[r * JN_WAVES + wv] = (uint32_t)__popcll(m);
+            }
+            const unsigned long long base = jn_reserve(s_wt, &s_base, out_count);
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                const uint32_t i = c + r * JN_THREADS + tid;
+                if (v[r]) {
+                    const unsigned long long pos = base + s_wt[r * JN_WAVES + wv] + lane;   // full waves except the last: lanes are dense
+                    const uint32_t rid = S.rids[i];
+                    if (pos < max_pairs) out_pairs[pos] = (b1 == b0) ? make_uint2(JN_NULL, rid) : make_uint2(rid, JN_NULL);
+                }
+            }
+            lds_barrier();
+        }
+        return;
+    }
+    const bool multi_chunk = b1 - b0 > (uint32_t)JN_CAP;
 
     // the first probe batch is fetched before the table is built: its HBM latency hides behind the build
     long long pk[JN_R];
@@ -654,6 +714,8 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
     for (uint32_t bc = b0; bc < b1; bc += JN_CAP) {
         const uint32_t nb = b1 - bc < (uint32_t)JN_CAP ? b1 - bc : (uint32_t)JN_CAP;
         for (uint32_t h = tid; h < (1u << JN_LOG2_SLOTS); h += JN_THREADS) heads[h] = JN_EMPTY;
+        if (KEEP_B)
+            for (uint32_t h = tid; h < (uint32_t)JN_CAP; h += JN_THREADS) t_hit[h] = 0;
         lds_barrier();
         {
             long long bk[JN_CAP / JN_THREADS];
@@ -696,14 +758,24 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
 #pragma unroll
             for (int r = 0; r < JN_R; ++r) {
                 uint32_t c = 0, f = 0xFFFFu;
-                if (first[r] != JN_EMPTY) {
+                const bool valid = first[r] != JN_EMPTY;
+                if (valid) {
                     uint32_t e = heads[slot_hash(pk[r], JN_LOG2_SLOTS)] & 0xFFFFu;
                     while (e != 0xFFFFu) {
                         if (t_keys[e] == pk[r]) {   // full-key compare (:152-153)
                             if (c == 0) f = e;
                             ++c;
+                            if (KEEP_B) t_hit[e] = 1;   // same value from every writer: a plain store is enough
                         }
                         e = t_next[e];
+                    }
+                }
+                if (KEEP_P && valid) {
+                    if (!multi_chunk) {
+                        if (c == 0) { c = 1; f = 0xFFFEu; }   // unmatched probe row: one (NULL, probe) pair, marked by f
+                    } else if (c) {
+                        const uint32_t i = pc + r * JN_THREADS + tid;
+                        atomicOr(&probe_hit[i >> 5], 1u << (i & 31));
                     }
                 }
                 cnt[r] = c;
@@ -716,22 +788,16 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 lp[r] = wave_exclusive_count(cnt[r], tot);
                 if (lane == 0) s_wt[r * JN_WAVES + wv] = tot;
             }
-            lds_barrier();
-            if (wv == 0) {
-                // 64 lanes <-> JN_R*JN_WAVES = 64 (slice, wave) totals, slice-major
-                const uint32_t v = s_wt[lane];
-                const uint32_t inc = wave_inclusive_scan(v);
-                const uint32_t total = __shfl(inc, 63, 64);
-                s_wt[lane] = inc - v;
-                if (lane == 0) s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;   // ONE atomic per batch
-            }
-            lds_barrier();
-            const unsigned long long base = s_base;
+            const unsigned long long base = jn_reserve(s_wt, &s_base, out_count);
             // phase B: emit.  Slice r of the batch is contiguous across the whole work-group.
 #pragma unroll
             for (int r = 0; r < JN_R; ++r) {
                 if (cnt[r]) {
                     unsigned long long pos = base + s_wt[r * JN_WAVES + wv] + lp[r];
+                    if (KEEP_P && first[r] == 0xFFFEu) {
+                        if (pos < max_pairs) out_pairs[pos] = make_uint2(JN_NULL, prid[r]);
+                        continue;
+                    }
                     uint32_t e = first[r];
                     uint32_t left = cnt[r];
                     for (;;) {
@@ -746,8 +812,56 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
             }
             lds_barrier();   // s_wt / s_base reused by the next batch
         }
+        if (KEEP_B) {
+            // build rows of this table chunk that no probe row matched: (build, NULL)
+            uint32_t v[JN_CAP / JN_THREADS], lpb[JN_CAP / JN_THREADS];
+#pragma unroll
+            for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {
+                const uint32_t i = r * JN_THREADS + tid;
+                v[r] = (i < nb && !t_hit[i]) ? 1u : 0u;
+                const unsigned long long m = __ballot(v[r]);
+                lpb[r] = mbcnt(m);
+                if (lane == 0) s_wt[r * JN_WAVES + wv] = (uint32_t)__popcll(m);
+            }
+            const unsigned long long base = jn_reserve(s_wt, &s_base, out_count);
+#pragma unroll
+            for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {
+                if (v[r]) {
+                    const unsigned long long pos = base + s_wt[r * JN_WAVES + wv] + lpb[r];
+                    if (pos < max_pairs) out_pairs[pos] = make_uint2(t_rids[r * JN_THREADS + tid], JN_NULL);
+                }
+            }
+            lds_barrier();
+        }
+    }
+    if (KEEP_P && multi_chunk) {
+        // probe rows that matched in none of the table chunks: (NULL, probe).  __syncthreads() drains vmcnt(0):
+        // every atomicOr this work-group issued has been performed before the bits are read back (from L2)
+        __syncthreads();
+        for (uint32_t pc = p0; pc < p1; pc += JN_THREADS * JN_R) {
+            uint32_t v[JN_R], lpb[JN_R];
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                const uint32_t i = pc + r * JN_THREADS + tid;
+                v[r] = (i < p1 && !((__hip_atomic_load(&probe_hit[i >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (i & 31)) & 1u)) ? 1u : 0u;
+                const unsigned long long m = __ballot(v[r]);
+                lpb[r] = mbcnt(m);
+                if (lane == 0) s_wt[r * JN_WAVES + wv] = (uint32_t)__popcll(m);
+            }
+            const unsigned long long base = jn_reserve(s_wt, &s_base, out_count);
+#pragma unroll
+            for (int r = 0; r < JN_R; ++r) {
+                const uint32_t i = pc + r * JN_THREADS + tid;
+                if (v[r]) {
+                    const unsigned long long pos = base + s_wt[r * JN_WAVES + wv] + lpb[r];
+                    if (pos < max_pairs) out_pairs[pos] = make_uint2(JN_NULL, P.rids[i]);
+                }
+            }
+            lds_barrier();
+        }
     }
 }
+static_assert(JN_CAP / JN_THREADS == JN_R, "the unmatched-build pass reuses the (slice, wave) scan layout");
 
 // ---------------------------------------------------------------------------
 // BroadcastHashJoin (join_kernel.rs:62-68): one global chained table over the whole
@@ -772,11 +886,14 @@ constexpr int BC_THREADS = 512;
 constexpr int BC_WAVES = BC_THREADS / 64;
 constexpr int BC_R = 8;
 
+template <int JT>
 __global__ __launch_bounds__(BC_THREADS) void k_bcast_probe(const long long* __restrict__ build_keys, const uint32_t* __restrict__ buckets,
                                                             uint32_t capacity, const uint32_t* __restrict__ next,
                                                             const long long* __restrict__ probe_keys, uint32_t n_probe,
                                                             uint32_t build_rid_base, uint32_t probe_rid_base, uint2* __restrict__ out_pairs,
-                                                            unsigned long long* __restrict__ out_count, unsigned long long max_pairs) {
+                                                            unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
+                                                            uint8_t* __restrict__ build_hit) {
+    constexpr bool KEEP_B = (JT & 1) != 0, KEEP_P = (JT & 2) != 0;
     __shared__ uint32_t s_wt[BC_R * BC_WAVES];
     __shared__ unsigned long long s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -799,9 +916,11 @@ __global__ __launch_bounds__(BC_THREADS) void k_bcast_probe(const long long* __r
                     if (build_keys[e] == pk[r]) {                      // :152-153
                         if (c == 0) f = e;
                         ++c;
+                        if (KEEP_B) build_hit[e] = 1;
                     }
                     e = next[e];                                       // :164
                 }
+                if (KEEP_P && c == 0) { c = 1; f = JN_EMPTY - 1; }     // unmatched probe row -> (NULL, probe)
             }
             cnt[r] = c;
             first[r] = f;
@@ -812,21 +931,16 @@ __global__ __launch_bounds__(BC_THREADS) void k_bcast_probe(const long long* __r
             lp[r] = wave_exclusive_count(cnt[r], tot);
             if (lane == 0) s_wt[r * BC_WAVES + wv] = tot;
         }
-        __syncthreads();
-        if (wv == 0) {
-            const uint32_t v = s_wt[lane];
-            const uint32_t inc = wave_inclusive_scan(v);
-            const uint32_t total = __shfl(inc, 63, 64);
-            s_wt[lane] = inc - v;
-            if (lane == 0) s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
-        }
-        __syncthreads();
-        const unsigned long long base = s_base;
+        const unsigned long long base = jn_reserve(s_wt, &s_base, out_count);
 #pragma unroll
         for (int r = 0; r < BC_R; ++r) {
             if (cnt[r]) {
                 const uint32_t i = pc + r * BC_THREADS + tid;
                 unsigned long long pos = base + s_wt[r * BC_WAVES + wv] + lp[r];
+                if (KEEP_P && first[r] == JN_EMPTY - 1) {
+                    if (pos < max_pairs) out_pairs[pos] = make_uint2(JN_NULL, probe_rid_base + i);
+                    continue;
+                }
                 uint32_t e = first[r], left = cnt[r];
                 for (;;) {
                     if (build_keys[e] == pk[r]) {
@@ -838,7 +952,39 @@ __global__ __launch_bounds__(BC_THREADS) void k_bcast_probe(const long long* __r
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+    }
+}
+static_assert(BC_R * BC_WAVES == JN_R * JN_WAVES && BC_THREADS == JN_THREADS, "jn_reserve layout");
+
+// Left / Full: build rows no probe row matched -> (build, NULL)
+__global__ __launch_bounds__(BC_THREADS) void k_bcast_unmatched_build(const uint8_t* __restrict__ build_hit, uint32_t n_build, uint32_t build_rid_base,
+                                                                      uint2* __restrict__ out_pairs, unsigned long long* __restrict__ out_count,
+                                                                      unsigned long long max_pairs) {
+    __shared__ uint32_t s_wt[BC_R * BC_WAVES];
+    __shared__ unsigned long long s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t batch = BC_THREADS * BC_R;
+    for (uint32_t c0 = blockIdx.x * batch; c0 < n_build; c0 += gridDim.x * batch) {
+        uint32_t v[BC_R], lp[BC_R];
+#pragma unroll
+        for (int r = 0; r < BC_R; ++r) {
+            const uint32_t i = c0 + r * BC_THREADS + tid;
+            v[r] = (i < n_build && !build_hit[i]) ? 1u : 0u;
+            const unsigned long long m = __ballot(v[r]);
+            lp[r] = mbcnt(m);
+            if (lane == 0) s_wt[r * BC_WAVES + wv] = (uint32_t)__popcll(m);
+        }
+        const unsigned long long base = jn_reserve(s_wt, &s_base, out_count);
+#pragma unroll
+        for (int r = 0; r < BC_R; ++r) {
+            const uint32_t i = c0 + r * BC_THREADS + tid;
+            if (v[r]) {
+                const unsigned long long pos = base + s_wt[r * BC_WAVES + wv] + lp[r];
+                if (pos < max_pairs) out_pairs[pos] = make_uint2(build_rid_base + i, JN_NULL);
+            }
+        }
+        lds_barrier();
     }
 }
 
@@ -1145,11 +1291,24 @@ static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint
 
 // shared tail: both sides partitioned -> LDS join
 static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, const SideResult& b, const SideResult& p, uint64_t n_build,
-                               uint64_t n_probe, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs) {
+                               uint64_t n_probe, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, int32_t join_type = 0) {
     JoinSide B{b.keys, b.rids, b.off, b.stride}, P{p.keys, p.rids, p.off, p.stride};
+    uint32_t* probe_hit = nullptr;
+    if (join_type & 2) {   // Right / Full: bitmap over probe positions for the (rare) multi-chunk sub-partitions
+        const uint64_t words = ceil_div(std::max<uint64_t>(1, n_probe), 32) + 1;
+        probe_hit = (uint32_t*)ws_take(ctx, words * 4);
+        if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (probe bitmap)");
+        GOLAP_HIP_TRY(ctx, hipMemsetAsync(probe_hit, 0, words * 4, st));
+    }
     KernelTimer t(ctx, "join_build_probe_lds", st, 12 * (n_build + n_probe));
-    hipLaunchKernelGGL(k_join_lds, dim3((uint32_t)plan.n_sub), dim3(JN_THREADS), 0, st, B, P, (uint2*)out_pairs, (unsigned long long*)out_count,
-                       (unsigned long long)max_pairs);
+    const dim3 grid((uint32_t)plan.n_sub), block(JN_THREADS);
+    unsigned long long* oc = (unsigned long long*)out_count;
+    switch (join_type) {
+        case 0: hipLaunchKernelGGL(k_join_lds<0>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
+        case 1: hipLaunchKernelGGL(k_join_lds<1>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
+        case 2: hipLaunchKernelGGL(k_join_lds<2>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
+        default: hipLaunchKernelGGL(k_join_lds<3>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
+    }
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     return GOLAP_OK;
 }
@@ -1161,7 +1320,7 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     JoinPlan plan;
     make_plan(p->n_build, 0, true, plan);
     const size_t np = plan.passes.size();
-    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->n_build, p->n_probe, 1, false), st));
+    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->n_build, p->n_probe, 1, false) + p->n_probe / 8 + 4096, st));
     const uint64_t nmax = std::max(p->n_build, p->n_probe);
     SideBuffers bb, pb;
     bb.final_keys = ws_take(ctx, p->n_build * 8);
@@ -1181,7 +1340,7 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     SideResult rb, rp;
     GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build_key_ptr, 0, p->build_rid_base, p->n_build, nullptr, bb, rb));
     GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe_key_ptr, 0, p->probe_rid_base, p->n_probe, nullptr, pb, rp));
-    GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs));
+    GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type));
     ws_end(ctx, st);
     return GOLAP_OK;
 }
@@ -1191,25 +1350,43 @@ static int32_t broadcast_hash_join(golap_ctx* ctx, const golap_join_params* p, h
         return fail(ctx, GOLAP_ERR_UNSUPPORTED, "BroadcastHashJoin: side too large for u32 row ids");
     const uint32_t nb = (uint32_t)p->n_build, npr = (uint32_t)p->n_probe;
     const uint32_t capacity = std::max<uint32_t>(1, nb + nb / 2);   // README.md:114
-    GOLAP_TRY(ws_begin(ctx, (uint64_t)capacity * 4 + (uint64_t)nb * 4 + 4096, st));
+    const bool keep_b = (p->join_type & 1) != 0;
+    GOLAP_TRY(ws_begin(ctx, (uint64_t)capacity * 4 + (uint64_t)nb * 4 + (keep_b ? nb : 0) + 8192, st));
     uint32_t* buckets = (uint32_t*)ws_take(ctx, (uint64_t)capacity * 4);
-    uint32_t* next = (uint32_t*)ws_take(ctx, (uint64_t)nb * 4);
-    if (!buckets || !next) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    uint32_t* next = (uint32_t*)ws_take(ctx, (uint64_t)std::max<uint32_t>(nb, 1) * 4);
+    uint8_t* hit = keep_b ? (uint8_t*)ws_take(ctx, std::max<uint32_t>(nb, 1)) : nullptr;
+    if (!buckets || !next || (keep_b && !hit)) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+    if (keep_b) GOLAP_HIP_TRY(ctx, hipMemsetAsync(hit, 0, std::max<uint32_t>(nb, 1), st));
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
     {
         KernelTimer t(ctx, "bcast_build_table", st, 8ull * nb);
         hipLaunchKernelGGL(k_fill_u32, dim3(std::min<uint32_t>(cus * 8, (uint32_t)ceil_div(capacity, 256))), dim3(256), 0, st, buckets, capacity,
                            JN_EMPTY);
-        hipLaunchKernelGGL(k_bcast_build, dim3(std::min<uint32_t>(cus * 8, (uint32_t)ceil_div(nb, 256))), dim3(256), 0, st,
-                           (const long long*)p->build_key_ptr, nb, buckets, capacity, next);
+        if (nb)
+            hipLaunchKernelGGL(k_bcast_build, dim3(std::min<uint32_t>(cus * 8, (uint32_t)ceil_div(nb, 256))), dim3(256), 0, st,
+                               (const long long*)p->build_key_ptr, nb, buckets, capacity, next);
     }
-    {
+    if (npr) {
         KernelTimer t(ctx, "bcast_probe_table", st, 8ull * npr);
         const uint32_t batch = BC_THREADS * BC_R;
-        hipLaunchKernelGGL(k_bcast_probe, dim3(std::min<uint32_t>(cus * 4, (uint32_t)ceil_div(npr, batch))), dim3(BC_THREADS), 0, st,
-                           (const long long*)p->build_key_ptr, buckets, capacity, next, (const long long*)p->probe_key_ptr, npr,
-                           p->build_rid_base, p->probe_rid_base, (uint2*)p->out_pairs_ptr, (unsigned long long*)p->out_count_ptr,
-                           (unsigned long long)p->max_pairs);
+        const dim3 grid(std::min<uint32_t>(cus * 4, (uint32_t)ceil_div(npr, batch))), block(BC_THREADS);
+#define GOLAP_BC(JT)                                                                                                                       \
+    hipLaunchKernelGGL(k_bcast_probe<JT>, grid, block, 0, st, (const long long*)p->build_key_ptr, buckets, capacity, next,                 \
+                       (const long long*)p->probe_key_ptr, npr, p->build_rid_base, p->probe_rid_base, (uint2*)p->out_pairs_ptr,            \
+                       (unsigned long long*)p->out_count_ptr, (unsigned long long)p->max_pairs, hit)
+        switch (p->join_type) {
+            case 0: GOLAP_BC(0); break;
+            case 1: GOLAP_BC(1); break;
+            case 2: GOLAP_BC(2); break;
+            default: GOLAP_BC(3); break;
+        }
+#undef GOLAP_BC
+    }
+    if (keep_b && nb) {
+        KernelTimer t(ctx, "bcast_unmatched_build", st, (uint64_t)nb);
+        const uint32_t batch = BC_THREADS * BC_R;
+        hipLaunchKernelGGL(k_bcast_unmatched_build, dim3(std::min<uint32_t>(cus * 4, (uint32_t)ceil_div(nb, batch))), dim3(BC_THREADS), 0, st, hit, nb,
+                           p->build_rid_base, (uint2*)p->out_pairs_ptr, (unsigned long long*)p->out_count_ptr, (unsigned long long)p->max_pairs);
     }
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     ws_end(ctx, st);
@@ -1235,7 +1412,13 @@ int32_t golap_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_joi
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_count_ptr, 0, 8, st));
-    if (p->n_build == 0 || p->n_probe == 0) return GOLAP_OK;   // executor.rs:231-233
+    if (p->join_type < 0 || p->join_type > 3) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad join_type %d", p->join_type);
+    if (p->n_build == 0 || p->n_probe == 0) {
+        // executor.rs:231-233: nothing to join.  An outer join still keeps the non-empty preserved side.
+        const bool keep = p->n_build ? (p->join_type & 1) != 0 : (p->n_probe && (p->join_type & 2) != 0);
+        if (!keep) return GOLAP_OK;
+        return broadcast_hash_join(ctx, p, st);   // one table pass handles an empty side
+    }
     if (strategy == GOLAP_JOIN_BROADCAST_HASH) return broadcast_hash_join(ctx, p, st);
     return radix_hash_join(ctx, p, st);
 }

@@ -114,7 +114,10 @@ __global__ __launch_bounds__(OP_THREADS) void k_take8(const unsigned long long* 
     unsigned long long n = count_ptr ? *count_ptr : n_max;
     if (n > n_max) n = n_max;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
-        out[i] = col[idx[i]];
+    {
+        const uint32_t j = idx[i];
+        out[i] = j == 0xFFFFFFFFu ? 0ull : col[j];   // NULL row id (outer joins) -> 0, the caller marks the slot invalid
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -190,7 +190,7 @@ class Context:
 
     # ---- GpuHashJoin ------------------------------------------------------------
     def join(self, build_keys, probe_keys, out_pairs=None, max_pairs=None, strategy=None, build_rid_base=0, probe_rid_base=0,
-             out_count=None):
+             out_count=None, join_type=0):
         """JoinKernel::join.  -> (pairs int32[max_pairs,2] holding u32 (build_rid, probe_rid), count int64[1] device).
 
         Pair order is unspecified; the count keeps counting past max_pairs (join_kernels.cuh:155-160).
@@ -209,7 +209,7 @@ class Context:
         if out_count is None:
             out_count = torch.zeros(1, dtype=torch.int64, device=build_keys.device)
         prm = N.JoinParams(_ptr(build_keys), _ptr(probe_keys), nb, npr, _ptr(out_pairs), _ptr(out_count), max_pairs,
-                           build_rid_base, probe_rid_base)
+                           build_rid_base, probe_rid_base, join_type)
         self._ck(self._lib.golap_join(self._h, strategy, C.byref(prm), _stream()))
         return out_pairs, out_count
 

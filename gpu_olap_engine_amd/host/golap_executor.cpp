@@ -34,6 +34,8 @@ struct Column {
     std::string name;
     DType dtype = DType::Other;
     std::vector<uint8_t> data;   // packed little-endian values, nulls -> 0 (record_batch_convert.rs:102-110)
+    std::vector<uint8_t> valid;  // Arrow validity bitmap of an OUTPUT column (empty = all valid); only outer joins produce nulls
+    uint64_t null_count = 0;
     uint64_t rows = 0;
     size_t width() const { return dtype == DType::Int32 ? 4 : 8; }
 };
@@ -96,7 +98,7 @@ bool import_batch(ArrowArray* arr, ArrowSchema* sch, RecordBatch& out, std::stri
 
 // ---- export (the exported arrays own copies of the column data) ----
 struct ExportPriv {
-    std::vector<std::vector<uint8_t>> data;
+    std::vector<std::vector<uint8_t>> data, valid;
     std::vector<const void*> bufs;   // 2 per child + 1 for the struct
     std::vector<ArrowArray> child_arrays;
     std::vector<ArrowArray*> child_ptrs;
@@ -125,18 +127,21 @@ void export_batch(RecordBatch&& b, ArrowArray* oa, ArrowSchema* os) {
     auto priv = std::make_shared<ExportPriv>();
     const size_t nc = b.cols.size();
     priv->data.resize(nc);
+    priv->valid.resize(nc);
     priv->bufs.resize(2 * nc + 1, nullptr);
     priv->child_arrays.resize(nc);
     priv->child_schemas.resize(nc);
     priv->names.resize(nc);
     for (size_t c = 0; c < nc; ++c) {
         priv->data[c] = std::move(b.cols[c].data);
+        priv->valid[c] = std::move(b.cols[c].valid);
         priv->names[c] = b.cols[c].name;
-        priv->bufs[2 * c] = nullptr;
+        priv->bufs[2 * c] = priv->valid[c].empty() ? nullptr : (const void*)priv->valid[c].data();
         priv->bufs[2 * c + 1] = priv->data[c].empty() ? (const void*)"" : (const void*)priv->data[c].data();
         ArrowArray& ca = priv->child_arrays[c];
         memset(&ca, 0, sizeof ca);
         ca.length = (int64_t)b.num_rows;
+        ca.null_count = (int64_t)b.cols[c].null_count;
         ca.n_buffers = 2;
         ca.buffers = &priv->bufs[2 * c];
         ca.release = release_child_array;
@@ -144,7 +149,7 @@ void export_batch(RecordBatch&& b, ArrowArray* oa, ArrowSchema* os) {
         memset(&cs, 0, sizeof cs);
         cs.format = format_of_dtype(b.cols[c].dtype);
         cs.name = priv->names[c].c_str();
-        cs.flags = 0;
+        cs.flags = b.cols[c].null_count ? 2 /* ARROW_FLAG_NULLABLE */ : 0;
         cs.release = release_child_schema;
         priv->child_ptrs.push_back(&ca);
         priv->child_sptrs.push_back(&cs);
@@ -378,7 +383,6 @@ static bool concat_i64(const std::vector<RecordBatch>& bs, const golap_expr& key
 // ---------------------------------------------------------------------------
 int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out) {
     if (left.empty() || right.empty()) return GOLAP_OK;                 // :231-233 -> vec![]
-    if (p.join_type != GOLAP_JOIN_INNER) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: only JoinType::Inner is implemented (join_kernels.cuh:115-166 is inner)");
     if (p.left_keys.empty() || p.right_keys.empty()) return herr(GOLAP_ERR_INVALID_ARG, "GpuHashJoin needs one key per side");
     // FIRST key expression only (:245)
     const golap_expr &lk = *p.left_keys[0], &rk = *p.right_keys[0];
@@ -396,7 +400,9 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
         if (c.dtype != DType::Int64 && c.dtype != DType::Float64) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: payload column '" + c.name + "' is neither Int64 nor Float64");
     uint64_t m = 0;
     DevBuf dpairs;
-    if (nb && np) {
+    const bool outer_keeps_something = (nb && (p.join_type == GOLAP_JOIN_LEFT || p.join_type == GOLAP_JOIN_FULL)) ||
+                                       (np && (p.join_type == GOLAP_JOIN_RIGHT || p.join_type == GOLAP_JOIN_FULL));
+    if ((nb && np) || outer_keeps_something) {
         DevBuf db, dp, dcnt;
         H_TRY(db.alloc(ctx, nb * 8));
         H_TRY(dp.alloc(ctx, np * 8));
@@ -404,13 +410,14 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
         H_TRY(h2d(bkeys.data(), db.ptr, nb * 8));
         H_TRY(h2d(pkeys.data(), dp.ptr, np * 8));
         H_TRY(xsync());
-        uint64_t cap = np;   // first guess: one match per probe row; the count is the TRUE total (join_kernels.cuh:155-160)
+        uint64_t cap = std::max<uint64_t>(np + ((p.join_type & 1) ? nb : 0), 1);   // first guess; the count is the TRUE total (join_kernels.cuh:155-160)
         for (int attempt = 0; attempt < 2; ++attempt) {
             H_TRY(dpairs.alloc(ctx, cap * 8));
             golap_join_params jp;
             memset(&jp, 0, sizeof jp);
             jp.build_key_ptr = db.ptr; jp.probe_key_ptr = dp.ptr; jp.n_build = nb; jp.n_probe = np;
             jp.out_pairs_ptr = dpairs.ptr; jp.out_count_ptr = dcnt.ptr; jp.max_pairs = cap;
+            jp.join_type = (int32_t)p.join_type;
             H_TRY(golap_join(ctx, golap_choose_strategy(nb), &jp, nullptr));   // JoinKernel::choose_strategy, join_kernel.rs:71-77
             H_TRY(ksync());
             H_TRY(d2h(dcnt.ptr, &m, 8));
@@ -457,6 +464,17 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
             H_TRY(golap_take_8byte(ctx, dcol.ptr, is_left ? dl.ptr : dr.ptr, 0, m, dout.ptr, nullptr));
             H_TRY(ksync());
             ob.cols[c].rows = m;
+            {   // rows whose source side is missing (NULL row id of an outer join) become Arrow nulls
+                const std::vector<uint32_t>& ix = is_left ? lidx : ridx;
+                uint64_t nulls = 0;
+                for (uint64_t i = 0; i < m; ++i) nulls += ix[i] == 0xFFFFFFFFu;
+                if (nulls) {
+                    ob.cols[c].null_count = nulls;
+                    ob.cols[c].valid.assign((m + 7) / 8, 0);
+                    for (uint64_t i = 0; i < m; ++i)
+                        if (ix[i] != 0xFFFFFFFFu) ob.cols[c].valid[i >> 3] |= (uint8_t)(1u << (i & 7));
+                }
+            }
             ob.cols[c].data.resize(m * 8);
             H_TRY(d2h(dout.ptr, ob.cols[c].data.data(), m * 8));
             H_TRY(xsync());

@@ -142,7 +142,7 @@ int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, 
  * (original order, executor.rs:479-484) and their count (u64, device). */
 int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t n_rows,
                              uint64_t out_indices_ptr /*u32[n_rows]*/, uint64_t out_count_ptr /*u64*/, void* stream);
-/* take_int64, executor.rs:496-507: out[i] = col[indices[i]] for 8-byte columns. */
+/* take_int64, executor.rs:496-507: out[i] = col[indices[i]] for 8-byte columns (index 0xFFFFFFFF = NULL row -> 0). */
 int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_ptr, uint64_t count_ptr /*u64 device, or 0*/,
                          uint64_t n_indices_max, uint64_t out_ptr, void* stream);
 /* BASELINE config 1 shape: execute_filter (executor.rs:161-178) feeding
@@ -177,6 +177,9 @@ typedef struct golap_join_params {
     uint64_t max_pairs;       /* capacity of out_pairs in pairs (join_kernels.cuh:127 max_matches) */
     uint32_t build_rid_base;  /* global row id of build row 0 (executor.rs:249 running offset)     */
     uint32_t probe_rid_base;
+    int32_t  join_type;       /* JoinType, logical_plan.rs:53-58: 0 Inner, 1 Left (every build row kept),
+                                 2 Right (every probe row kept), 3 Full; the missing side of an unmatched
+                                 row is row id 0xFFFFFFFF.  The reference's kernels are inner-only.  */
 } golap_join_params;
 
 /* Inner join on int64 keys; row ids are 0-based positions + *_rid_base.  Pair

@@ -38,6 +38,7 @@ def lib():
             "orc_hash_int64_array": (None, [i64p, C.c_uint64, u32p]),
             "orc_radix_partition": (None, [i64p, u32p, C.c_uint64, C.c_int, i64p, u32p, u64p]),
             "orc_hash_join_i64": (C.c_uint64, [i64p, C.c_uint64, i64p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, C.c_uint64]),
+            "orc_hash_join_outer_i64": (C.c_uint64, [i64p, C.c_uint64, i64p, C.c_uint64, C.c_int, u32p, C.c_uint64]),
             "orc_execute_hash_join": (C.c_uint64, [i64p, u64p, C.c_uint32, i64p, u64p, C.c_uint32, u32p, C.c_uint64]),
             "orc_pair_mix": (C.c_uint64, [C.c_uint32, C.c_uint32]),
             "orc_pairs_checksum": (C.c_uint64, [u32p, C.c_uint64]),
@@ -120,6 +121,15 @@ def hash_join(build_keys, probe_keys, build_rid_base=0, probe_rid_base=0, max_pa
     out = np.empty((cap, 2), np.uint32)
     lib().orc_hash_join_i64(_p(b, C.c_int64), b.size, _p(p, C.c_int64), p.size, build_rid_base, probe_rid_base,
                             _p(out, C.c_uint32), cap)
+    return out, m
+
+
+def hash_join_outer(build_keys, probe_keys, join_type):
+    """join_type 0 Inner / 1 Left / 2 Right / 3 Full -> canonical (M,2) uint32 [build_rid, probe_rid], NULL = 0xFFFFFFFF."""
+    b, p = _c(build_keys, np.int64), _c(probe_keys, np.int64)
+    m = lib().orc_hash_join_outer_i64(_p(b, C.c_int64), b.size, _p(p, C.c_int64), p.size, join_type, None, 0)
+    out = np.empty((m, 2), np.uint32)
+    lib().orc_hash_join_outer_i64(_p(b, C.c_int64), b.size, _p(p, C.c_int64), p.size, join_type, _p(out, C.c_uint32), m)
     return out, m
 
 

@@ -153,6 +153,38 @@ uint64_t orc_hash_join_i64(const int64_t* build_keys, uint64_t n_build,
     return m;
 }
 
+// Outer variants of the same join (JoinType, gpu-olap-core/src/logical_plan.rs:53-58; the reference's executor
+// and kernels only ever produce the inner result).  Left = build side preserved, Right = probe side preserved,
+// Full = both; the missing side of an unmatched row is row id 0xFFFFFFFF (NULL).  Canonical order as above
+// (NULL sorts last).  join_type: 0 Inner, 1 Left, 2 Right, 3 Full.
+uint64_t orc_hash_join_outer_i64(const int64_t* build_keys, uint64_t n_build, const int64_t* probe_keys, uint64_t n_probe,
+                                 int join_type, uint32_t* out_pairs, uint64_t max_pairs) {
+    std::unordered_map<int64_t, std::vector<uint32_t>> m;
+    for (uint64_t i = 0; i < n_build; ++i) m[build_keys[i]].push_back((uint32_t)i);
+    std::vector<uint8_t> hit(n_build, 0);
+    std::vector<uint64_t> pairs;
+    const bool keep_build = join_type == 1 || join_type == 3, keep_probe = join_type == 2 || join_type == 3;
+    for (uint64_t j = 0; j < n_probe; ++j) {
+        auto it = m.find(probe_keys[j]);
+        if (it == m.end()) {
+            if (keep_probe) pairs.push_back(((uint64_t)(uint32_t)j << 32) | 0xFFFFFFFFull);
+            continue;
+        }
+        for (uint32_t b : it->second) { hit[b] = 1; pairs.push_back(((uint64_t)(uint32_t)j << 32) | b); }
+    }
+    if (keep_build)
+        for (uint64_t i = 0; i < n_build; ++i)
+            if (!hit[i]) pairs.push_back((0xFFFFFFFFull << 32) | (uint32_t)i);
+    std::sort(pairs.begin(), pairs.end());
+    uint64_t mm = pairs.size(), w = std::min(mm, max_pairs);
+    if (out_pairs)
+        for (uint64_t i = 0; i < w; ++i) {
+            out_pairs[2 * i] = (uint32_t)(pairs[i] & 0xFFFFFFFFu);
+            out_pairs[2 * i + 1] = (uint32_t)(pairs[i] >> 32);
+        }
+    return mm;
+}
+
 // ---------------------------------------------------------------------------
 // Hash join, executor semantics -- gpu-olap-core/src/executor.rs:220-265.
 // Build side = left, FIRST key column only, Int64, HashMap<i64, Vec<usize>>

@@ -143,6 +143,47 @@ def test_capacity_overflow_keeps_counting(ctx, strategy):
     assert len(set(map(tuple, got.tolist()))) == cap
 
 
+def outer_check(ctx, b, p, strategy, jt):
+    bt = torch.from_numpy(np.ascontiguousarray(b, dtype=np.int64)).cuda() if len(b) else torch.empty(0, dtype=torch.int64, device="cuda")
+    pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)).cuda() if len(p) else torch.empty(0, dtype=torch.int64, device="cuda")
+    exp, me = oracle.hash_join_outer(b, p, jt)
+    cap = max(1, me + 64)
+    pairs, cnt = ctx.join(bt, pt, max_pairs=cap, strategy=strategy, join_type=jt)
+    torch.cuda.synchronize()
+    m = int(cnt.item())
+    assert m == me, f"jt={jt}: count {m} != oracle {me}"
+    got = canonical(pairs[:m].cpu().numpy().view(np.uint32))
+    assert np.array_equal(got, exp), f"jt={jt}"
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+@pytest.mark.parametrize("jt", [N.JT_INNER, N.JT_LEFT, N.JT_RIGHT, N.JT_FULL])
+def test_outer_joins(ctx, strategy, jt):
+    """JoinType (logical_plan.rs:53-58): Left keeps every build row, Right every probe row, Full both; NULL side = 0xFFFFFFFF."""
+    rng = np.random.default_rng(jt)
+    # hand-checkable
+    outer_check(ctx, [1, 2, 2, 3, 9], [2, 5, 3, 2], strategy, jt)
+    # random with misses and duplicates on both sides
+    outer_check(ctx, rng.integers(0, 3000, 20_000), rng.integers(1500, 4500, 30_000), strategy, jt)
+    # empty sides
+    outer_check(ctx, [], [4, 5, 6], strategy, jt)
+    outer_check(ctx, [4, 5, 6], [], strategy, jt)
+    # disjoint: nothing matches
+    outer_check(ctx, np.arange(0, 5000), np.arange(10_000, 17_000), strategy, jt)
+    # skew: one sub-partition needs several LDS table chunks (probe "matched" state must survive across chunks)
+    i = np.arange(12_000, dtype=np.int64)
+    b = (i << 32) | (i ^ 0x5A5A)                      # one hash value, 12000 distinct keys -> 3 table chunks
+    p = np.concatenate([b[::2], (i[:3000] << 32) | (i[:3000] ^ 0x1111), b[:10]])
+    outer_check(ctx, b, p, strategy, jt)
+
+
+def test_outer_join_large_radix(ctx):
+    n = 3_000_000
+    b = oracle.gen_sm64_mod(51, 0, n, 2 * n)
+    p = oracle.gen_sm64_mod(52, 0, n, 2 * n)
+    outer_check(ctx, b, p, N.JOIN_RADIX_HASH, N.JT_FULL)
+
+
 def test_radix_multi_pass_16m(ctx):
     """16M join 16M forces two partition passes (sub-partitions must fit the LDS table)."""
     n = 16_000_000

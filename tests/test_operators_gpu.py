@@ -103,8 +103,29 @@ def test_hash_join_edge_cases(ctx):
     out = O.execute(O.GpuHashJoin(O.Batches([l]), O.Batches([r]), [O.Column(0, "id")], [O.Column(0, "id")]), ctx)
     assert out[0].num_rows == 2000
     assert np.array_equal(out[0].column(1).to_numpy(), np.tile(np.arange(50), 40)) and np.array_equal(out[0].column(3).to_numpy(), np.repeat(np.arange(40.0), 50))
-    with pytest.raises(O.OperatorError):
-        O.execute(O.GpuHashJoin(O.Batches([l]), O.Batches([r]), [O.Column(0, "id")], [O.Column(0, "id")], join_type="Left"), ctx)
+    with pytest.raises(KeyError):
+        O.execute(O.GpuHashJoin(O.Batches([l]), O.Batches([r]), [O.Column(0, "id")], [O.Column(0, "id")], join_type="Cross"), ctx)
+
+
+@pytest.mark.parametrize("jt,code", [("Left", 1), ("Right", 2), ("Full", 3)])
+def test_outer_joins_produce_arrow_nulls(ctx, jt, code):
+    """JoinType::{Left,Right,Full} (logical_plan.rs:53-58): the missing side's columns are Arrow nulls."""
+    rng = np.random.default_rng(code)
+    lk = rng.integers(0, 200, 500).astype(np.int64)
+    rk = rng.integers(100, 300, 400).astype(np.int64)
+    lp, rp = rng.random(500), rng.integers(0, 10**6, 400).astype(np.int64)
+    out = O.execute(O.GpuHashJoin(O.Batches([rb(id=lk, lpay=lp)]), O.Batches([rb(fk=rk, rpay=rp)]), [O.Column(0, "id")], [O.Column(0, "fk")], join_type=jt), ctx)
+    pairs, m = oracle.hash_join_outer(lk, rk, code)
+    assert out[0].num_rows == m
+    bi, pi = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    bnull, pnull = pairs[:, 0] == 0xFFFFFFFF, pairs[:, 1] == 0xFFFFFFFF
+    exp_id = [None if n else int(lk[i]) for i, n in zip(bi, bnull)]
+    exp_lp = [None if n else float(lp[i]) for i, n in zip(bi, bnull)]
+    exp_fk = [None if n else int(rk[i]) for i, n in zip(pi, pnull)]
+    exp_rp = [None if n else int(rp[i]) for i, n in zip(pi, pnull)]
+    assert out[0].column(0).to_pylist() == exp_id and out[0].column(1).to_pylist() == exp_lp
+    assert out[0].column(2).to_pylist() == exp_fk and out[0].column(3).to_pylist() == exp_rp
+    assert out[0].column(0).null_count == int(bnull.sum()) and out[0].column(2).null_count == int(pnull.sum())
 
 
 def test_aggregate_ungrouped_all_funcs(ctx):
