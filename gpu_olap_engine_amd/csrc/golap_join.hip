@@ -43,6 +43,17 @@ constexpr int JN_R = 8;                    // probe rows per thread per batch
 constexpr uint32_t JN_EMPTY = 0xFFFFFFFFu; // join_kernels.cuh:146 sentinel
 static_assert(JN_R * JN_WAVES == 64, "slice x wave totals are scanned by one wave");
 
+// streamed-once inputs: non-temporal loads keep them from displacing the partially written output lines in L2
+// (GOLAP_NT=0 at build time restores plain loads for A/B runs)
+#ifndef GOLAP_NT
+#define GOLAP_NT 0   // measured on MI355X: non-temporal input loads were 0-8 % slower in both scatter kernels
+#endif
+#if GOLAP_NT
+#define NT_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define NT_LOAD(p) (*(p))
+#endif
+
 constexpr int SC_THREADS = 256;
 constexpr int SC_EPT = 16;
 constexpr int SC_ELEMS = SC_THREADS * SC_EPT;   // 4096 elements per scan block
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
 #pragma unroll
         for (int r = 0; r < BT_RPT; ++r) {   // unconditional, clamped: all 24 loads in flight together
             const uint32_t i = r * PT_THREADS + tid;
-            key[r] = in_keys[rbase + (i < tn ? i : tn - 1)];
+            key[r] = NT_LOAD(&in_keys[rbase + (i < tn ? i : tn - 1)]);
         }
         lds_barrier();
 #pragma unroll
@@ -482,13 +493,13 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
 #pragma unroll
     for (int r = 0; r < WC_RPT; ++r) {   // unconditional loads on clamped indices (t_eff >= 1): all in flight together
         const uint32_t i = r * WC_THREADS + tid;
-        key[r] = in_keys[off + (i < t_eff ? i : t_eff - 1)];
+        key[r] = NT_LOAD(&in_keys[off + (i < t_eff ? i : t_eff - 1)]);
     }
     if (in_rids) {
 #pragma unroll
         for (int r = 0; r < WC_RPT; ++r) {
             const uint32_t i = r * WC_THREADS + tid;
-            rid[r] = in_rids[off + (i < t_eff ? i : t_eff - 1)];
+            rid[r] = NT_LOAD(&in_rids[off + (i < t_eff ? i : t_eff - 1)]);
         }
     } else {
 #pragma unroll
@@ -576,13 +587,13 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
 #pragma unroll
             for (int r = 0; r < WC_RPT; ++r) {
                 const uint32_t i = r * WC_THREADS + tid;
-                key[r] = in_keys[nb + (i < t_next ? i : t_next - 1)];
+                key[r] = NT_LOAD(&in_keys[nb + (i < t_next ? i : t_next - 1)]);
             }
             if (in_rids) {
 #pragma unroll
                 for (int r = 0; r < WC_RPT; ++r) {
                     const uint32_t i = r * WC_THREADS + tid;
-                    rid[r] = in_rids[nb + (i < t_next ? i : t_next - 1)];
+                    rid[r] = NT_LOAD(&in_rids[nb + (i < t_next ? i : t_next - 1)]);
                 }
             } else {
 #pragma unroll
