@@ -95,7 +95,7 @@ class ShardedJoin:
             return self.forced_extra_bits
         return max(0, min(2, self.backend.total_bits(n_build_total) - 8 - 9))
 
-    def _exchange_start(self, keys, rids, offs_host, e1):
+    def _exchange_start(self, keys, rids, offs_host, e1, rows_hint):
         """keys/rids are partitioned owner-major into (256 << e1) buckets; offs_host are the bucket offsets.
         Starts the all-to-all (async) and returns an _Exchange whose segment table is indexed [group][source],
         group = local bucket index in [0, (256/P) << e1).
@@ -120,10 +120,9 @@ class ShardedJoin:
         x.n_recv = int(rsz.sum())
         x.keys = self.backend.empty(max(x.n_recv, 1), torch.int64, keys)
         x.rids = self.backend.empty(max(x.n_recv, 1), torch.int32, keys)
-        # rounds: every rank must agree -> derive from the global maximum message (rows)
-        biggest = torch.tensor([max(int(sizes.sum(dim=1).max()), int(rsz.sum(dim=1).max()))], dtype=torch.int64, device=dev)
-        dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=self.group)
-        rounds = max(1, min(per, -(-int(biggest.item()) * 8 // self.max_msg_bytes)))
+        # rounds: every rank must agree WITHOUT another collective -> a bound every rank can compute: no message
+        # can carry more rows than one rank holds (rows_hint = global rows / P, identical everywhere)
+        rounds = max(1, min(per, -(-(int(rows_hint) + P) * 8 // self.max_msg_bytes)))
         bounds = [per * j // rounds for j in range(rounds + 1)]
         x.seg_off = [0] * (per * P)
         x.seg_len = [0] * (per * P)
@@ -164,18 +163,21 @@ class ShardedJoin:
             pos += int(sum(recv_counts))
         return x
 
-    def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs=None, max_pairs=None):
+    def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs=None, max_pairs=None,
+             n_probe_total=None):
         """Local shard of the global join -> (pairs [m,2] int32 view of u32 GLOBAL row ids, count tensor, rows received per side).
 
         Schedule (one compute stream + the collective's own stream):
           partition(build) -> exchange(build) starts || partition(probe) -> exchange(probe) starts ||
           local sub-partitioning(build) -> local sub-partitioning(probe) -> LDS join."""
         P = self.world
+        if n_probe_total is None:
+            n_probe_total = n_build_total
         e1 = self.extra_bits(n_build_total)
         bk, br, boff = self.backend.radix_partition(build_keys, build_rid_base, P, e1)
-        xb = self._exchange_start(bk, br, boff.cpu().numpy(), e1)
+        xb = self._exchange_start(bk, br, boff.cpu().numpy(), e1, -(-n_build_total // P))
         pk, pr, poff = self.backend.radix_partition(probe_keys, probe_rid_base, P, e1)
-        xp = self._exchange_start(pk, pr, poff.cpu().numpy(), e1)
+        xp = self._exchange_start(pk, pr, poff.cpu().numpy(), e1, -(-n_probe_total // P))
         n_groups = (N_PARTITIONS // P) << e1
         self.backend.join_begin(n_groups, P, 8 + e1, max(1, n_build_total // P), xb.n_recv, xp.n_recv)
         xb.wait()

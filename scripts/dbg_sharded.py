@@ -20,10 +20,10 @@ sj = ShardedJoin(HipBackend(ctx))
 if os.environ.get("CHECK_BIG"):   # demonstrates the RCCL > 4 GiB single-message problem (world size 1, 8 GB self send)
     bk, br, boff = ctx.radix_partition(b, rid_base=0, n_owners=1)
     sj.max_msg_bytes = 1 << 40
-    x = sj._exchange_start(bk, br, boff.cpu().numpy(), 0); x.wait(); torch.cuda.synchronize()
+    x = sj._exchange_start(bk, br, boff.cpu().numpy(), 0, n); x.wait(); torch.cuda.synchronize()
     log("single-round exchange equal to source:", bool(torch.equal(x.keys[:n], bk[:n])), bool(torch.equal(x.rids[:n], br[:n])))
     sj.max_msg_bytes = 1 << 30
-    x = sj._exchange_start(bk, br, boff.cpu().numpy(), 0); x.wait(); torch.cuda.synchronize()
+    x = sj._exchange_start(bk, br, boff.cpu().numpy(), 0, n); x.wait(); torch.cuda.synchronize()
     log("bounded-round exchange equal to source:", bool(torch.equal(x.keys[:n], bk[:n])), bool(torch.equal(x.rids[:n], br[:n])))
     del x, bk, br
 out = torch.empty((n + 1024, 2), dtype=torch.int32, device="cuda")

@@ -20,9 +20,9 @@ for it in range(3):
     e1 = sj.extra_bits(n); mark("extra_bits")
     bk, br, boff = be.radix_partition(b, 0, 1, e1); mark("partition b")
     o = boff.cpu().numpy(); mark("offs cpu")
-    xb = sj._exchange_start(bk, br, o, e1); mark("exchange_start b")
+    xb = sj._exchange_start(bk, br, o, e1, n); mark("exchange_start b")
     pk, pr, poff = be.radix_partition(p, 0, 1, e1); mark("partition p")
-    xp = sj._exchange_start(pk, pr, poff.cpu().numpy(), e1); mark("exchange_start p")
+    xp = sj._exchange_start(pk, pr, poff.cpu().numpy(), e1, n); mark("exchange_start p")
     be.join_begin(256 << e1, 1, 8 + e1, n, xb.n_recv, xp.n_recv); mark("join_begin")
     xb.wait(); be.join_side(0, xb.keys, xb.rids, xb.seg_off, xb.seg_len, xb.n_recv); mark("side b")
     xp.wait(); be.join_side(1, xp.keys, xp.rids, xp.seg_off, xp.seg_len, xp.n_recv); mark("side p")
