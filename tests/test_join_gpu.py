@@ -396,6 +396,32 @@ def test_verify_pairs_and_determinism(ctx):
     assert sums[0][0] == oracle.pairs_checksum(exp)
 
 
+@pytest.mark.parametrize("strategy", STRATS)
+def test_join_is_hip_graph_capturable(ctx, strategy):
+    """No allocation / synchronisation on the warm launch path: a join can be captured into a HIP graph and replayed."""
+    n = 300_000
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx.join(bt, pt, out_pairs=out, max_pairs=n, strategy=strategy, out_count=cnt)   # warms the workspace
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        ctx.join(bt, pt, out_pairs=out, max_pairs=n, strategy=strategy, out_count=cnt)
+    torch.cuda.synchronize()
+    exp, me = oracle.hash_join(bt.cpu().numpy(), pt.cpu().numpy())
+    for _ in range(2):
+        out.zero_(); cnt.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        assert m == me
+        assert np.array_equal(canonical(out[:m].cpu().numpy().view(np.uint32)), exp)
+
+
 def test_sort_merge_unsupported(ctx):
     from gpu_olap_engine_amd.engine import GolapError
     t = torch.zeros(4, dtype=torch.int64, device="cuda")
