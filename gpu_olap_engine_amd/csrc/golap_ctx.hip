@@ -228,6 +228,23 @@ void TransferQueue::destroy() {
 }
 
 // ---------------------------------------------------------------------------
+// zero_async
+// ---------------------------------------------------------------------------
+__global__ void k_zero_u32(uint32_t* __restrict__ a, unsigned long long n) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) a[i] = 0u;
+}
+
+int32_t zero_async(golap_ctx* ctx, hipStream_t st, void* ptr, uint64_t bytes) {
+    if (!bytes) return GOLAP_OK;
+    if ((uint64_t)(uintptr_t)ptr & 3) return fail(ctx, GOLAP_ERR_INVALID_ARG, "zero_async: pointer must be 4-byte aligned");
+    const unsigned long long n = (bytes + 3) / 4;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->prop.multiProcessorCount * 8, (n + 255) / 256));
+    hipLaunchKernelGGL(k_zero_u32, dim3(grid), dim3(256), 0, st, (uint32_t*)ptr, n);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Workspace
 // ---------------------------------------------------------------------------
 int32_t ws_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st) {

@@ -130,6 +130,11 @@ struct KernelTimer {
     PendingEvent ev;
     bool on;
     KernelTimer(golap_ctx* c, const char* name, hipStream_t s, uint64_t bytes = 0) : ctx(c), st(s), on(c->prof.enabled) {
+        if (on) {   // timing events have no meaning inside a stream capture (and must not become graph nodes)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+            if (cs != hipStreamCaptureStatusNone) on = false;
+        }
         if (!on) return;
         ev.stat = c->prof.stat_index(name);
         c->prof.stats[ev.stat].launches += 1;
@@ -162,8 +167,13 @@ uint64_t ws_take(golap_ctx* ctx, uint64_t bytes);   // 256-B aligned bump; retur
 void ws_end(golap_ctx* ctx, hipStream_t st);
 
 // in-place exclusive scan of n u32 values (n <= 16.7M); block_sums needs ceil(n/4096)+1 u32 (golap_join.hip)
-int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums);
+int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if = nullptr);
 constexpr uint32_t FLAT_SCAN_BLOCK = 4096;
+
+// Zero-fill by a kernel, not hipMemsetAsync: a captured memset node was observed to write garbage on its first
+// graph launch when a pageable D2H copy ran between capture and launch (ROCm 7.0 runtime); kernel nodes are immune.
+// `bytes` is rounded up to a multiple of 4 (callers own at least that much).
+int32_t zero_async(golap_ctx* ctx, hipStream_t st, void* ptr, uint64_t bytes);
 
 static inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 static inline uint64_t ceil_div(uint64_t x, uint64_t a) { return (x + a - 1) / a; }

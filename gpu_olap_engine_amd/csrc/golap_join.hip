@@ -74,8 +74,11 @@ __global__ void k_setup_uniform(uint32_t n, uint32_t chunk_rows, uint32_t n_chun
 
 // groups of this pass = (group, bucket) pairs of the previous pass: group g spans
 // [prev[g*prev_stride], prev[(g+1)*prev_stride]) in the previous pass's output.
+// `run_if` (here and on the other exact-path kernels): when non-null the launch is a no-op unless *run_if != 0 --
+// the device-side switch that lets the histogram path stand by behind the no-histogram fast path.
 __global__ void k_setup_from_scan(const uint32_t* __restrict__ prev, uint32_t prev_stride, uint32_t n_groups, uint32_t S,
-                                  uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_len) {
+                                  uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ run_if = nullptr) {
+    if (run_if && *run_if == 0) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_groups * S) return;
     uint32_t g = i / S, s = i % S;
@@ -115,8 +118,10 @@ __global__ void k_setup_from_segments(const uint32_t* __restrict__ seg_off, cons
 // ---------------------------------------------------------------------------
 template <int PASS_TAG>   // only gives each pass its own kernel name in profiles
 __global__ __launch_bounds__(PT_THREADS) void k_hist(const long long* __restrict__ in_keys, const uint32_t* __restrict__ chunk_off,
-                                                     const uint32_t* __restrict__ chunk_len, uint32_t* __restrict__ hist, PassCfg cfg) {
+                                                     const uint32_t* __restrict__ chunk_len, uint32_t* __restrict__ hist, PassCfg cfg,
+                                                     const uint32_t* __restrict__ run_if = nullptr) {
     __shared__ uint32_t s_cnt[PT_MAX_F];
+    if (run_if && *run_if == 0) return;
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
     if (len == 0) return;   // hist is pre-zeroed
@@ -161,8 +166,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(SC_THREADS) void k_scan_reduce(const uint32_t* __restrict__ a, uint32_t n, uint32_t* __restrict__ block_sums) {
+__global__ __launch_bounds__(SC_THREADS) void k_scan_reduce(const uint32_t* __restrict__ a, uint32_t n, uint32_t* __restrict__ block_sums,
+                                                            const uint32_t* __restrict__ run_if = nullptr) {
     __shared__ uint32_t s_w[4];
+    if (run_if && *run_if == 0) return;
     const uint32_t base = blockIdx.x * SC_ELEMS;
     uint32_t v = 0;
 #pragma unroll
@@ -176,8 +183,10 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_reduce(const uint32_t* __re
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-__global__ __launch_bounds__(SC_THREADS) void k_scan_top(uint32_t* __restrict__ block_sums, uint32_t n_blocks) {
+__global__ __launch_bounds__(SC_THREADS) void k_scan_top(uint32_t* __restrict__ block_sums, uint32_t n_blocks,
+                                                         const uint32_t* __restrict__ run_if = nullptr) {
     __shared__ uint32_t s_w[4];
+    if (run_if && *run_if == 0) return;
     // each thread owns SC_EPT consecutive block sums
     uint32_t v[SC_EPT], sum = 0;
 #pragma unroll
@@ -196,8 +205,10 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_top(uint32_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(SC_THREADS) void k_scan_down(uint32_t* __restrict__ a, uint32_t n, const uint32_t* __restrict__ block_sums) {
+__global__ __launch_bounds__(SC_THREADS) void k_scan_down(uint32_t* __restrict__ a, uint32_t n, const uint32_t* __restrict__ block_sums,
+                                                          const uint32_t* __restrict__ run_if = nullptr) {
     __shared__ uint32_t s_w[4];
+    if (run_if && *run_if == 0) return;
     const uint32_t base = blockIdx.x * SC_ELEMS + threadIdx.x * SC_EPT;   // thread owns SC_EPT consecutive elements
     uint32_t v[SC_EPT], sum = 0;
 #pragma unroll
@@ -434,6 +445,53 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
 }
 
 // ---------------------------------------------------------------------------
+// No-histogram last pass.  With ONE work-group per group (S = 1) the write cursors of a group's buckets live in
+// that work-group's LDS, so the pass needs no histogram at all -- provided every (group, bucket) sub-partition
+// owns a pre-provisioned slot.  Hash partitioning makes sub-partition sizes concentrate around n_g / F, so a slot of
+// avg + 6 sqrt(avg) + 48 rows (16-row aligned, i.e. every slot starts on a 128-byte key line) overflows with
+// probability < 1e-8 per slot.  If a slot does overflow (skewed keys), the work-group raises a device flag, the
+// histogram path -- launched right behind with run_if = flag -- redoes the pass exactly, and the join kernel picks
+// the layout by the same flag: nothing is read back to the host, the call stays asynchronous.
+// ---------------------------------------------------------------------------
+struct FixedArgs {
+    const uint32_t* prev_scanned;   // scanned histogram of the previous pass: group g = [prev[g*prev_S], prev[(g+1)*prev_S])
+    uint32_t prev_S;
+    const uint32_t* slot_base;      // [G+1] first row of group g's slot block
+    const uint32_t* slot_cap;       // [G]   rows per slot of group g
+    uint32_t* sub_start;            // [G*F] out: first row of sub-partition (g, f)
+    uint32_t* sub_len;              // [G*F] out: rows of sub-partition (g, f)
+    uint32_t* overflow;             // out: set to 1 when any slot overflowed
+};
+
+__device__ __forceinline__ uint32_t isqrt_u32(uint32_t x) {
+    uint32_t r = (uint32_t)sqrtf((float)x);
+    while ((unsigned long long)r * r > x) --r;
+    while ((unsigned long long)(r + 1) * (r + 1) <= x) ++r;
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_slots_setup(const uint32_t* __restrict__ prev, uint32_t prev_S, uint32_t G, uint32_t F, uint32_t sigmas,
+                                                      uint32_t pad, uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap) {
+    __shared__ uint32_t s_w[16];
+    const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
+    uint32_t total = 0;
+    if (g < G) {
+        const uint32_t n_g = prev[(size_t)(g + 1) * prev_S] - prev[(size_t)g * prev_S];
+        const uint32_t avg = (n_g + F - 1) / F;
+        const uint32_t cap = (avg + sigmas * isqrt_u32(avg) + pad + 15u) & ~15u;
+        slot_cap[g] = cap;
+        total = cap * F;
+    }
+    const uint32_t inc = wave_inclusive_scan(total);
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < wv; ++i) base += s_w[i];
+    if (g < G) slot_base[g] = base + inc - total;
+    if (g == G - 1) slot_base[G] = base + inc;
+}
+
+// ---------------------------------------------------------------------------
 // scatter v2: line-aligned write combining.
 // rocprofv3 on v1 (profiles/r01a): WRITE_SIZE = 1.54 x the bytes written, because a
 // tile's run for one bucket (8-16 rows at fan-out 256-512) starts and ends inside a
@@ -455,11 +513,12 @@ constexpr int WC_CAP = 12288;                 // staging rows (carry + new): 144
 constexpr int WC_MAX_F = 512;                 // carry <= 15 * F = 7680 rows, leaves >= 512 new rows per tile
 constexpr int WC_CARRY_PT = 16 * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
 
-template <int PASS_TAG>
+template <int PASS_TAG, bool FIXED>
 __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __restrict__ in_keys, const uint32_t* __restrict__ in_rids,
                                                            uint32_t rid_base, const uint32_t* __restrict__ chunk_off,
                                                            const uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ scanned,
-                                                           long long* __restrict__ out_keys, uint32_t* __restrict__ out_rids, PassCfg cfg) {
+                                                           long long* __restrict__ out_keys, uint32_t* __restrict__ out_rids, PassCfg cfg,
+                                                           FixedArgs fx, const uint32_t* __restrict__ run_if) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [WC_CAP]
     uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + WC_CAP * 8);      // [WC_CAP]
@@ -473,12 +532,24 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
     uint32_t* s_w = s_emit + F;            // [WC_WAVES]
     uint32_t* s_misc = s_w + WC_WAVES;     // [0] carry total of the next tile
 
+    if (run_if && *run_if == 0) return;
     const uint32_t chunk = blockIdx.x;
-    const uint32_t len = chunk_len[chunk];
-    if (len == 0) return;
-    const uint32_t off = chunk_off[chunk];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {
+    uint32_t len, off, slot0 = 0, cap = 0;
+    if (FIXED) {   // one work-group = one whole group; buckets go to their pre-provisioned slots
+        off = fx.prev_scanned[(size_t)chunk * fx.prev_S];
+        len = fx.prev_scanned[(size_t)(chunk + 1) * fx.prev_S] - off;
+        slot0 = fx.slot_base[chunk];
+        cap = fx.slot_cap[chunk];
+        if (len == 0) {
+            if (tid < F) { fx.sub_start[(size_t)chunk * F + tid] = slot0 + tid * cap; fx.sub_len[(size_t)chunk * F + tid] = 0; }
+            return;
+        }
+        if (tid < F) { s_gpos[tid] = slot0 + tid * cap; s_carry[tid] = 0; s_csrc[tid] = 0; }
+    } else {
+        len = chunk_len[chunk];
+        if (len == 0) return;
+        off = chunk_off[chunk];
         const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
         if (tid < F) {
             s_gpos[tid] = scanned[((size_t)g * F + tid) * cfg.S + s];
@@ -608,9 +679,12 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
                 const uint32_t e = s_emit[b];
                 if (e == 0) continue;
                 const uint32_t sb = s_start[b], gp = s_gpos[b];
+                const uint32_t lim = FIXED ? slot0 + (b + 1u) * cap : 0xFFFFFFFFu;   // rows past a slot's end are dropped (flag raised below)
                 for (uint32_t k = ((l - gp) & 15u) + 16u * (q % gpb); k < e; k += 16u * gpb) {   // lane l owns global index == l (mod 16)
-                    out_keys[gp + k] = s_keys[sb + k];
-                    out_rids[gp + k] = s_rids[sb + k];
+                    if (!FIXED || gp + k < lim) {
+                        out_keys[gp + k] = s_keys[sb + k];
+                        out_rids[gp + k] = s_rids[sb + k];
+                    }
                 }
             }
         }
@@ -623,6 +697,15 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         }
         if (last) break;
         t_eff = t_next;
+    }
+    if (FIXED) {
+        lds_barrier();
+        if (tid < F) {
+            const uint32_t start = slot0 + tid * cap, cnt = s_gpos[tid] - start;
+            fx.sub_start[(size_t)chunk * F + tid] = start;
+            fx.sub_len[(size_t)chunk * F + tid] = cnt < cap ? cnt : cap;
+            if (cnt > cap) atomicOr(fx.overflow, 1u);
+        }
     }
 }
 static_assert(WC_CAP - 15 * WC_MAX_F >= 512, "a tile must always have room for new rows");
@@ -639,7 +722,21 @@ struct JoinSide {
     const uint32_t* rids;
     const uint32_t* off;   // sub-partition sp spans [off[sp*stride], off[(sp+1)*stride])
     uint32_t stride;
+    // no-histogram layout (valid while *flag == 0): sub-partition sp = [alt_start[sp], alt_start[sp] + alt_len[sp])
+    const uint32_t* alt_start;
+    const uint32_t* alt_len;
+    const uint32_t* flag;
 };
+
+__device__ __forceinline__ void side_bounds(const JoinSide& S, uint32_t sp, uint32_t& lo, uint32_t& hi) {
+    if (S.alt_start && *S.flag == 0) {
+        lo = S.alt_start[sp];
+        hi = lo + S.alt_len[sp];
+    } else {
+        lo = S.off[(size_t)sp * S.stride];
+        hi = S.off[(size_t)(sp + 1) * S.stride];
+    }
+}
 
 constexpr uint32_t JN_NULL = 0xFFFFFFFFu;   // row id of the missing side of an unmatched row (outer joins)
 
@@ -678,8 +775,9 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
     __shared__ unsigned long long s_base;
 
     const uint32_t sp = blockIdx.x;
-    const uint32_t b0 = B.off[(size_t)sp * B.stride], b1 = B.off[(size_t)(sp + 1) * B.stride];
-    const uint32_t p0 = P.off[(size_t)sp * P.stride], p1 = P.off[(size_t)(sp + 1) * P.stride];
+    uint32_t b0, b1, p0, p1;
+    side_bounds(B, sp, b0, b1);
+    side_bounds(P, sp, p0, p1);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (b1 == b0 || p1 == p0) {
         // one side empty: nothing matches; an outer join still keeps the other side's rows
@@ -1111,7 +1209,27 @@ struct SideResult {
     uint32_t stride = 1;
     const long long* keys = nullptr;
     const uint32_t* rids = nullptr;
+    const uint32_t* alt_start = nullptr;   // no-histogram layout of the last pass (see FixedArgs)
+    const uint32_t* alt_len = nullptr;
+    const uint32_t* flag = nullptr;
+    uint64_t positions = 0;                // rows the final buffers span (padded when the slots layout is used)
 };
+
+// the last pass can skip its histogram when it is the second of two passes over contiguous groups
+static bool use_fast_last_pass(const JoinPlan& plan, bool has_segs) {
+    const char* env = getenv("GOLAP_NOHIST");   // "0" disables (A/B hook)
+    if (env && !strcmp(env, "0")) return false;
+    if (has_segs || plan.passes.size() != 2) return false;
+    const PassPlan& pp = plan.passes[1];
+    return pp.G <= 1024 && pp.cfg.F >= 32 && pp.cfg.F <= (uint32_t)WC_MAX_F;
+}
+
+// rows the final buffers of one side must hold: slots are avg + 6 sqrt(avg) + 48, 16-row aligned (k_slots_setup)
+static uint64_t final_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
+    if (!use_fast_last_pass(plan, has_segs)) return n;
+    const double FG = (double)plan.passes[1].G * (double)plan.passes[1].cfg.F;
+    return n + (uint64_t)(6.0 * (std::sqrt(FG * (double)std::max<uint64_t>(n, 1)) + FG)) + (uint64_t)(72.0 * FG) + 4096;
+}
 
 struct SegTable {
     uint64_t dev_off = 0, dev_len = 0;   // device u32 [G*n_src]
@@ -1148,15 +1266,15 @@ static bool use_big_scatter(uint32_t F, bool local_pass, bool has_rids) {
 template <int TAG>
 static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids, uint32_t rid_base,
                                 const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys, uint32_t* out_rids,
-                                const PassCfg& cfg) {
+                                const PassCfg& cfg, const uint32_t* run_if) {
     if (hist) {
-        hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg);
+        hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if);
     } else if (!wc && use_big_scatter(cfg.F, false, rids != nullptr) && TAG == 1) {
         hipLaunchKernelGGL(k_scatter_big<1>, dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
                            out_keys, out_rids, cfg);
     } else if (wc) {
-        hipLaunchKernelGGL(k_scatter_wc<TAG>, dim3(n_chunks), dim3(WC_THREADS), scatter_wc_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len,
-                           hist_arr, out_keys, out_rids, cfg);
+        hipLaunchKernelGGL((k_scatter_wc<TAG, false>), dim3(n_chunks), dim3(WC_THREADS), scatter_wc_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len,
+                           hist_arr, out_keys, out_rids, cfg, FixedArgs{}, run_if);
     } else {
         hipLaunchKernelGGL(k_scatter<TAG>, dim3(n_chunks), dim3(PT_THREADS), scatter_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len, hist_arr,
                            out_keys, out_rids, cfg);
@@ -1165,21 +1283,21 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
 
 static void launch_pass_kernel(int tag, bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids,
                                uint32_t rid_base, const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys,
-                               uint32_t* out_rids, const PassCfg& cfg) {
+                               uint32_t* out_rids, const PassCfg& cfg, const uint32_t* run_if = nullptr) {
     switch (tag) {
-        case 0: launch_hist_scatter<1>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg); break;
-        case 1: launch_hist_scatter<2>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg); break;
-        default: launch_hist_scatter<3>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg); break;
+        case 0: launch_hist_scatter<1>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if); break;
+        case 1: launch_hist_scatter<2>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if); break;
+        default: launch_hist_scatter<3>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if); break;
     }
 }
 
-int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums) {
+int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if) {
     const uint32_t n_blocks = (uint32_t)ceil_div(n, SC_ELEMS);
     if (n_blocks > (uint32_t)SC_ELEMS) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "scan of %u elements exceeds the 2-level limit", n);
     KernelTimer t(ctx, "scan_offsets", st);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SC_THREADS), 0, st, block_sums, n_blocks);
-    hipLaunchKernelGGL(k_scan_down, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums, run_if);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SC_THREADS), 0, st, block_sums, n_blocks, run_if);
+    hipLaunchKernelGGL(k_scan_down, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums, run_if);
     return GOLAP_OK;
 }
 
@@ -1207,11 +1325,42 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     const uint32_t* prev_scanned = nullptr;
     uint32_t prev_S = 1;
     char name[48];
+    const bool fast_last = use_fast_last_pass(plan, segs != nullptr);
+    const uint32_t* run_if = nullptr;
     for (size_t k = 0; k < np; ++k) {
         PassPlan& pp = plan.passes[k];
         uint32_t S;
         uint32_t n_chunks;
         uint32_t chunk_rows = 0;
+        if (fast_last && k == 1) {
+            // ---- no-histogram pass: one work-group per group writes into pre-provisioned slots ----
+            const uint32_t G = pp.G, F = pp.cfg.F;
+            uint32_t* slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(G + 1) * 4);
+            uint32_t* slot_cap = (uint32_t*)ws_take(ctx, (uint64_t)G * 4);
+            uint32_t* sub_start = (uint32_t*)ws_take(ctx, (uint64_t)G * F * 4);
+            uint32_t* sub_len = (uint32_t*)ws_take(ctx, (uint64_t)G * F * 4);
+            uint32_t* flag = (uint32_t*)ws_take(ctx, 4);
+            if (!slot_base || !slot_cap || !sub_start || !sub_len || !flag) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (slot arrays)");
+            GOLAP_TRY(zero_async(ctx, st, (void*)(flag), 4));
+            uint32_t sigmas = 6, pad = 48;
+            if (const char* env = getenv("GOLAP_SLOT_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }   // test hook: 0 forces overflows
+            hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, prev_scanned, prev_S, G, F, sigmas, pad, slot_base, slot_cap);
+            FixedArgs fx{prev_scanned, prev_S, slot_base, slot_cap, sub_start, sub_len, flag};
+            PassCfg cfg = pp.cfg;
+            cfg.S = 1;
+            {
+                snprintf(name, sizeof name, "radix_scatter_p%zu", k + 1);
+                KernelTimer t(ctx, name, st, 24 * n_rows);
+                hipLaunchKernelGGL((k_scatter_wc<2, true>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F), st, (const long long*)cur_keys,
+                                   (const uint32_t*)cur_rids, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                   (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, (const uint32_t*)nullptr);
+            }
+            GOLAP_HIP_TRY(ctx, hipGetLastError());
+            res.alt_start = sub_start;
+            res.alt_len = sub_len;
+            res.flag = flag;
+            run_if = flag;   // the exact pass below stands by: its kernels return at once unless a slot overflowed
+        }
         if (k == 0 && !segs) {
             // single group: uniform chunks
             uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(std::max<uint64_t>(1, n_rows), PT_TILE)));
@@ -1232,7 +1381,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)n_chunks * 4);
         uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)n_chunks * 4);
         if (!hist || !bsums || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (small arrays)");
-        GOLAP_HIP_TRY(ctx, hipMemsetAsync(hist, 0, (L + 1) * 4, st));
+        GOLAP_TRY(zero_async(ctx, st, (void*)(hist), (L + 1) * 4));
         // descriptors
         {
             const uint32_t tb = 256, gb = (uint32_t)ceil_div(n_chunks, tb);
@@ -1242,22 +1391,22 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
                 hipLaunchKernelGGL(k_setup_from_segments, dim3(gb), dim3(tb), 0, st, (const uint32_t*)segs->dev_off,
                                    (const uint32_t*)segs->dev_len, pp.G, segs->n_src, S / segs->n_src, c_off, c_len);
             else
-                hipLaunchKernelGGL(k_setup_from_scan, dim3(gb), dim3(tb), 0, st, prev_scanned, prev_S, pp.G, S, c_off, c_len);
+                hipLaunchKernelGGL(k_setup_from_scan, dim3(gb), dim3(tb), 0, st, prev_scanned, prev_S, pp.G, S, c_off, c_len, run_if);
         }
         {
-            snprintf(name, sizeof name, "radix_hist_p%zu", k + 1);
-            KernelTimer t(ctx, name, st, 8 * n_rows);
-            launch_pass_kernel((int)k, true, false, n_chunks, st, (const long long*)cur_keys, nullptr, 0, c_off, c_len, hist, nullptr, nullptr, pp.cfg);
+            snprintf(name, sizeof name, run_if ? "radix_hist_p%zu_standby" : "radix_hist_p%zu", k + 1);
+            KernelTimer t(ctx, name, st, run_if ? 0 : 8 * n_rows);
+            launch_pass_kernel((int)k, true, false, n_chunks, st, (const long long*)cur_keys, nullptr, 0, c_off, c_len, hist, nullptr, nullptr, pp.cfg, run_if);
         }
-        GOLAP_TRY(flat_scan(ctx, st, hist, (uint32_t)(L + 1), bsums));
+        GOLAP_TRY(flat_scan(ctx, st, hist, (uint32_t)(L + 1), bsums, run_if));
         const bool last = k + 1 == np;
         const uint64_t out_keys = last ? buf.final_keys : buf.tmp_keys[k & 1];
         const uint64_t out_rids = last ? buf.final_rids : buf.tmp_rids[k & 1];
         {
-            snprintf(name, sizeof name, "radix_scatter_p%zu", k + 1);
-            KernelTimer t(ctx, name, st, (cur_rids ? 12 : 8) * n_rows + 12 * n_rows);
-            launch_pass_kernel((int)k, false, use_wc_scatter(pp.cfg.F, pp.G > 1), n_chunks, st, (const long long*)cur_keys, (const uint32_t*)cur_rids, rid_base,
-                               c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg);
+            snprintf(name, sizeof name, run_if ? "radix_scatter_p%zu_standby" : "radix_scatter_p%zu", k + 1);
+            KernelTimer t(ctx, name, st, run_if ? 0 : (cur_rids ? 12 : 8) * n_rows + 12 * n_rows);
+            launch_pass_kernel((int)k, false, run_if ? true : use_wc_scatter(pp.cfg.F, pp.G > 1), n_chunks, st, (const long long*)cur_keys,
+                               (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg, run_if);
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
         cur_keys = out_keys;
@@ -1270,6 +1419,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     res.stride = prev_S;
     res.keys = (const long long*)cur_keys;
     res.rids = (const uint32_t*)cur_rids;
+    res.positions = final_rows(plan, n_rows, segs != nullptr);
     return GOLAP_OK;
 }
 
@@ -1280,9 +1430,11 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
+    {
+        const void* wcs[] = {(const void*)k_scatter_wc<1, false>, (const void*)k_scatter_wc<2, false>, (const void*)k_scatter_wc<3, false>,
+                             (const void*)k_scatter_wc<2, true>};
+        for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
+    }
     done = true;
     return GOLAP_OK;
 }
@@ -1291,8 +1443,11 @@ static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint
     const uint64_t nmax = std::max(n_build, n_probe);
     const size_t np = plan.passes.size();
     uint64_t bytes = 0;
-    bytes += round_up(n_build * 8, 256) + round_up(n_build * 4, 256);   // build final
-    bytes += round_up(n_probe * 8, 256) + round_up(n_probe * 4, 256);   // probe final
+    const uint64_t fb = final_rows(plan, n_build, has_segs), fp = final_rows(plan, n_probe, has_segs);
+    bytes += round_up(fb * 8, 256) + round_up(fb * 4, 256);   // build final (slot-padded when the last pass skips its histogram)
+    bytes += round_up(fp * 8, 256) + round_up(fp * 4, 256);   // probe final
+    if (use_fast_last_pass(plan, has_segs))
+        bytes += 2 * (2 * round_up((uint64_t)plan.passes[1].G * plan.passes[1].cfg.F * 4, 256) + 2 * round_up((uint64_t)(plan.passes[1].G + 1) * 4, 256) + 1024);
     const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
     bytes += n_tmp * (round_up(nmax * 8, 256) + round_up(nmax * 4, 256));
     bytes += side_small_bytes(plan, n_build, n_src, has_segs) + side_small_bytes(plan, n_probe, n_src, has_segs);
@@ -1303,13 +1458,13 @@ static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint
 // shared tail: both sides partitioned -> LDS join
 static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, const SideResult& b, const SideResult& p, uint64_t n_build,
                                uint64_t n_probe, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, int32_t join_type = 0) {
-    JoinSide B{b.keys, b.rids, b.off, b.stride}, P{p.keys, p.rids, p.off, p.stride};
+    JoinSide B{b.keys, b.rids, b.off, b.stride, b.alt_start, b.alt_len, b.flag}, P{p.keys, p.rids, p.off, p.stride, p.alt_start, p.alt_len, p.flag};
     uint32_t* probe_hit = nullptr;
     if (join_type & 2) {   // Right / Full: bitmap over probe positions for the (rare) multi-chunk sub-partitions
-        const uint64_t words = ceil_div(std::max<uint64_t>(1, n_probe), 32) + 1;
+        const uint64_t words = ceil_div(std::max<uint64_t>(1, std::max(n_probe, p.positions)), 32) + 1;
         probe_hit = (uint32_t*)ws_take(ctx, words * 4);
         if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (probe bitmap)");
-        GOLAP_HIP_TRY(ctx, hipMemsetAsync(probe_hit, 0, words * 4, st));
+        GOLAP_TRY(zero_async(ctx, st, (void*)(probe_hit), words * 4));
     }
     KernelTimer t(ctx, "join_build_probe_lds", st, 12 * (n_build + n_probe));
     const dim3 grid((uint32_t)plan.n_sub), block(JN_THREADS);
@@ -1331,13 +1486,14 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     JoinPlan plan;
     make_plan(p->n_build, 0, true, plan);
     const size_t np = plan.passes.size();
-    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->n_build, p->n_probe, 1, false) + p->n_probe / 8 + 4096, st));
+    GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->n_build, p->n_probe, 1, false) + final_rows(plan, p->n_probe, false) / 8 + 4096, st));
     const uint64_t nmax = std::max(p->n_build, p->n_probe);
     SideBuffers bb, pb;
-    bb.final_keys = ws_take(ctx, p->n_build * 8);
-    bb.final_rids = ws_take(ctx, p->n_build * 4);
-    pb.final_keys = ws_take(ctx, p->n_probe * 8);
-    pb.final_rids = ws_take(ctx, p->n_probe * 4);
+    const uint64_t fb = final_rows(plan, p->n_build, false), fp = final_rows(plan, p->n_probe, false);
+    bb.final_keys = ws_take(ctx, fb * 8);
+    bb.final_rids = ws_take(ctx, fb * 4);
+    pb.final_keys = ws_take(ctx, fp * 8);
+    pb.final_rids = ws_take(ctx, fp * 4);
     const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
     for (size_t i = 0; i < n_tmp; ++i) {
         bb.tmp_keys[i] = pb.tmp_keys[i] = ws_take(ctx, nmax * 8);
@@ -1367,7 +1523,7 @@ static int32_t broadcast_hash_join(golap_ctx* ctx, const golap_join_params* p, h
     uint32_t* next = (uint32_t*)ws_take(ctx, (uint64_t)std::max<uint32_t>(nb, 1) * 4);
     uint8_t* hit = keep_b ? (uint8_t*)ws_take(ctx, std::max<uint32_t>(nb, 1)) : nullptr;
     if (!buckets || !next || (keep_b && !hit)) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
-    if (keep_b) GOLAP_HIP_TRY(ctx, hipMemsetAsync(hit, 0, std::max<uint32_t>(nb, 1), st));
+    if (keep_b) GOLAP_TRY(zero_async(ctx, st, (void*)(hit), std::max<uint32_t>(nb, 1)));
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
     {
         KernelTimer t(ctx, "bcast_build_table", st, 8ull * nb);
@@ -1422,7 +1578,7 @@ int32_t golap_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_joi
     std::lock_guard<std::mutex> lk(ctx->mu);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
-    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_count_ptr, 0, 8, st));
+    GOLAP_TRY(zero_async(ctx, st, (void*)((void*)p->out_count_ptr), 8));
     if (p->join_type < 0 || p->join_type > 3) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad join_type %d", p->join_type);
     if (p->n_build == 0 || p->n_probe == 0) {
         // executor.rs:231-233: nothing to join.  An outer join still keeps the non-empty preserved side.
@@ -1483,7 +1639,7 @@ int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* p, v
     plan.total_bits = pp.bits;
     plan.n_sub = F;
     if (p->n_rows == 0) {
-        GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)p->out_offsets_ptr, 0, (size_t)(F + 1) * 4, st));
+        GOLAP_TRY(zero_async(ctx, st, (void*)((void*)p->out_offsets_ptr), (size_t)(F + 1) * 4));
         return GOLAP_OK;
     }
     GOLAP_TRY(ws_begin(ctx, side_small_bytes(plan, p->n_rows, 1, false) + 4096, st));
@@ -1613,7 +1769,7 @@ static int32_t part_side(golap_ctx* ctx, int32_t which, const golap_partitioned_
 static int32_t part_finish(golap_ctx* ctx, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, hipStream_t st) {
     PartJoinState& S = pjs_of(ctx);
     if (!S.active || !S.done[0] || !S.done[1]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "golap_join_partitioned_finish needs begin + both sides");
-    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)out_count, 0, 8, st));
+    GOLAP_TRY(zero_async(ctx, st, (void*)((void*)out_count), 8));
     S.active = false;
     if (S.rows[0] == 0 || S.rows[1] == 0) return GOLAP_OK;
     GOLAP_TRY(launch_lds_join(ctx, st, S.plan, S.res[0], S.res[1], S.rows[0], S.rows[1], out_pairs, out_count, max_pairs));

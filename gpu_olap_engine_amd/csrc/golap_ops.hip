@@ -388,13 +388,13 @@ int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred,
     std::lock_guard<std::mutex> lk(ctx->mu);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
-    if (n_rows == 0) { GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)out_count_ptr, 0, 8, st)); return GOLAP_OK; }
+    if (n_rows == 0) { GOLAP_TRY(zero_async(ctx, st, (void*)((void*)out_count_ptr), 8)); return GOLAP_OK; }
     const uint32_t n_blocks = (uint32_t)ceil_div(n_rows, FC_ROWS);
     GOLAP_TRY(ws_begin(ctx, (uint64_t)(n_blocks + 1) * 4 + ceil_div(n_blocks + 1, FLAT_SCAN_BLOCK) * 4 + 8192, st));
     uint32_t* counts = (uint32_t*)ws_take(ctx, (uint64_t)(n_blocks + 1) * 4);
     uint32_t* bsums = (uint32_t*)ws_take(ctx, ceil_div(n_blocks + 1, FLAT_SCAN_BLOCK) * 4 + 4);
     if (!counts || !bsums) return fail(ctx, GOLAP_ERR_OOM, "filter workspace exhausted");
-    GOLAP_HIP_TRY(ctx, hipMemsetAsync(counts + n_blocks, 0, 4, st));
+    GOLAP_TRY(zero_async(ctx, st, (void*)(counts + n_blocks), 4));
     {
         KernelTimer t(ctx, "filter_count", st, 8 * n_rows);
         hipLaunchKernelGGL(k_filter_count, dim3(n_blocks), dim3(OP_THREADS), 0, st, (const long long*)column_ptr, (unsigned long long)n_rows, pred->op,
@@ -625,7 +625,7 @@ int32_t golap_verify_pairs(golap_ctx* ctx, uint64_t pairs_ptr, uint64_t n_pairs,
     std::lock_guard<std::mutex> lk(ctx->mu);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
-    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)out_ptr, 0, 32, st));
+    GOLAP_TRY(zero_async(ctx, st, (void*)((void*)out_ptr), 32));
     if (n_pairs == 0) return GOLAP_OK;
     hipLaunchKernelGGL(k_verify_pairs, dim3(stream_grid(ctx, n_pairs, OP_THREADS * 4)), dim3(OP_THREADS), 0, st, (const uint2*)pairs_ptr,
                        (unsigned long long)n_pairs, (const long long*)build_key_ptr, (const long long*)probe_key_ptr, build_rid_base, probe_rid_base,

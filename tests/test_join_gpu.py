@@ -200,6 +200,36 @@ def test_radix_multi_pass_16m(ctx):
     assert me == n and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("env", [{"GOLAP_NOHIST": "0"}, {"GOLAP_SLOT_SIGMAS": "0"}, {"GOLAP_SLOT_SIGMAS": "1"}, {}])
+@pytest.mark.parametrize("jt", [0, 3])
+def test_no_histogram_last_pass_and_its_overflow_fallback(ctx, env, jt):
+    """Two-pass joins skip the second histogram (slots of avg + 6 sigma); GOLAP_SLOT_SIGMAS=0/1 force slot overflows,
+    so the device-side flag must hand over to the stand-by exact pass; GOLAP_NOHIST=0 is the plain exact path."""
+    n = 6_000_000
+    assert ctx.join_plan(n)["bits2"] > 0
+    b = oracle.gen_sm64_mod(61, 0, n, n)              # duplicates + misses on both sides
+    p = oracle.gen_sm64_mod(62, 0, n, n)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        outer_check(ctx, b, p, N.JOIN_RADIX_HASH, jt)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_no_histogram_pass_with_skewed_groups(ctx):
+    """a few heavy keys overflow their slots for real (no test hook): the fallback must kick in on its own."""
+    n = 5_000_000
+    rng = np.random.default_rng(8)
+    b = np.concatenate([oracle.gen_build_keys(0, n, n), np.full(30_000, 123456, np.int64)])
+    p = np.concatenate([oracle.gen_probe_keys(0, n, n), np.full(40, 123456, np.int64), rng.integers(0, n, 1000)])
+    check(ctx, b, p, N.JOIN_RADIX_HASH, max_pairs=8_000_000)
+
+
 @pytest.mark.parametrize("bits", ["8,4,4", "10,6", "8,7"])
 def test_forced_pass_structures(ctx, bits):
     """every pass structure must give the same pairs (GOLAP_PASS_BITS experiment hook)."""
