@@ -340,18 +340,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
 // ---------------------------------------------------------------------------
 // scatter v3 (global first pass, implicit row ids): register-resident big tile.
 // A tile is 512 threads x BT_RPT keys held in registers; buckets are ranked once for the
-// whole tile, then the tile is pushed through a 4096-row LDS window in BT_NWIN rounds, so a
-// bucket's run per tile is BT_NWIN x longer than in v1 for the same LDS (fan-out 512: 24 rows =
+// whole tile, then the tile is pushed through a 4096-row LDS window in 3 rounds, so a
+// bucket's run per tile is 3 x longer than in v1 for the same LDS (fan-out 512: 24 rows =
 // 1.5 key lines instead of 8 rows = half a line).  24 keys/thread keep the kernel at 128 VGPRs
 // (two work-groups per CU).  Measured at 1B rows, fan-out 512: 18.0 -> 13.8 ms.  No row-id array is read (join_kernels.cuh:75:
 // row id = position), so the registers go to keys.
 // ---------------------------------------------------------------------------
-constexpr int BT_RPT = 24;
-constexpr int BT_NWIN = 3;
-constexpr int BT_TILE = PT_THREADS * BT_RPT;   // 16384 rows
-constexpr int BT_WIN = BT_TILE / BT_NWIN;      // 4096 rows staged at a time
+constexpr int BT_WIN = 4096;                   // rows staged in LDS at a time
 
-template <int PASS_TAG>
+template <int PASS_TAG, int BT_RPT>
 __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* __restrict__ in_keys, uint32_t rid_base,
                                                             const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
                                                             const uint32_t* __restrict__ scanned, long long* __restrict__ out_keys,
@@ -363,6 +360,7 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
     uint32_t* s_start = s_cnt + cfg.F;
     uint32_t* s_gpos = s_start + cfg.F;
     uint32_t* s_w = s_gpos + cfg.F;
+    constexpr int BT_TILE = PT_THREADS * BT_RPT;   // rows per register-resident tile
 
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
@@ -1270,8 +1268,16 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
     if (hist) {
         hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if);
     } else if (!wc && use_big_scatter(cfg.F, false, rids != nullptr) && TAG == 1) {
-        hipLaunchKernelGGL(k_scatter_big<1>, dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
-                           out_keys, out_rids, cfg);
+        const char* e = getenv("GOLAP_BIG_RPT");   // A/B hook
+        if (e && atoi(e) == 20)
+            hipLaunchKernelGGL((k_scatter_big<1, 20>), dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
+                               out_keys, out_rids, cfg);
+        else if (e && atoi(e) == 16)
+            hipLaunchKernelGGL((k_scatter_big<1, 16>), dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
+                               out_keys, out_rids, cfg);
+        else
+            hipLaunchKernelGGL((k_scatter_big<1, 24>), dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
+                               out_keys, out_rids, cfg);
     } else if (wc) {
         hipLaunchKernelGGL((k_scatter_wc<TAG, false>), dim3(n_chunks), dim3(WC_THREADS), scatter_wc_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len,
                            hist_arr, out_keys, out_rids, cfg, FixedArgs{}, run_if);
@@ -1429,7 +1435,9 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
     {
         const void* wcs[] = {(const void*)k_scatter_wc<1, false>, (const void*)k_scatter_wc<2, false>, (const void*)k_scatter_wc<3, false>,
                              (const void*)k_scatter_wc<2, true>};

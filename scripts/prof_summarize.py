@@ -45,12 +45,13 @@ json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 
 # HBM traffic per launch for bench.py's roofline.traffic: FETCH_SIZE x 2 (gfx950 under-count of wide coalesced
 # reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes.  Keyed by the library's profile names.
-NAMES = [("k_scatter_big<1>", "radix_scatter_p1"), ("k_scatter<1>", "radix_scatter_p1"), ("k_scatter_wc<2>", "radix_scatter_p2"),
-         ("k_scatter<2>", "radix_scatter_p2"), ("k_hist<1>", "radix_hist_p1"), ("k_hist<2>", "radix_hist_p2"), ("k_join_lds", "join_build_probe_lds")]
+NAMES = [("k_scatter_big<1", "radix_scatter_p1"), ("k_scatter<1", "radix_scatter_p1"), ("k_scatter_wc<2, true", "radix_scatter_p2"),
+         ("k_scatter_wc<2>", "radix_scatter_p2"), ("k_scatter<2", "radix_scatter_p2"), ("k_hist<1", "radix_hist_p1"), ("k_join_lds<0", "join_build_probe_lds"),
+         ("k_join_lds(", "join_build_probe_lds")]
 traffic = {}
 for k, v in out.items():
     for pat, prof in NAMES:
-        if pat in k and "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+        if pat in k and prof not in traffic and "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
             f, w = v["FETCH_SIZE_KiB_per_launch"] * 1024, v["WRITE_SIZE_KiB_per_launch"] * 1024
             traffic[prof] = {"kernel": k.split("(")[0], "fetch_size_raw_bytes": f, "fetch_bytes_corrected_x2": 2 * f, "write_bytes": w,
                              "hbm_bytes_per_launch": 2 * f + w, "avg_ns": v.get("avg_ns")}
