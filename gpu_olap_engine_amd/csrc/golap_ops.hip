@@ -228,14 +228,31 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
     const unsigned long long lo = (unsigned long long)blockIdx.x * rows_per_block;
     unsigned long long hi = lo + rows_per_block;
     if (hi > n) hi = n;
-    for (unsigned long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t g = (uint32_t)((unsigned long long)keys[i] % n_groups);
-        const double x = VAL_F64 ? vf[i] : (double)vi[i];
-        atomicAdd(&s_sum[g], x);
-        atomicAdd(&s_cnt[g], 1u);
-        if (NEED_MM) {   // MIN / MAX requested by some spec: two more LDS atomics per row
-            __hip_atomic_fetch_min(&s_mn[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_max(&s_mx[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // 8 rows per thread per round, loads unconditional on clamped indices so that all 16 are in flight together
+    // (a conditional load compiles to branch + s_waitcnt vmcnt(0) and serialises them)
+    constexpr int GR = 8;
+    for (unsigned long long base = lo; base < hi; base += (unsigned long long)blockDim.x * GR) {
+        KeyT k[GR];
+        double x[GR];
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+            unsigned long long i = base + (unsigned long long)r * blockDim.x + threadIdx.x;
+            if (i >= hi) i = hi - 1;
+            k[r] = keys[i];
+            x[r] = VAL_F64 ? vf[i] : (double)vi[i];
+        }
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+            const unsigned long long i = base + (unsigned long long)r * blockDim.x + threadIdx.x;
+            if (i < hi) {
+                const uint32_t g = (uint32_t)((unsigned long long)k[r] % n_groups);
+                atomicAdd(&s_sum[g], x[r]);
+                atomicAdd(&s_cnt[g], 1u);
+                if (NEED_MM) {   // MIN / MAX requested by some spec: two more LDS atomics per row
+                    __hip_atomic_fetch_min(&s_mn[g], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(&s_mx[g], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     }
     __syncthreads();
