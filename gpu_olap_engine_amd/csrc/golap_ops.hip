@@ -67,7 +67,8 @@ __global__ __launch_bounds__(OP_THREADS) void k_filter_count(const long long* __
 #pragma unroll
     for (int r = 0; r < FC_RPT; ++r) {
         const unsigned long long i = base + r * OP_THREADS + threadIdx.x;
-        c += (i < n && cmp_i64(op, col[i], lit)) ? 1u : 0u;
+        const long long v = col[i < n ? i : n - 1];   // unconditional (clamped) so that all 16 loads are in flight together
+        c += (i < n && cmp_i64(op, v, lit)) ? 1u : 0u;
     }
     c = wave_reduce_add(c);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(OP_THREADS) void k_filter_write(const long long* __
 #pragma unroll
     for (int r = 0; r < FC_RPT; ++r) {
         const unsigned long long i = base + r * OP_THREADS + threadIdx.x;
-        keep[r] = i < n && cmp_i64(op, col[i], lit);
+        const long long v = col[i < n ? i : n - 1];
+        keep[r] = i < n && cmp_i64(op, v, lit);
         const unsigned long long m = __ballot(keep[r]);
         lp[r] = mbcnt(m);
         if (lane == 0) s_w[r * OP_WAVES + wv] = (uint32_t)__popcll(m);

@@ -206,9 +206,9 @@ def test_no_histogram_last_pass_and_its_overflow_fallback(ctx, env, jt):
     """Two-pass joins skip the second histogram (slots of avg + 6 sigma); GOLAP_SLOT_SIGMAS=0/1 force slot overflows,
     so the device-side flag must hand over to the stand-by exact pass; GOLAP_NOHIST=0 is the plain exact path."""
     n = 6_000_000
-    assert ctx.join_plan(n)["bits2"] > 0
     b = oracle.gen_sm64_mod(61, 0, n, n)              # duplicates + misses on both sides
     p = oracle.gen_sm64_mod(62, 0, n, n)
+    env = dict(env, GOLAP_PASS_BITS="8,6")            # second pass with fan-out 64: the no-histogram form applies (it needs F >= 32)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -227,7 +227,28 @@ def test_no_histogram_pass_with_skewed_groups(ctx):
     rng = np.random.default_rng(8)
     b = np.concatenate([oracle.gen_build_keys(0, n, n), np.full(30_000, 123456, np.int64)])
     p = np.concatenate([oracle.gen_probe_keys(0, n, n), np.full(40, 123456, np.int64), rng.integers(0, n, 1000)])
-    check(ctx, b, p, N.JOIN_RADIX_HASH, max_pairs=8_000_000)
+    os.environ["GOLAP_PASS_BITS"] = "8,6"
+    try:
+        check(ctx, b, p, N.JOIN_RADIX_HASH, max_pairs=8_000_000)
+    finally:
+        del os.environ["GOLAP_PASS_BITS"]
+
+
+def test_no_histogram_pass_is_taken_and_flag_stays_clear(ctx):
+    """stats show the no-histogram form ran (stand-by kernels present, no radix_hist_p2) and verify_pairs agrees at 60M rows."""
+    n = 60_000_000
+    assert ctx.join_plan(n)["bits2"] >= 5
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    ctx.stats_reset()
+    pairs, cnt = ctx.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
+    v = ctx.verify_pairs(pairs, n, bt, pt).cpu().numpy().view(np.uint64)
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    assert "radix_scatter_p2_standby" in st and "radix_hist_p2" not in st
+    assert st["radix_scatter_p2_standby"]["total_ms"] < 0.5          # stand-by launches return at once: the flag stayed clear
+    assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2
 
 
 @pytest.mark.parametrize("bits", ["8,4,4", "10,6", "8,7"])
