@@ -353,7 +353,6 @@ void golap_ctx_destroy(golap_ctx* ctx) {
     ctx->xfer.destroy();
     if (ctx->ws.base) (void)ctx->slabs.release(ctx, ctx->ws.base, ctx->ws.cls);
     ctx->slabs.destroy();
-    for (void* p : ctx->pinned_small) (void)hipHostFree(p);
     if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
     delete ctx;
 }

@@ -117,7 +117,6 @@ struct golap_ctx {
     golap::Workspace ws;
     hipEvent_t ws_done = nullptr;     // last use of the workspace (cross-stream ordering)
     hipStream_t ws_stream = nullptr;
-    std::vector<void*> pinned_small;  // small pinned host staging buffers for table uploads
     std::shared_ptr<void> pjs;        // golap::PartJoinState (golap_join.hip)
 };
 

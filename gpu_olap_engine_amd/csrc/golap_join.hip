@@ -1613,7 +1613,14 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
     memset(out, 0, sizeof *out);
     out->bits1 = plan.passes[0].bits;
     out->bits2 = plan.total_bits - plan.passes[0].bits;
-    out->tile_rows = PT_TILE;
+    out->tile_rows = use_big_scatter(plan.passes[0].cfg.F, false, false) ? PT_THREADS * 24 : PT_TILE;   // first-pass tile (big-tile kernel: 24 keys per thread)
+    {
+        const uint64_t n = std::max<uint64_t>(1, n_build);
+        const uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n, PT_TILE)));
+        out->chunks1 = (uint32_t)ceil_div(n, round_up(ceil_div(n, c1), PT_TILE));
+    }
+    out->slots2 = plan.passes.size() < 2 ? 0 : (use_fast_last_pass(plan, false) ? 1 : slots_for(plan.passes[1].G, n_build));
+    out->no_histogram_last_pass = use_fast_last_pass(plan, false) ? 1 : 0;
     out->table_capacity = JN_CAP;
     out->n_subpartitions = plan.n_sub;
     return GOLAP_OK;

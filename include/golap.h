@@ -329,10 +329,13 @@ int32_t golap_stats_reset(golap_ctx* ctx);
 
 /* Plan the last join used (for DESIGN/bench reporting). */
 typedef struct golap_join_plan {
-    uint32_t bits1, bits2;        /* fan-out bits of pass 1 (>= radix_bits) and pass 2 */
-    uint32_t tile_rows, chunks1, slots2;
+    uint32_t bits1, bits2;        /* fan-out bits of pass 1 (>= radix_bits) and of the later passes together */
+    uint32_t tile_rows;           /* rows per tile of the first scatter pass */
+    uint32_t chunks1;             /* work-groups (chunks of tiles) of the first pass */
+    uint32_t slots2;              /* chunks per group in pass 2 (1 = one work-group per group, the no-histogram form) */
     uint32_t table_capacity;      /* LDS hash-table rows per sub-partition */
     uint64_t n_subpartitions;
+    uint32_t no_histogram_last_pass;   /* 1 when pass 2 writes into pre-provisioned slots */
 } golap_join_plan;
 int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners, golap_join_plan* out);
 

@@ -89,7 +89,8 @@ def test_join_plan_is_host_only(lib):
     for n, (b1, b2) in {500_000: (8, 0), 1_000_000: (9, 0), 100_000_000: (8, 7), 1_000_000_000: (9, 9)}.items():
         assert lib.golap_join_plan_get(None, n, 1, C.byref(p)) == 0
         assert (p.bits1, p.bits2) == (b1, b2), n
-        assert p.n_subpartitions == 1 << (b1 + b2) and p.table_capacity == 4096 and p.tile_rows == 4096
+        assert p.n_subpartitions == 1 << (b1 + b2) and p.table_capacity == 4096 and p.tile_rows in (4096, 12288)
+        assert p.no_histogram_last_pass == (1 if b2 >= 5 else 0) and p.chunks1 >= 1
 
 
 def test_no_device_fails_loudly(lib):
