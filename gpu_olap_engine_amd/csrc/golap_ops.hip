@@ -281,6 +281,190 @@ __global__ __launch_bounds__(OP_THREADS) void k_group_fold(const double* __restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// grouped aggregate for group counts beyond one LDS table: partition, then LDS-aggregate.
+// Global float atomics run at ~24 G adds/s on this chip whatever the schedule (measured: 42 ms per 1B rows), so
+// rows are first range-partitioned by slot / AG_GB (slot = key % n_groups, join_kernels.cuh:230) with the same
+// histogram -> flat scan -> LDS-staged tile scatter scheme as the join (12 B/row: u32 slot + f64 value), after
+// which every bucket holds <= AG_GB consecutive slots and is folded with the LDS pre-aggregation kernel
+// (several work-groups per bucket, partial tables folded in a fixed order: reproducible, no global atomics).
+// ---------------------------------------------------------------------------
+constexpr int AG_THREADS = 512;
+constexpr int AG_WAVES = AG_THREADS / 64;
+constexpr int AG_RPT = 8;
+constexpr int AG_TILE = AG_THREADS * AG_RPT;   // 4096 rows staged in LDS
+constexpr int AG_GB = 2048;                    // slots per bucket (one 56 KiB LDS table)
+constexpr int AG_MAX_B = 1024;                 // buckets (fan-out of the single partition pass)
+
+template <typename KeyT>
+__global__ __launch_bounds__(AG_THREADS) void k_agg_hist(const KeyT* __restrict__ keys, unsigned long long n, uint32_t n_groups, uint32_t chunk_rows,
+                                                         uint32_t S, uint32_t B, uint32_t* __restrict__ hist /*[B][S]*/) {
+    __shared__ uint32_t s_cnt[AG_MAX_B];
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
+    if (lo >= n) return;
+    const unsigned long long hi = lo + chunk_rows < n ? lo + chunk_rows : n;
+    for (uint32_t b = threadIdx.x; b < B; b += AG_THREADS) s_cnt[b] = 0;
+    __syncthreads();
+    for (unsigned long long base = lo; base < hi; base += (unsigned long long)AG_THREADS * 8) {
+        KeyT k[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            unsigned long long i = base + (unsigned long long)r * AG_THREADS + threadIdx.x;
+            k[r] = keys[i < hi ? i : hi - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned long long i = base + (unsigned long long)r * AG_THREADS + threadIdx.x;
+            if (i < hi) atomicAdd(&s_cnt[(uint32_t)((unsigned long long)k[r] % n_groups) / AG_GB], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += AG_THREADS) hist[(size_t)b * S + blockIdx.x] = s_cnt[b];
+}
+
+template <typename KeyT, bool VAL_F64>
+__global__ __launch_bounds__(AG_THREADS) void k_agg_scatter(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
+                                                            uint32_t n_groups, uint32_t chunk_rows, uint32_t S, uint32_t B,
+                                                            const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
+                                                            double* __restrict__ out_val) {
+    __shared__ double s_val[AG_TILE];
+    __shared__ uint32_t s_slot[AG_TILE];
+    __shared__ uint32_t s_cnt[AG_MAX_B], s_start[AG_MAX_B], s_gpos[AG_MAX_B], s_w[AG_WAVES];
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
+    if (lo >= n) return;
+    const unsigned long long hi = lo + chunk_rows < n ? lo + chunk_rows : n;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long* vi = (const long long*)val;
+    const double* vf = (const double*)val;
+    for (uint32_t b = tid; b < B; b += AG_THREADS) s_gpos[b] = scanned[(size_t)b * S + blockIdx.x];
+    for (unsigned long long t0 = lo; t0 < hi; t0 += AG_TILE) {
+        const uint32_t tn = hi - t0 < (unsigned long long)AG_TILE ? (uint32_t)(hi - t0) : (uint32_t)AG_TILE;
+        for (uint32_t b = tid; b < B; b += AG_THREADS) s_cnt[b] = 0;
+        uint32_t slot[AG_RPT], br[AG_RPT];
+        double x[AG_RPT];
+#pragma unroll
+        for (int r = 0; r < AG_RPT; ++r) {   // unconditional loads on clamped indices: all in flight together
+            const uint32_t i = r * AG_THREADS + tid;
+            const unsigned long long gi = t0 + (i < tn ? i : tn - 1);
+            slot[r] = (uint32_t)((unsigned long long)keys[gi] % n_groups);
+            x[r] = VAL_F64 ? vf[gi] : (double)vi[gi];   // executor.rs:521 `as f64`
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < AG_RPT; ++r) {
+            const uint32_t i = r * AG_THREADS + tid;
+            if (i < tn) {
+                const uint32_t b = slot[r] / AG_GB;
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
+            const uint32_t c0 = f0 < B ? s_cnt[f0] : 0u, c1 = f1 < B ? s_cnt[f1] : 0u;
+            const uint32_t inc = wave_inclusive_scan(c0 + c1);
+            if (lane == 63) s_w[wv] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < AG_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            const uint32_t e0 = base + inc - (c0 + c1);
+            if (f0 < B) s_start[f0] = e0;
+            if (f1 < B) s_start[f1] = e0 + c0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < AG_RPT; ++r) {
+            const uint32_t i = r * AG_THREADS + tid;
+            if (i < tn) {
+                const uint32_t pos = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
+                s_slot[pos] = slot[r];
+                s_val[pos] = x[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < AG_RPT; ++r) {
+            const uint32_t i = r * AG_THREADS + tid;
+            if (i < tn) {
+                const uint32_t sl = s_slot[i], b = sl / AG_GB;
+                const uint32_t gp = s_gpos[b] + (i - s_start[b]);
+                out_slot[gp] = sl;
+                out_val[gp] = s_val[i];
+            }
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < B; b += AG_THREADS) s_gpos[b] += s_cnt[b];
+    }
+}
+
+// bucket b = slots [b*AG_GB, (b+1)*AG_GB); work-group (b, w) folds its share of the bucket's rows into an LDS table
+template <bool NEED_MM>
+__global__ __launch_bounds__(AG_THREADS) void k_agg_bucket(const uint32_t* __restrict__ slot, const double* __restrict__ val,
+                                                           const uint32_t* __restrict__ scanned, uint32_t S, uint32_t W,
+                                                           double* __restrict__ slab /*[B*W][4][AG_GB]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double* s_sum = reinterpret_cast<double*>(s_raw);
+    double* s_mn = s_sum + AG_GB;
+    double* s_mx = s_mn + AG_GB;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mx + AG_GB);
+    const uint32_t b = blockIdx.x / W, w = blockIdx.x % W;
+    for (uint32_t g = threadIdx.x; g < (uint32_t)AG_GB; g += AG_THREADS) { s_sum[g] = 0.0; s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; s_cnt[g] = 0; }
+    __syncthreads();
+    const uint32_t o0 = scanned[(size_t)b * S], o1 = scanned[(size_t)(b + 1) * S];
+    const uint32_t share = (o1 - o0 + W - 1) / W;
+    const uint32_t lo = o0 + w * share < o1 ? o0 + w * share : o1;
+    const uint32_t hi = lo + share < o1 ? lo + share : o1;
+    const uint32_t kbase = b * AG_GB;
+    for (uint32_t base = lo; base < hi; base += AG_THREADS * 8) {
+        uint32_t k[8];
+        double x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            uint32_t i = base + r * AG_THREADS + threadIdx.x;
+            if (i >= hi) i = hi - 1;
+            k[r] = slot[i];
+            x[r] = val[i];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t i = base + r * AG_THREADS + threadIdx.x;
+            if (i < hi) {
+                const uint32_t g = k[r] - kbase;
+                atomicAdd(&s_sum[g], x[r]);
+                atomicAdd(&s_cnt[g], 1u);
+                if (NEED_MM) {
+                    __hip_atomic_fetch_min(&s_mn[g], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(&s_mx[g], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* row = slab + (size_t)blockIdx.x * 4 * AG_GB;
+    for (uint32_t g = threadIdx.x; g < (uint32_t)AG_GB; g += AG_THREADS) {
+        row[g] = s_sum[g];
+        row[AG_GB + g] = (double)s_cnt[g];
+        row[2 * AG_GB + g] = s_mn[g];
+        row[3 * AG_GB + g] = s_mx[g];
+    }
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_agg_bucket_fold(const double* __restrict__ slab, uint32_t W, uint32_t n_groups,
+                                                                double* __restrict__ stats4) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        const uint32_t b = g / AG_GB, l = g % AG_GB;
+        double sum = 0.0, cnt = 0.0, mn = GOLAP_F64_MAX, mx = -GOLAP_F64_MAX;
+        for (uint32_t w = 0; w < W; ++w) {   // fixed order: reproducible
+            const double* row = slab + (size_t)(b * W + w) * 4 * AG_GB;
+            sum += row[l]; cnt += row[AG_GB + l];
+            mn = row[2 * AG_GB + l] < mn ? row[2 * AG_GB + l] : mn;
+            mx = row[3 * AG_GB + l] > mx ? row[3 * AG_GB + l] : mx;
+        }
+        stats4[g * 4 + 0] = sum; stats4[g * 4 + 1] = cnt; stats4[g * 4 + 2] = mn; stats4[g * 4 + 3] = mx;
+    }
+}
+
 // large group counts: global table, agent-scope atomics per row ("global merge",
 // aggregate_kernel.rs:6, :84-86).  Sums of integer-valued data are exact; for
 // general doubles the order of the adds is not fixed (documented in DESIGN.md).
@@ -495,6 +679,15 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     const bool grouped = p->group_key_ptr != 0;
     // LDS path when the 28-byte-per-group table fits comfortably (2 work-groups per CU)
     const bool lds_path = grouped && (uint64_t)G * 28 <= 64 * 1024;
+    // beyond one LDS table: partition by slot range, then LDS-aggregate (big inputs only; GOLAP_AGG_PART=0 -> global atomics)
+    const char* part_env = getenv("GOLAP_AGG_PART");
+    const bool part_path = grouped && !lds_path && G <= (uint32_t)AG_GB * AG_MAX_B && p->n_rows >= (1ull << 22) && p->n_rows < 0xFFFFFFF0ull &&
+                           !(part_env && !strcmp(part_env, "0"));
+    const uint32_t pB = part_path ? (uint32_t)ceil_div(G, AG_GB) : 0;
+    const uint32_t pS = part_path ? (uint32_t)std::min<uint64_t>(2048, ceil_div(p->n_rows, AG_TILE)) : 0;
+    const uint32_t p_chunk = part_path ? (uint32_t)round_up(ceil_div(p->n_rows, pS), AG_TILE) : 0;
+    const uint32_t pS2 = part_path ? (uint32_t)ceil_div(p->n_rows, p_chunk) : 0;   // chunks actually used
+    const uint32_t pW = part_path ? std::max<uint32_t>(1, std::min<uint32_t>(8, 2048 / pB)) : 0;
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
     uint32_t lds_grid = 0;
     uint64_t rows_per_block = 0;
@@ -505,12 +698,31 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     const uint32_t red_grid = stream_grid(ctx, p->n_rows, OP_THREADS * 8);
     uint64_t ws = (uint64_t)G * 32 + 8192;
     ws += lds_path ? (uint64_t)lds_grid * 4 * G * 8 : 0;
+    if (part_path)
+        ws += round_up(p->n_rows * 4, 256) + round_up(p->n_rows * 8, 256) + round_up(((uint64_t)pB * pS2 + 1) * 4, 256) +
+              round_up(ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4, 256) + round_up((uint64_t)pB * pW * 4 * AG_GB * 8, 256) + 4096;
     ws += grouped ? 0 : (uint64_t)red_grid * 32;
     GOLAP_TRY(ws_begin(ctx, ws + 4096, st));
     double* stats4 = (double*)ws_take(ctx, (uint64_t)G * 32);
     double* slab = lds_path ? (double*)ws_take(ctx, (uint64_t)lds_grid * 4 * G * 8) : nullptr;
     double* partials = grouped ? nullptr : (double*)ws_take(ctx, (uint64_t)red_grid * 32);
     if (!stats4 || (lds_path && !slab) || (!grouped && !partials)) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted");
+    uint32_t *p_slot = nullptr, *p_hist = nullptr, *p_bsums = nullptr;
+    double *p_val = nullptr, *p_slab = nullptr;
+    if (part_path) {
+        p_slot = (uint32_t*)ws_take(ctx, p->n_rows * 4);
+        p_val = (double*)ws_take(ctx, p->n_rows * 8);
+        p_hist = (uint32_t*)ws_take(ctx, ((uint64_t)pB * pS2 + 1) * 4);
+        p_bsums = (uint32_t*)ws_take(ctx, ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4);
+        p_slab = (double*)ws_take(ctx, (uint64_t)pB * pW * 4 * AG_GB * 8);
+        if (!p_slot || !p_val || !p_hist || !p_bsums || !p_slab) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted (partition buffers)");
+        static bool attr2 = false;
+        if (!attr2) {
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB * 28 + 16));
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB * 28 + 16));
+            attr2 = true;
+        }
+    }
     if (lds_path) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -564,6 +776,37 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
             {
                 KernelTimer t(ctx, "hash_aggregate_fold", st, 0);
                 hipLaunchKernelGGL(k_group_fold, dim3((uint32_t)ceil_div(G, OP_THREADS)), dim3(OP_THREADS), 0, st, slab, lds_grid, G, stats4);
+            }
+        } else if (part_path) {
+            const uint64_t L = (uint64_t)pB * pS2;
+            GOLAP_TRY(zero_async(ctx, st, p_hist, (L + 1) * 4));
+            {
+                KernelTimer t(ctx, "agg_partition_hist", st, key_bytes * p->n_rows);
+                if (p->key_dtype == GOLAP_DT_INT32)
+                    hipLaunchKernelGGL(k_agg_hist<int>, dim3(pS2), dim3(AG_THREADS), 0, st, (const int*)p->group_key_ptr, (unsigned long long)p->n_rows, G,
+                                       p_chunk, pS2, pB, p_hist);
+                else
+                    hipLaunchKernelGGL(k_agg_hist<long long>, dim3(pS2), dim3(AG_THREADS), 0, st, (const long long*)p->group_key_ptr,
+                                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist);
+            }
+            GOLAP_TRY(flat_scan(ctx, st, p_hist, (uint32_t)(L + 1), p_bsums));
+            {
+                KernelTimer t(ctx, "agg_partition_scatter", st, (key_bytes + 8 + 12) * p->n_rows);
+#define GOLAP_AGG_SC(KT, VF)                                                                                                          \
+    hipLaunchKernelGGL((k_agg_scatter<KT, VF>), dim3(pS2), dim3(AG_THREADS), 0, st, (const KT*)p->group_key_ptr, val,                 \
+                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val)
+                if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_SC(int, true); else GOLAP_AGG_SC(int, false); }
+                else { if (vf) GOLAP_AGG_SC(long long, true); else GOLAP_AGG_SC(long long, false); }
+#undef GOLAP_AGG_SC
+            }
+            {
+                KernelTimer t(ctx, "hash_aggregate_lds_buckets", st, 12 * p->n_rows + 12ull * G);
+                if (need_minmax)
+                    hipLaunchKernelGGL(k_agg_bucket<true>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
+                else
+                    hipLaunchKernelGGL(k_agg_bucket<false>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
+                hipLaunchKernelGGL(k_agg_bucket_fold, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, p_slab,
+                                   pW, G, stats4);
             }
         } else {
             hipLaunchKernelGGL(k_group_init, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, stats4, G);

@@ -112,6 +112,32 @@ def test_grouped_aggregate(ctx, key_dtype, G):
         assert (a[0] == 0).all() and (a[1] == 0).all() and (a[2] == np.finfo(np.float64).max).all() and (a[3] == -np.finfo(np.float64).max).all() and (a[4] == 0).all()
 
 
+@pytest.mark.parametrize("key_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("G", [3000, 100_000, 1_000_003])
+def test_grouped_aggregate_partitioned_path(ctx, key_dtype, G):
+    """group counts beyond one LDS table on a big input: partition by slot range, then LDS-aggregate (no global atomics);
+    must equal the oracle and the global-atomic path (GOLAP_AGG_PART=0)."""
+    import os
+    n = 5_000_000
+    keys = oracle.gen_sm64_mod(71, 0, n, G, key_dtype)
+    vals = oracle.gen_sm64_mod(72, 0, n, 4096, np.float64) - 2048.0
+    ok, ost = oracle.group_aggregate(keys.astype(np.int64), vals)
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0)]
+    dk, dv = dev(keys), dev(vals)
+    ctx.stats_reset()
+    out, counts = ctx.aggregate(specs, [dv], group_keys=dk, n_groups=G, want_counts=True)
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    assert "agg_partition_scatter" in ctx.stats()
+    present = counts > 0
+    assert np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
+    os.environ["GOLAP_AGG_PART"] = "0"
+    try:
+        out2 = ctx.aggregate(specs, [dv], group_keys=dk, n_groups=G).cpu().numpy()
+    finally:
+        del os.environ["GOLAP_AGG_PART"]
+    assert np.array_equal(out2, out)
+
+
 def test_grouped_two_value_columns_int_and_float(ctx):
     n, G = 200_000, 300
     keys = oracle.gen_sm64_mod(3, 0, n, G, np.int64)
