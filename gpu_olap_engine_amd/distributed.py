@@ -191,3 +191,45 @@ class ShardedJoin:
         # the received buffers may be released now: every kernel that reads them is already enqueued on this
         # stream, and torch's caching allocator reuses memory in stream order
         return pairs, cnt, xb.n_recv, xp.n_recv
+
+
+class ShardedAggregate:
+    """GROUP BY over row-sharded inputs (SURVEY 8(e) "Aggregate"): every rank pre-aggregates its own rows into the dense
+    [stat][group] table on its GPU (golap_aggregate: LDS pre-aggregation / partition-then-aggregate), then the tables are
+    combined with all-reduce -- SUM for sums and counts, MIN / MAX for extrema; AVG is finalised from the reduced sum and
+    count.  Sums of integer-valued data stay bit-exact under any reduction order."""
+
+    SUM, COUNT, MIN, MAX, AVG = 0, 1, 2, 3, 4
+
+    def __init__(self, local_stats, group=None):
+        """local_stats(values, group_keys, n_groups) -> float64 tensor [4, n_groups] = (sum, count, min, max) of the LOCAL rows."""
+        self.local_stats = local_stats
+        self.group = group
+
+    @staticmethod
+    def hip_local_stats(ctx):
+        def f(values, group_keys, n_groups):
+            return ctx.aggregate([(0, 0), (1, 0), (2, 0), (3, 0)], [values], group_keys=group_keys, n_groups=n_groups)
+        return f
+
+    def aggregate(self, values, group_keys, n_groups, funcs):
+        st = self.local_stats(values, group_keys, n_groups)                 # [4, G] on the local device
+        sc = st[0:2].contiguous()
+        mn = st[2].contiguous()
+        mx = st[3].contiguous()
+        dist.all_reduce(sc, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        out = []
+        for f in funcs:
+            if f == self.SUM:
+                out.append(sc[0])
+            elif f == self.COUNT:
+                out.append(sc[1])
+            elif f == self.MIN:
+                out.append(mn)
+            elif f == self.MAX:
+                out.append(mx)
+            else:                                                            # AVG = sum / count, 0.0 for an empty group (executor.rs:339-345)
+                out.append(torch.where(sc[1] > 0, sc[0] / sc[1].clamp(min=1.0), torch.zeros_like(sc[0])))
+        return torch.stack(out)

@@ -145,3 +145,51 @@ def test_slot_mapping_is_a_bijection():
         for p in range(256):
             assert slots[p] // per == owner_of_partition(p, world) == p % world
     assert shard_range(10, 0, 4) == (0, 2) and shard_range(10, 3, 4) == (6, 10)
+
+
+def _agg_worker(rank, world, port, n, G, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from gpu_olap_engine_amd.distributed import ShardedAggregate, shard_range
+        lo, hi = shard_range(n, rank, world)
+        keys = oracle.gen_sm64_mod(7, lo, hi - lo, G, np.int64)
+        vals = oracle.gen_sm64_mod(8, lo, hi - lo, 1024, np.float64)
+
+        def local_stats(values, group_keys, n_groups):          # oracle-backed stand-in for golap_aggregate
+            ks, st = oracle.group_aggregate(group_keys.numpy(), values.numpy())
+            t = np.zeros((4, n_groups)); t[2] = np.finfo(np.float64).max; t[3] = -np.finfo(np.float64).max
+            t[0, ks], t[1, ks], t[2, ks], t[3, ks] = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+            return torch.from_numpy(t)
+
+        sa = ShardedAggregate(local_stats)
+        out = sa.aggregate(torch.from_numpy(vals), torch.from_numpy(keys), G, [sa.SUM, sa.COUNT, sa.MIN, sa.MAX, sa.AVG])
+        q.put((rank, out.numpy().copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_aggregate_gloo():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    n, G, world = 60_000, 500, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agg_worker, args=(r, world, port, n, G, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ks, st = oracle.group_aggregate(oracle.gen_sm64_mod(7, 0, n, G, np.int64), oracle.gen_sm64_mod(8, 0, n, 1024, np.float64))
+    assert np.array_equal(ks, np.arange(G))
+    for rank, out in res:                                   # every rank holds the full reduced table
+        assert np.array_equal(out[0], st[:, 0]) and np.array_equal(out[1], st[:, 1]) and np.array_equal(out[2], st[:, 2])
+        assert np.array_equal(out[3], st[:, 3]) and np.array_equal(out[4], st[:, 4])
