@@ -473,6 +473,28 @@ def test_join_is_hip_graph_capturable(ctx, strategy):
         assert np.array_equal(canonical(out[:m].cpu().numpy().view(np.uint32)), exp)
 
 
+EDGE_SIZES = [1, 63, 64, 65, 511, 512, 4095, 4096, 4097, 8191, 8192, 8193, 12287, 12288, 12289, 24576, 49153, 131071, 262145]
+
+
+@pytest.mark.parametrize("bits", [None, "8,5", "9,6", "10,5", "8,4,5"])
+def test_tile_and_chunk_boundaries(ctx, bits):
+    """sizes straddling every tile / window / staging boundary of the scatter kernels (4096, 8192, 12288 rows, 16-row lines),
+    under forced pass structures (plain, no-histogram second pass, three passes), inner and full outer, vs the oracle."""
+    rng = np.random.default_rng(hash(bits) & 0xFFFF)
+    if bits:
+        os.environ["GOLAP_PASS_BITS"] = bits
+    try:
+        for trial in range(len(EDGE_SIZES)):
+            nb = EDGE_SIZES[trial]
+            npr = EDGE_SIZES[(trial * 7 + 3) % len(EDGE_SIZES)]
+            span = max(4, (nb + npr) // 3)
+            b = rng.integers(-span, span, nb).astype(np.int64)
+            p = rng.integers(-span, span, npr).astype(np.int64)
+            outer_check(ctx, b, p, N.JOIN_RADIX_HASH, N.JT_FULL if trial % 2 else N.JT_INNER)
+    finally:
+        os.environ.pop("GOLAP_PASS_BITS", None)
+
+
 def test_sort_merge_unsupported(ctx):
     from gpu_olap_engine_amd.engine import GolapError
     t = torch.zeros(4, dtype=torch.int64, device="cuda")
