@@ -7,16 +7,20 @@
 //   build           join_kernels.cuh:80-111  (chained table, head swap by atomic exchange)
 //   probe           join_kernels.cuh:115-166 (walk chain, full-key compare, emit (build_rid, probe_rid))
 // What is new (MI355X-first, none of it is in the reference):
-//   * the per-row global atomicAdd of :72 is replaced by histogram -> flat exclusive
-//     scan -> LDS-staged scatter (rows are regrouped by bucket inside a 4096-row LDS
-//     tile, then written as contiguous runs), one work-group per chunk of tiles so
-//     the frontier cache lines of every bucket are completed by the same CU / L2;
-//   * partitioning is applied repeatedly (radix_shift, :53, is the hook the reference
-//     leaves for that) until a sub-partition's build side fits a 4096-row LDS table;
-//   * build/probe run on LDS tables (ds atomics), matches are counted first, the
-//     output range is reserved with ONE global atomic per work-group batch and the
-//     pairs are written with wavefront ballot/prefix compaction -- not one global
-//     atomic per match (:155).
+//   * the per-row global atomicAdd of :72 is replaced by histogram -> flat exclusive scan -> LDS-staged
+//     scatter; three scatter kernels, chosen per pass:
+//       k_scatter      4096-row LDS tile, rows regrouped by bucket, contiguous runs       (small fan-outs)
+//       k_scatter_big  register-resident 12288-row tile pushed through the LDS window     (global first pass)
+//       k_scatter_wc   line-aligned write combining: per-bucket carries in LDS, every     (local passes)
+//                      128-byte key line written once, whole, by one 16-lane group
+//   * partitioning is applied repeatedly (radix_shift, :53, is the hook the reference leaves for that)
+//     until a sub-partition's build side fits a 4096-row LDS table; the last of two passes needs no
+//     histogram (one work-group per group, slot-provisioned sub-partitions, device-side overflow fallback);
+//   * build/probe run on LDS tables (ds atomics), matches are counted first, the output range is
+//     reserved with ONE global atomic per work-group batch and the pairs are written with wavefront
+//     ballot/prefix compaction -- not one global atomic per match (:155); Left/Right/Full variants;
+//   * tile loads are unconditional on clamped indices (a conditional load costs a branch + vmcnt(0)) and
+//     barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier), so stores and prefetches stay in flight.
 #include "golap_device.h"
 #include "golap_internal.h"
 
