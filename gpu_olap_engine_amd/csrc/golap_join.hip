@@ -350,21 +350,25 @@ __global__ __launch_bounds__(PT_THREADS) void k_scatter(const long long* __restr
 // (two work-groups per CU).  Measured at 1B rows, fan-out 512: 18.0 -> 13.8 ms.  No row-id array is read (join_kernels.cuh:75:
 // row id = position), so the registers go to keys.
 // ---------------------------------------------------------------------------
-constexpr int BT_WIN = 4096;                   // rows staged in LDS at a time
+constexpr int BT_WIN = 4096;                   // rows staged in LDS at a time (default instantiation)
 
-template <int PASS_TAG, int BT_RPT>
-__global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* __restrict__ in_keys, uint32_t rid_base,
+// NT threads x BT_RPT keys per tile, WIN-row LDS window, WPE waves per SIMD (register budget 512 / WPE);
+// PF: the next tile's keys are loaded into a second register set while the current tile drains through LDS.
+template <int PASS_TAG, int BT_RPT, int NT = PT_THREADS, int WIN = BT_WIN, int WPE = 4, bool PF = false, int WU = 8>
+__global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __restrict__ in_keys, uint32_t rid_base,
                                                             const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
                                                             const uint32_t* __restrict__ scanned, long long* __restrict__ out_keys,
                                                             uint32_t* __restrict__ out_rids, PassCfg cfg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [BT_WIN]
-    uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + BT_WIN * 8);      // [BT_WIN]
-    uint32_t* s_cnt = s_rids + BT_WIN;
+    long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [WIN]
+    uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + WIN * 8);         // [WIN]
+    uint32_t* s_cnt = s_rids + WIN;
     uint32_t* s_start = s_cnt + cfg.F;
     uint32_t* s_gpos = s_start + cfg.F;
     uint32_t* s_w = s_gpos + cfg.F;
-    constexpr int BT_TILE = PT_THREADS * BT_RPT;   // rows per register-resident tile
+    constexpr int BT_TILE = NT * BT_RPT;   // rows per register-resident tile
+    constexpr int NW = NT / 64;
+    static_assert(BT_TILE <= 65536, "rank is packed into 16 bits");
 
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
@@ -374,27 +378,44 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
     const uint32_t F = cfg.F;
     {
         const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
-        for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] = scanned[((size_t)g * F + f) * cfg.S + s];
+        for (uint32_t f = tid; f < F; f += NT) s_gpos[f] = scanned[((size_t)g * F + f) * cfg.S + s];
+    }
+    long long key[BT_RPT];
+    long long nxt[PF ? BT_RPT : 1];
+    if (PF) {
+#pragma unroll
+        for (int r = 0; r < BT_RPT; ++r) {
+            const uint32_t i = r * NT + tid;
+            key[r] = NT_LOAD(&in_keys[off + (i < len ? i : len - 1)]);
+        }
     }
     for (uint32_t t0 = 0; t0 < len; t0 += BT_TILE) {
         const uint32_t tn = len - t0 < (uint32_t)BT_TILE ? len - t0 : (uint32_t)BT_TILE;
         const uint32_t rbase = off + t0;
-        for (uint32_t f = tid; f < F; f += PT_THREADS) s_cnt[f] = 0;
-        long long key[BT_RPT];
+        for (uint32_t f = tid; f < F; f += NT) s_cnt[f] = 0;
         uint32_t br[BT_RPT];
+        if (!PF) {
 #pragma unroll
-        for (int r = 0; r < BT_RPT; ++r) {   // unconditional, clamped: all 24 loads in flight together
-            const uint32_t i = r * PT_THREADS + tid;
-            key[r] = NT_LOAD(&in_keys[rbase + (i < tn ? i : tn - 1)]);
+            for (int r = 0; r < BT_RPT; ++r) {   // unconditional, clamped: all loads in flight together
+                const uint32_t i = r * NT + tid;
+                key[r] = NT_LOAD(&in_keys[rbase + (i < tn ? i : tn - 1)]);
+            }
         }
         lds_barrier();
 #pragma unroll
         for (int r = 0; r < BT_RPT; ++r) {
-            const uint32_t i = r * PT_THREADS + tid;
+            const uint32_t i = r * NT + tid;
             br[r] = 0xFFFFFFFFu;
             if (i < tn) {
                 const uint32_t b = bucket_of(hash_int64(key[r]), cfg);
-                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 16384
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 65536
+            }
+        }
+        if (PF) {   // next tile (clamped into the chunk: the last tile re-reads valid rows it then ignores)
+#pragma unroll
+            for (int r = 0; r < BT_RPT; ++r) {
+                const uint32_t i = t0 + BT_TILE + r * NT + tid;
+                nxt[r] = NT_LOAD(&in_keys[off + (i < len ? i : len - 1)]);
             }
         }
         lds_barrier();
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
             lds_barrier();
             uint32_t base = 0;
 #pragma unroll
-            for (int i = 0; i < PT_WAVES; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            for (int i = 0; i < NW; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
             const uint32_t e0 = base + inc - (c0 + c1);
             if (f0 < F) s_start[f0] = e0;
             if (f1 < F) s_start[f1] = e0 + c0;
@@ -416,22 +437,22 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
 #pragma unroll
         for (int r = 0; r < BT_RPT; ++r)
             if (br[r] != 0xFFFFFFFFu) br[r] = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
-        for (uint32_t w0 = 0; w0 < tn; w0 += BT_WIN) {
+        for (uint32_t w0 = 0; w0 < tn; w0 += WIN) {
 #pragma unroll
             for (int r = 0; r < BT_RPT; ++r) {
                 {
                     const uint32_t pos = br[r] - w0;   // invalid rows (0xFFFFFFFF) and rows of other windows fall outside
-                    if (pos < (uint32_t)BT_WIN) {
+                    if (pos < (uint32_t)WIN) {
                         s_keys[pos] = key[r];
-                        s_rids[pos] = rid_base + rbase + r * PT_THREADS + tid;          // join_kernels.cuh:75
+                        s_rids[pos] = rid_base + rbase + r * NT + tid;          // join_kernels.cuh:75
                     }
                 }
             }
             lds_barrier();
-            const uint32_t wn = tn - w0 < (uint32_t)BT_WIN ? tn - w0 : (uint32_t)BT_WIN;
-#pragma unroll
-            for (int j = 0; j < BT_WIN / PT_THREADS; ++j) {
-                const uint32_t i = j * PT_THREADS + tid;
+            const uint32_t wn = tn - w0 < (uint32_t)WIN ? tn - w0 : (uint32_t)WIN;
+#pragma unroll WU
+            for (int j = 0; j < WIN / NT; ++j) {
+                const uint32_t i = j * NT + tid;
                 if (i < wn) {
                     const long long k = s_keys[i];
                     const uint32_t b = bucket_of(hash_int64(k), cfg);
@@ -442,7 +463,11 @@ __global__ __launch_bounds__(PT_THREADS, 4) void k_scatter_big(const long long* 
             }
             lds_barrier();
         }
-        for (uint32_t f = tid; f < F; f += PT_THREADS) s_gpos[f] += s_cnt[f];
+        for (uint32_t f = tid; f < F; f += NT) s_gpos[f] += s_cnt[f];
+        if (PF) {
+#pragma unroll
+            for (int r = 0; r < BT_RPT; ++r) key[r] = nxt[r];
+        }
     }
 }
 
@@ -1171,6 +1196,18 @@ static uint32_t slots_for(uint32_t G, uint64_t n_rows) {
     return (uint32_t)std::max<uint64_t>(1, std::min(by_wg, by_rows));
 }
 
+// uniform chunks of the global first pass: <= 2048 work-groups; once the input is large enough, chunks of at least four
+// 24576-row tiles so that the 1024-thread big-tile scatter applies (launch_hist_scatter)
+static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) {
+    const uint64_t n = std::max<uint64_t>(1, n_rows);
+    uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n, PT_TILE)));
+    const uint64_t big = n / (4 * 24576);
+    if (big >= 512) c1 = std::min<uint64_t>(2048, big);
+    const uint32_t chunk_rows = (uint32_t)round_up(ceil_div(n, c1), PT_TILE);
+    if (chunk_rows_out) *chunk_rows_out = chunk_rows;
+    return (uint32_t)std::max<uint64_t>(1, ceil_div(n, chunk_rows));
+}
+
 static void make_plan(uint64_t n_build, uint32_t owners_log2, bool first_pass_is_reference_partition, JoinPlan& plan) {
     plan.passes.clear();
     uint32_t need = bits_needed(n_build);
@@ -1253,7 +1290,7 @@ static bool use_wc_scatter(uint32_t F, bool local_pass) {
     return local_pass && F >= 32;
 }
 
-static size_t scatter_big_lds_bytes(uint32_t F) { return (size_t)BT_WIN * 12 + (size_t)F * 12 + PT_WAVES * 4 + 16; }
+static size_t scatter_big_lds_bytes(uint32_t F, uint32_t win = BT_WIN, uint32_t nt = PT_THREADS) { return (size_t)win * 12 + (size_t)F * 12 + (nt / 64) * 4 + 16; }
 
 // big-tile scatter: global first pass with implicit row ids and a fan-out whose v1 runs would be < 1 line
 static bool use_big_scatter(uint32_t F, bool local_pass, bool has_rids) {
@@ -1268,20 +1305,40 @@ static bool use_big_scatter(uint32_t F, bool local_pass, bool has_rids) {
 template <int TAG>
 static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids, uint32_t rid_base,
                                 const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys, uint32_t* out_rids,
-                                const PassCfg& cfg, const uint32_t* run_if) {
+                                const PassCfg& cfg, const uint32_t* run_if, uint64_t n_rows) {
     if (hist) {
         hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if);
     } else if (!wc && use_big_scatter(cfg.F, false, rids != nullptr) && TAG == 1) {
-        const char* e = getenv("GOLAP_BIG_RPT");   // A/B hook
-        if (e && atoi(e) == 20)
-            hipLaunchKernelGGL((k_scatter_big<1, 20>), dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
-                               out_keys, out_rids, cfg);
-        else if (e && atoi(e) == 16)
-            hipLaunchKernelGGL((k_scatter_big<1, 16>), dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
-                               out_keys, out_rids, cfg);
-        else
-            hipLaunchKernelGGL((k_scatter_big<1, 24>), dim3(n_chunks), dim3(PT_THREADS), scatter_big_lds_bytes(cfg.F), st, keys, rid_base, c_off, c_len, hist_arr,
-                               out_keys, out_rids, cfg);
+        const char* e = getenv("GOLAP_BIG_RPT");   // A/B hook: "<variant>"
+        // default: 1024 threads x 24 keys (24576-row tile, one work-group per CU) once there are enough chunks of several
+        // tiles to give every CU a few; the 512-thread tile (two work-groups per CU) for mid-sized inputs
+        const int v = e ? atoi(e) : (n_chunks >= 512 && n_rows / n_chunks >= 4 * 24576 ? 1224 : 24);
+#define GOLAP_BIG(RPT, NT, WIN, WPE, PF, ...)                                                                                             \
+    hipLaunchKernelGGL((k_scatter_big<1, RPT, NT, WIN, WPE, PF, ##__VA_ARGS__>), dim3(n_chunks), dim3(NT), scatter_big_lds_bytes(cfg.F, WIN, NT), st, keys, \
+                       rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg)
+        switch (v) {
+            case 20: GOLAP_BIG(20, 512, 4096, 4, false); break;
+            case 16: GOLAP_BIG(16, 512, 4096, 4, false); break;
+            case 1016: GOLAP_BIG(16, 1024, 8192, 4, true); break;    // 16384-row tile, 1 WG/CU, prefetch
+            case 1116: GOLAP_BIG(16, 1024, 8192, 4, false); break;
+            case 1024: GOLAP_BIG(24, 1024, 8192, 4, false); break;   // 24576-row tile
+            case 1020: GOLAP_BIG(20, 1024, 8192, 4, false); break;
+            case 768: GOLAP_BIG(16, 768, 6144, 6, false); break;     // 12288-row tile, 80 VGPRs, 2 WG/CU
+            case 640: GOLAP_BIG(20, 640, 5120, 5, false); break;     // 12800-row tile, 96 VGPRs
+            case 1118: GOLAP_BIG(18, 1024, 9216, 4, false); break;   // 18432-row tile, two window rounds
+            case 1120: GOLAP_BIG(20, 1024, 10240, 4, false, 2); break;
+            case 1220: GOLAP_BIG(20, 1024, 10240, 4, false, 5); break;
+            case 1124: GOLAP_BIG(24, 1024, 8192, 4, false, 2); break;
+            case 1224: GOLAP_BIG(24, 1024, 12288, 4, false, 3); break;
+            case 1216: GOLAP_BIG(16, 1024, 8192, 4, false, 4); break;
+            case 1316: GOLAP_BIG(16, 1024, 8192, 4, false, 2); break;
+            case 548: GOLAP_BIG(48, 512, 8192, 2, false); break;     // 24576-row tile, 256 VGPRs, 1 WG/CU
+            case 532: GOLAP_BIG(32, 512, 8192, 2, true); break;      // 16384-row tile + prefetch
+            case 248: GOLAP_BIG(48, 256, 4096, 2, false); break;     // 12288-row tile, 256 VGPRs, 2 WG/CU
+            case 232: GOLAP_BIG(32, 256, 4096, 2, true); break;      // 8192-row tile + prefetch, 2 WG/CU
+            default: GOLAP_BIG(24, 512, 4096, 4, false); break;
+        }
+#undef GOLAP_BIG
     } else if (wc) {
         hipLaunchKernelGGL((k_scatter_wc<TAG, false>), dim3(n_chunks), dim3(WC_THREADS), scatter_wc_lds_bytes(cfg.F), st, keys, rids, rid_base, c_off, c_len,
                            hist_arr, out_keys, out_rids, cfg, FixedArgs{}, run_if);
@@ -1293,11 +1350,11 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
 
 static void launch_pass_kernel(int tag, bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids,
                                uint32_t rid_base, const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys,
-                               uint32_t* out_rids, const PassCfg& cfg, const uint32_t* run_if = nullptr) {
+                               uint32_t* out_rids, const PassCfg& cfg, const uint32_t* run_if = nullptr, uint64_t n_rows = 0) {
     switch (tag) {
-        case 0: launch_hist_scatter<1>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if); break;
-        case 1: launch_hist_scatter<2>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if); break;
-        default: launch_hist_scatter<3>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if); break;
+        case 0: launch_hist_scatter<1>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows); break;
+        case 1: launch_hist_scatter<2>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows); break;
+        default: launch_hist_scatter<3>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows); break;
     }
 }
 
@@ -1373,9 +1430,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         }
         if (k == 0 && !segs) {
             // single group: uniform chunks
-            uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(std::max<uint64_t>(1, n_rows), PT_TILE)));
-            chunk_rows = (uint32_t)round_up(ceil_div(std::max<uint64_t>(1, n_rows), c1), PT_TILE);
-            S = (uint32_t)std::max<uint64_t>(1, ceil_div(std::max<uint64_t>(1, n_rows), chunk_rows));
+            S = first_pass_chunks(n_rows, &chunk_rows);
         } else if (k == 0) {
             uint32_t cps = std::max<uint32_t>(1, slots_for(pp.G * segs->n_src, n_rows));
             S = segs->n_src * cps;
@@ -1416,7 +1471,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             snprintf(name, sizeof name, run_if ? "radix_scatter_p%zu_standby" : "radix_scatter_p%zu", k + 1);
             KernelTimer t(ctx, name, st, run_if ? 0 : (cur_rids ? 12 : 8) * n_rows + 12 * n_rows);
             launch_pass_kernel((int)k, false, run_if ? true : use_wc_scatter(pp.cfg.F, pp.G > 1), n_chunks, st, (const long long*)cur_keys,
-                               (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg, run_if);
+                               (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg, run_if, n_rows);
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
         cur_keys = out_keys;
@@ -1439,9 +1494,30 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
-    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_big_lds_bytes(PT_MAX_F)));
+#define GOLAP_BIG_ATTR(RPT, NT, WIN, WPE, PF, ...)                                                                              \
+    GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_big<1, RPT, NT, WIN, WPE, PF, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)scatter_big_lds_bytes(PT_MAX_F, WIN, NT)))
+    GOLAP_BIG_ATTR(24, 512, 4096, 4, false);
+    GOLAP_BIG_ATTR(20, 512, 4096, 4, false);
+    GOLAP_BIG_ATTR(16, 512, 4096, 4, false);
+    GOLAP_BIG_ATTR(16, 1024, 8192, 4, true);
+    GOLAP_BIG_ATTR(16, 1024, 8192, 4, false);
+    GOLAP_BIG_ATTR(24, 1024, 8192, 4, false);
+    GOLAP_BIG_ATTR(20, 1024, 8192, 4, false);
+    GOLAP_BIG_ATTR(16, 768, 6144, 6, false);
+    GOLAP_BIG_ATTR(20, 640, 5120, 5, false);
+    GOLAP_BIG_ATTR(18, 1024, 9216, 4, false);
+    GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 2);
+    GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 5);
+    GOLAP_BIG_ATTR(24, 1024, 8192, 4, false, 2);
+    GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3);
+    GOLAP_BIG_ATTR(16, 1024, 8192, 4, false, 4);
+    GOLAP_BIG_ATTR(16, 1024, 8192, 4, false, 2);
+    GOLAP_BIG_ATTR(48, 512, 8192, 2, false);
+    GOLAP_BIG_ATTR(32, 512, 8192, 2, true);
+    GOLAP_BIG_ATTR(48, 256, 4096, 2, false);
+    GOLAP_BIG_ATTR(32, 256, 4096, 2, true);
+#undef GOLAP_BIG_ATTR
     {
         const void* wcs[] = {(const void*)k_scatter_wc<1, false>, (const void*)k_scatter_wc<2, false>, (const void*)k_scatter_wc<3, false>,
                              (const void*)k_scatter_wc<2, true>};
@@ -1617,12 +1693,10 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
     memset(out, 0, sizeof *out);
     out->bits1 = plan.passes[0].bits;
     out->bits2 = plan.total_bits - plan.passes[0].bits;
-    out->tile_rows = use_big_scatter(plan.passes[0].cfg.F, false, false) ? PT_THREADS * 24 : PT_TILE;   // first-pass tile (big-tile kernel: 24 keys per thread)
-    {
-        const uint64_t n = std::max<uint64_t>(1, n_build);
-        const uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n, PT_TILE)));
-        out->chunks1 = (uint32_t)ceil_div(n, round_up(ceil_div(n, c1), PT_TILE));
-    }
+    out->chunks1 = first_pass_chunks(n_build, nullptr);
+    // first-pass tile: big-tile kernel = 24 keys per thread, 1024 threads for large inputs (launch_hist_scatter)
+    out->tile_rows = !use_big_scatter(plan.passes[0].cfg.F, false, false) ? PT_TILE
+                     : (out->chunks1 >= 512 && n_build / out->chunks1 >= 4 * 24576 ? 1024 * 24 : PT_THREADS * 24);
     out->slots2 = plan.passes.size() < 2 ? 0 : (use_fast_last_pass(plan, false) ? 1 : slots_for(plan.passes[1].G, n_build));
     out->no_histogram_last_pass = use_fast_last_pass(plan, false) ? 1 : 0;
     out->table_capacity = JN_CAP;
