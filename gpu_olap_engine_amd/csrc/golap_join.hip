@@ -76,18 +76,39 @@ __global__ void k_setup_uniform(uint32_t n, uint32_t chunk_rows, uint32_t n_chun
     chunk_len[c] = len;
 }
 
-// groups of this pass = (group, bucket) pairs of the previous pass: group g spans
-// [prev[g*prev_stride], prev[(g+1)*prev_stride]) in the previous pass's output.
+// Groups of a pass = buckets of the previous pass.  Two layouts exist for them:
+//   exact    group g spans [scanned[g*stride], scanned[(g+1)*stride]) of the previous output (histogram + scan path);
+//   reserved group g spans [g*cap, g*cap + min(cursor[g], cap)): the previous pass reserved its output ranges with
+//            per-tile atomics on `cursor` instead of a histogram (k_scatter_big<.., RESERVE>); valid while *flag == 0.
+struct GroupSrc {
+    const uint32_t* scanned;
+    uint32_t stride;
+    const uint32_t* cursor;   // null: exact layout only
+    uint32_t cap;
+    const uint32_t* flag;     // set when a reserved range overflowed: the exact path has redone the pass
+};
+
+__device__ __forceinline__ void group_extent(const GroupSrc& gs, uint32_t g, uint32_t& start, uint32_t& len) {
+    if (gs.cursor && *gs.flag == 0) {
+        const uint32_t c = gs.cursor[g];
+        start = g * gs.cap;
+        len = c < gs.cap ? c : gs.cap;
+    } else {
+        start = gs.scanned[(size_t)g * gs.stride];
+        len = gs.scanned[(size_t)(g + 1) * gs.stride] - start;
+    }
+}
+
 // `run_if` (here and on the other exact-path kernels): when non-null the launch is a no-op unless *run_if != 0 --
 // the device-side switch that lets the histogram path stand by behind the no-histogram fast path.
-__global__ void k_setup_from_scan(const uint32_t* __restrict__ prev, uint32_t prev_stride, uint32_t n_groups, uint32_t S,
-                                  uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ run_if = nullptr) {
+__global__ void k_setup_from_scan(GroupSrc gs, uint32_t n_groups, uint32_t S, uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_len,
+                                  const uint32_t* __restrict__ run_if = nullptr) {
     if (run_if && *run_if == 0) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_groups * S) return;
     uint32_t g = i / S, s = i % S;
-    uint32_t start = prev[(size_t)g * prev_stride], end = prev[(size_t)(g + 1) * prev_stride];
-    uint32_t len = end - start;
+    uint32_t start, len;
+    group_extent(gs, g, start, len);
     uint32_t cr = (len + S - 1) / S;
     cr = (cr + PT_TILE - 1) / PT_TILE * PT_TILE;
     unsigned long long o = (unsigned long long)s * cr;
@@ -354,11 +375,24 @@ constexpr int BT_WIN = 4096;                   // rows staged in LDS at a time (
 
 // NT threads x BT_RPT keys per tile, WIN-row LDS window, WPE waves per SIMD (register budget 512 / WPE);
 // PF: the next tile's keys are loaded into a second register set while the current tile drains through LDS.
-template <int PASS_TAG, int BT_RPT, int NT = PT_THREADS, int WIN = BT_WIN, int WPE = 4, bool PF = false, int WU = 8>
+//
+// RESERVE (no first-pass histogram): instead of reading cursors from a scanned histogram, every tile reserves its
+// bucket runs with one returning global atomic per (tile, bucket) on `rs.cursor` -- F atomics per 24576 rows, issued
+// together before the tile's LDS scan and consumed after it.  Bucket f owns rows [f*cap, (f+1)*cap) of the output;
+// hash partitioning keeps bucket sizes within n/F + 6 sigma, and a bucket that does not fit raises rs.overflow (the
+// histogram path, standing by with run_if = overflow, then redoes the pass exactly).  Rows within a bucket land in
+// tile-completion order, which the join does not depend on.
+struct ReserveArgs {
+    uint32_t* cursor;     // [F] rows reserved so far per bucket (zeroed)
+    uint32_t cap;         // rows provisioned per bucket
+    uint32_t* overflow;   // set to 1 when a bucket outgrew its range
+};
+
+template <int PASS_TAG, int BT_RPT, int NT = PT_THREADS, int WIN = BT_WIN, int WPE = 4, bool PF = false, int WU = 8, bool RESERVE = false>
 __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __restrict__ in_keys, uint32_t rid_base,
                                                             const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
                                                             const uint32_t* __restrict__ scanned, long long* __restrict__ out_keys,
-                                                            uint32_t* __restrict__ out_rids, PassCfg cfg) {
+                                                            uint32_t* __restrict__ out_rids, PassCfg cfg, ReserveArgs rs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [WIN]
     uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + WIN * 8);         // [WIN]
@@ -376,7 +410,7 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
     const uint32_t off = chunk_off[chunk];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t F = cfg.F;
-    {
+    if (!RESERVE) {
         const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
         for (uint32_t f = tid; f < F; f += NT) s_gpos[f] = scanned[((size_t)g * F + f) * cfg.S + s];
     }
@@ -419,9 +453,15 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
             }
         }
         lds_barrier();
+        uint32_t rsv0 = 0, rsv1 = 0, rsv_over = 0;
         {
             const uint32_t f0 = 2 * tid, f1 = 2 * tid + 1;
             const uint32_t c0 = f0 < F ? s_cnt[f0] : 0u, c1 = f1 < F ? s_cnt[f1] : 0u;
+            uint32_t r0 = 0, r1 = 0;
+            if (RESERVE) {   // in flight during the scan below
+                if (c0) r0 = atomicAdd(&rs.cursor[f0], c0);
+                if (c1) r1 = atomicAdd(&rs.cursor[f1], c1);
+            }
             const uint32_t inc = wave_inclusive_scan(c0 + c1);
             if (lane == 63) s_w[wv] = inc;
             lds_barrier();
@@ -431,6 +471,11 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
             const uint32_t e0 = base + inc - (c0 + c1);
             if (f0 < F) s_start[f0] = e0;
             if (f1 < F) s_start[f1] = e0 + c0;
+            if (RESERVE) {   // consumed as late as possible: after the first window is staged (below)
+                rsv0 = r0;
+                rsv1 = r1;
+                if (r0 + c0 > rs.cap || r1 + c1 > rs.cap) rsv_over = 1u;   // r + c cannot wrap: both < 2^31
+            }
         }
         lds_barrier();
         // tile-local slot of every row, computed once (the window rounds below only compare it)
@@ -448,6 +493,11 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                     }
                 }
             }
+            if (RESERVE && w0 == 0) {   // the reservations have had the scan and the staging above to come back
+                if (2 * tid < F) s_gpos[2 * tid] = 2 * tid * rs.cap + rsv0;
+                if (2 * tid + 1 < F) s_gpos[2 * tid + 1] = (2 * tid + 1) * rs.cap + rsv1;
+                if (rsv_over) atomicOr(rs.overflow, 1u);
+            }
             lds_barrier();
             const uint32_t wn = tn - w0 < (uint32_t)WIN ? tn - w0 : (uint32_t)WIN;
 #pragma unroll WU
@@ -457,13 +507,16 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                     const long long k = s_keys[i];
                     const uint32_t b = bucket_of(hash_int64(k), cfg);
                     const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
-                    out_keys[gp] = k;
-                    out_rids[gp] = s_rids[i];
+                    if (!RESERVE || gp < (b + 1u) * rs.cap) {   // rows past a bucket's range are dropped (overflow raised above)
+                        out_keys[gp] = k;
+                        out_rids[gp] = s_rids[i];
+                    }
                 }
             }
             lds_barrier();
         }
-        for (uint32_t f = tid; f < F; f += NT) s_gpos[f] += s_cnt[f];
+        if (!RESERVE)
+            for (uint32_t f = tid; f < F; f += NT) s_gpos[f] += s_cnt[f];
         if (PF) {
 #pragma unroll
             for (int r = 0; r < BT_RPT; ++r) key[r] = nxt[r];
@@ -481,8 +534,7 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
 // the layout by the same flag: nothing is read back to the host, the call stays asynchronous.
 // ---------------------------------------------------------------------------
 struct FixedArgs {
-    const uint32_t* prev_scanned;   // scanned histogram of the previous pass: group g = [prev[g*prev_S], prev[(g+1)*prev_S])
-    uint32_t prev_S;
+    GroupSrc groups;                // extents of this pass's groups in the previous pass's output
     const uint32_t* slot_base;      // [G+1] first row of group g's slot block
     const uint32_t* slot_cap;       // [G]   rows per slot of group g
     uint32_t* sub_start;            // [G*F] out: first row of sub-partition (g, f)
@@ -497,13 +549,14 @@ __device__ __forceinline__ uint32_t isqrt_u32(uint32_t x) {
     return r;
 }
 
-__global__ __launch_bounds__(1024) void k_slots_setup(const uint32_t* __restrict__ prev, uint32_t prev_S, uint32_t G, uint32_t F, uint32_t sigmas,
+__global__ __launch_bounds__(1024) void k_slots_setup(GroupSrc gs, uint32_t G, uint32_t F, uint32_t sigmas,
                                                       uint32_t pad, uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap) {
     __shared__ uint32_t s_w[16];
     const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
     uint32_t total = 0;
     if (g < G) {
-        const uint32_t n_g = prev[(size_t)(g + 1) * prev_S] - prev[(size_t)g * prev_S];
+        uint32_t g_start, n_g;
+        group_extent(gs, g, g_start, n_g);
         const uint32_t avg = (n_g + F - 1) / F;
         const uint32_t cap = (avg + sigmas * isqrt_u32(avg) + pad + 15u) & ~15u;
         slot_cap[g] = cap;
@@ -564,8 +617,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t len, off, slot0 = 0, cap = 0;
     if (FIXED) {   // one work-group = one whole group; buckets go to their pre-provisioned slots
-        off = fx.prev_scanned[(size_t)chunk * fx.prev_S];
-        len = fx.prev_scanned[(size_t)(chunk + 1) * fx.prev_S] - off;
+        group_extent(fx.groups, chunk, off, len);
         slot0 = fx.slot_base[chunk];
         cap = fx.slot_cap[chunk];
         if (len == 0) {
@@ -1263,6 +1315,43 @@ static bool use_fast_last_pass(const JoinPlan& plan, bool has_segs) {
     return pp.G <= 1024 && pp.cfg.F >= 32 && pp.cfg.F <= (uint32_t)WC_MAX_F;
 }
 
+static bool use_big_scatter(uint32_t F, bool local_pass, bool has_rids);
+
+static uint32_t isqrt_host(uint64_t x) {
+    uint64_t r = (uint64_t)std::sqrt((double)x);
+    while (r * r > x) --r;
+    while ((r + 1) * (r + 1) <= x) ++r;
+    return (uint32_t)r;
+}
+
+// rows provisioned per first-pass bucket when the first pass reserves its output by atomics (k_scatter_big<.., RESERVE>)
+static uint64_t reserve_cap(uint64_t n_rows, uint32_t F) {
+    uint32_t sigmas = 6, pad = 48;
+    if (const char* env = getenv("GOLAP_RESERVE_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }   // test hook: 0 forces overflows
+    const uint64_t avg = ceil_div(std::max<uint64_t>(n_rows, 1), F);
+    return round_up(avg + (uint64_t)sigmas * isqrt_host(avg) + pad, 16);
+}
+
+// No-histogram FIRST pass: single-source global pass of a two-pass plan whose second pass is the no-histogram one,
+// large enough for the 1024-thread big-tile kernel.
+static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool has_segs, bool has_rids) {
+    const char* env = getenv("GOLAP_RESERVE");   // "0" disables (A/B hook), "1" drops the size condition (test hook)
+    if (env && !strcmp(env, "0")) return false;
+    if (!use_fast_last_pass(plan, has_segs) || has_rids) return false;
+    const uint32_t F = plan.passes[0].cfg.F;
+    if (!use_big_scatter(F, false, false)) return false;
+    uint32_t chunk_rows = 0;
+    const uint32_t chunks = first_pass_chunks(n_rows, &chunk_rows);
+    if (!(env && !strcmp(env, "1")) && (chunks < 512 || n_rows / chunks < 4 * 24576)) return false;
+    return reserve_cap(n_rows, F) * F < 0xFFFFFFF0ull;
+}
+
+// rows the first-pass output buffer must hold
+static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
+    if (!use_reserve_first_pass(plan, n, has_segs, false)) return n;
+    return std::max<uint64_t>(n, reserve_cap(n, plan.passes[0].cfg.F) * plan.passes[0].cfg.F);
+}
+
 // rows the final buffers of one side must hold: slots are avg + 6 sqrt(avg) + 48, 16-row aligned (k_slots_setup)
 static uint64_t final_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
     if (!use_fast_last_pass(plan, has_segs)) return n;
@@ -1315,7 +1404,7 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
         const int v = e ? atoi(e) : (n_chunks >= 512 && n_rows / n_chunks >= 4 * 24576 ? 1224 : 24);
 #define GOLAP_BIG(RPT, NT, WIN, WPE, PF, ...)                                                                                             \
     hipLaunchKernelGGL((k_scatter_big<1, RPT, NT, WIN, WPE, PF, ##__VA_ARGS__>), dim3(n_chunks), dim3(NT), scatter_big_lds_bytes(cfg.F, WIN, NT), st, keys, \
-                       rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg)
+                       rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, ReserveArgs{})
         switch (v) {
             case 20: GOLAP_BIG(20, 512, 4096, 4, false); break;
             case 16: GOLAP_BIG(16, 512, 4096, 4, false); break;
@@ -1393,12 +1482,48 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     uint32_t prev_S = 1;
     char name[48];
     const bool fast_last = use_fast_last_pass(plan, segs != nullptr);
+    const bool reserve_first = use_reserve_first_pass(plan, n_rows, segs != nullptr, in_rids != 0);
     const uint32_t* run_if = nullptr;
+    GroupSrc groups{};   // how the current pass finds its groups in the previous pass's output
     for (size_t k = 0; k < np; ++k) {
         PassPlan& pp = plan.passes[k];
         uint32_t S;
         uint32_t n_chunks;
         uint32_t chunk_rows = 0;
+        if (reserve_first && k == 0) {
+            // ---- no-histogram first pass: tiles reserve their bucket runs by atomics (k_scatter_big<.., RESERVE>) ----
+            const uint32_t F = pp.cfg.F;
+            const uint32_t cap = (uint32_t)reserve_cap(n_rows, F);
+            uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F * 4);
+            uint32_t* flag1 = (uint32_t*)ws_take(ctx, 4);
+            const uint32_t nc = first_pass_chunks(n_rows, &chunk_rows);
+            uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
+            uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
+            if (!cursor || !flag1 || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (reservation arrays)");
+            GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F * 4));
+            GOLAP_TRY(zero_async(ctx, st, (void*)flag1, 4));
+            hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_rows, chunk_rows, nc, c_off, c_len);
+            PassCfg cfg = pp.cfg;
+            cfg.S = nc;
+            {
+                KernelTimer t(ctx, "radix_scatter_p1", st, 20 * n_rows);
+#define GOLAP_RSV(RPT, WIN, WU)                                                                                                            \
+    hipLaunchKernelGGL((k_scatter_big<1, RPT, 1024, WIN, 4, false, WU, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F, WIN, 1024), st,      \
+                       (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,         \
+                       (long long*)buf.tmp_keys[0], (uint32_t*)buf.tmp_rids[0], cfg, ReserveArgs{cursor, cap, flag1})
+                const char* e = getenv("GOLAP_RESERVE");   // A/B hook: kernel variant
+                const int v = e ? atoi(e) : 3;
+                if (v == 2) GOLAP_RSV(24, 12288, 2);
+                else if (v == 20) GOLAP_RSV(20, 10240, 5);
+                else GOLAP_RSV(24, 12288, 3);
+#undef GOLAP_RSV
+            }
+            GOLAP_HIP_TRY(ctx, hipGetLastError());
+            groups.cursor = cursor;
+            groups.cap = cap;
+            groups.flag = flag1;
+            run_if = flag1;   // the histogram path below stands by
+        }
         if (fast_last && k == 1) {
             // ---- no-histogram pass: one work-group per group writes into pre-provisioned slots ----
             const uint32_t G = pp.G, F = pp.cfg.F;
@@ -1411,8 +1536,8 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             GOLAP_TRY(zero_async(ctx, st, (void*)(flag), 4));
             uint32_t sigmas = 6, pad = 48;
             if (const char* env = getenv("GOLAP_SLOT_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }   // test hook: 0 forces overflows
-            hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, prev_scanned, prev_S, G, F, sigmas, pad, slot_base, slot_cap);
-            FixedArgs fx{prev_scanned, prev_S, slot_base, slot_cap, sub_start, sub_len, flag};
+            hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F, sigmas, pad, slot_base, slot_cap);
+            FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, flag};
             PassCfg cfg = pp.cfg;
             cfg.S = 1;
             {
@@ -1456,7 +1581,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
                 hipLaunchKernelGGL(k_setup_from_segments, dim3(gb), dim3(tb), 0, st, (const uint32_t*)segs->dev_off,
                                    (const uint32_t*)segs->dev_len, pp.G, segs->n_src, S / segs->n_src, c_off, c_len);
             else
-                hipLaunchKernelGGL(k_setup_from_scan, dim3(gb), dim3(tb), 0, st, prev_scanned, prev_S, pp.G, S, c_off, c_len, run_if);
+                hipLaunchKernelGGL(k_setup_from_scan, dim3(gb), dim3(tb), 0, st, groups, pp.G, S, c_off, c_len, run_if);
         }
         {
             snprintf(name, sizeof name, run_if ? "radix_hist_p%zu_standby" : "radix_hist_p%zu", k + 1);
@@ -1478,6 +1603,9 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         cur_rids = out_rids;
         prev_scanned = hist;
         prev_S = S;
+        groups.scanned = hist;
+        groups.stride = S;
+        if (k > 0) groups.cursor = nullptr;   // only the first pass has a reserved layout
         (void)side;
     }
     res.off = prev_scanned;
@@ -1506,6 +1634,9 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_BIG_ATTR(20, 1024, 8192, 4, false);
     GOLAP_BIG_ATTR(16, 768, 6144, 6, false);
     GOLAP_BIG_ATTR(20, 640, 5120, 5, false);
+    GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, true);
+    GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 2, true);
+    GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 5, true);
     GOLAP_BIG_ATTR(18, 1024, 9216, 4, false);
     GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 2);
     GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 5);
@@ -1528,7 +1659,6 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
 }
 
 static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint64_t n_probe, uint32_t n_src, bool has_segs) {
-    const uint64_t nmax = std::max(n_build, n_probe);
     const size_t np = plan.passes.size();
     uint64_t bytes = 0;
     const uint64_t fb = final_rows(plan, n_build, has_segs), fp = final_rows(plan, n_probe, has_segs);
@@ -1537,7 +1667,9 @@ static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint
     if (use_fast_last_pass(plan, has_segs))
         bytes += 2 * (2 * round_up((uint64_t)plan.passes[1].G * plan.passes[1].cfg.F * 4, 256) + 2 * round_up((uint64_t)(plan.passes[1].G + 1) * 4, 256) + 1024);
     const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
-    bytes += n_tmp * (round_up(nmax * 8, 256) + round_up(nmax * 4, 256));
+    const uint64_t tmax = std::max(pass1_rows(plan, n_build, has_segs), pass1_rows(plan, n_probe, has_segs));
+    bytes += n_tmp * (round_up(tmax * 8, 256) + round_up(tmax * 4, 256));
+    bytes += 2 * (round_up((uint64_t)PT_MAX_F * 4, 256) + 512);   // first-pass reservation cursors + flags
     bytes += side_small_bytes(plan, n_build, n_src, has_segs) + side_small_bytes(plan, n_probe, n_src, has_segs);
     bytes += 2 * round_up((uint64_t)4096 * 4 * 2, 256);   // segment tables
     return bytes + (1 << 20);
@@ -1575,7 +1707,6 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     make_plan(p->n_build, 0, true, plan);
     const size_t np = plan.passes.size();
     GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->n_build, p->n_probe, 1, false) + final_rows(plan, p->n_probe, false) / 8 + 4096, st));
-    const uint64_t nmax = std::max(p->n_build, p->n_probe);
     SideBuffers bb, pb;
     const uint64_t fb = final_rows(plan, p->n_build, false), fp = final_rows(plan, p->n_probe, false);
     bb.final_keys = ws_take(ctx, fb * 8);
@@ -1583,9 +1714,10 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     pb.final_keys = ws_take(ctx, fp * 8);
     pb.final_rids = ws_take(ctx, fp * 4);
     const size_t n_tmp = np >= 3 ? 2 : (np == 2 ? 1 : 0);
+    const uint64_t tmax = std::max(pass1_rows(plan, p->n_build, false), pass1_rows(plan, p->n_probe, false));
     for (size_t i = 0; i < n_tmp; ++i) {
-        bb.tmp_keys[i] = pb.tmp_keys[i] = ws_take(ctx, nmax * 8);
-        bb.tmp_rids[i] = pb.tmp_rids[i] = ws_take(ctx, nmax * 4);
+        bb.tmp_keys[i] = pb.tmp_keys[i] = ws_take(ctx, tmax * 8);
+        bb.tmp_rids[i] = pb.tmp_rids[i] = ws_take(ctx, tmax * 4);
         if (!bb.tmp_keys[i] || !bb.tmp_rids[i]) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
     }
     if (!bb.final_keys || !bb.final_rids || !pb.final_keys || !pb.final_rids) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");

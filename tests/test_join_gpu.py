@@ -221,6 +221,47 @@ def test_no_histogram_last_pass_and_its_overflow_fallback(ctx, env, jt):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("env", [{}, {"GOLAP_RESERVE_SIGMAS": "0"}, {"GOLAP_RESERVE_SIGMAS": "1"}, {"GOLAP_SLOT_SIGMAS": "0"},
+                                 {"GOLAP_RESERVE_SIGMAS": "0", "GOLAP_SLOT_SIGMAS": "0"}])
+@pytest.mark.parametrize("jt", [0, 3])
+def test_no_histogram_first_pass_and_its_overflow_fallback(ctx, env, jt):
+    """Large two-pass joins also skip the FIRST histogram: tiles reserve their bucket runs with atomics inside ranges of
+    n/F + 6 sigma rows.  GOLAP_RESERVE=1 applies that form at a size the oracle checks in seconds; GOLAP_RESERVE_SIGMAS=0/1
+    force range overflows (hand-over to the stand-by histogram pass), alone and together with second-pass slot overflows."""
+    n = 6_000_000
+    b = oracle.gen_sm64_mod(71, 0, n, n)
+    p = oracle.gen_sm64_mod(72, 0, n, n)
+    env = dict(env, GOLAP_PASS_BITS="8,6", GOLAP_RESERVE="1")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx.stats_reset()
+        outer_check(ctx, b, p, N.JOIN_RADIX_HASH, jt)
+        st = ctx.stats()
+        assert "radix_hist_p1" not in st and "radix_hist_p1_standby" in st     # the reserving form ran, the histogram stood by
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_no_histogram_first_pass_with_one_hot_key(ctx):
+    """a bucket that outgrows its reserved range for real (one key holds 10 % of the build side)."""
+    n = 4_000_000
+    rng = np.random.default_rng(9)
+    b = np.concatenate([oracle.gen_build_keys(0, n, n), np.full(400_000, 777, np.int64)])
+    p = np.concatenate([oracle.gen_probe_keys(0, n, n), np.full(3, 777, np.int64), rng.integers(0, n, 1000)])
+    env = dict(GOLAP_PASS_BITS="8,6", GOLAP_RESERVE="1")
+    os.environ.update(env)
+    try:
+        check(ctx, b, p, N.JOIN_RADIX_HASH, max_pairs=8_000_000)
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
 def test_no_histogram_pass_with_skewed_groups(ctx):
     """a few heavy keys overflow their slots for real (no test hook): the fallback must kick in on its own."""
     n = 5_000_000
@@ -247,7 +288,9 @@ def test_no_histogram_pass_is_taken_and_flag_stays_clear(ctx):
     torch.cuda.synchronize()
     st = ctx.stats()
     assert "radix_scatter_p2_standby" in st and "radix_hist_p2" not in st
-    assert st["radix_scatter_p2_standby"]["total_ms"] < 0.5          # stand-by launches return at once: the flag stayed clear
+    assert "radix_scatter_p1_standby" in st and "radix_hist_p1" not in st      # first pass reserved its output, no histogram either
+    assert st["radix_scatter_p2_standby"]["total_ms"] < 0.5          # stand-by launches return at once: the flags stayed clear
+    assert st["radix_scatter_p1_standby"]["total_ms"] < 0.5
     assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2
 
 
