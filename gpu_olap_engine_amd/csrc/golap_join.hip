@@ -593,7 +593,9 @@ constexpr int WC_CAP = 12288;                 // staging rows (carry + new): 144
 constexpr int WC_MAX_F = 512;                 // carry <= 15 * F = 7680 rows, leaves >= 512 new rows per tile
 constexpr int WC_CARRY_PT = 16 * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
 
-template <int PASS_TAG, bool FIXED>
+// LINE = rows per write-combined segment.  16 (a whole 128-byte key line) is the only instantiation: 8-row segments
+// (64-byte key / 32-byte row-id writes) halve the carry but measured 12.4 -> 14.8 ms at 1B rows -- HBM wants whole lines.
+template <int PASS_TAG, bool FIXED, int LINE = 16>
 __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __restrict__ in_keys, const uint32_t* __restrict__ in_rids,
                                                            uint32_t rid_base, const uint32_t* __restrict__ chunk_off,
                                                            const uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ scanned,
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
             if (tid < F) {
                 s_start[tid] = base + inc - c;
                 const uint32_t gp = s_gpos[tid], end = gp + c;
-                const uint32_t ae = last ? end : (end & ~15u);
+                const uint32_t ae = last ? end : (end & ~(uint32_t)(LINE - 1));
                 const uint32_t e = ae > gp ? ae - gp : 0u;
                 s_emit[tid] = e;
                 nc = c - e;
@@ -693,11 +695,12 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         }
         lds_barrier();
         // carried rows: old staging position -> registers -> new staging position
-        long long ck[WC_CARRY_PT];
-        uint32_t cr[WC_CARRY_PT], cdst[WC_CARRY_PT];
+        constexpr int CARRY_PT = LINE * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
+        long long ck[CARRY_PT];
+        uint32_t cr[CARRY_PT], cdst[CARRY_PT];
 #pragma unroll
-        for (int c8 = 0; c8 < WC_CARRY_PT; ++c8) {
-            const uint32_t j = c8 * WC_THREADS + tid, b = j >> 4, k = j & 15u;
+        for (int c8 = 0; c8 < CARRY_PT; ++c8) {
+            const uint32_t j = c8 * WC_THREADS + tid, b = j / LINE, k = j % LINE;
             cdst[c8] = 0xFFFFFFFFu;
             if (b < F && k < s_carry[b]) {
                 const uint32_t src = s_csrc[b] + k;
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         }
         lds_barrier();
 #pragma unroll
-        for (int c8 = 0; c8 < WC_CARRY_PT; ++c8) {
+        for (int c8 = 0; c8 < CARRY_PT; ++c8) {
             if (cdst[c8] != 0xFFFFFFFFu) {
                 s_keys[cdst[c8]] = ck[c8];
                 s_rids[cdst[c8]] = cr[c8];
@@ -752,14 +755,15 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         }
         // write out: one 16-lane group per 128-byte key line
         {
-            const uint32_t q = tid >> 4, l = tid & 15u;
-            const uint32_t gpb = F >= 64u ? 1u : 64u / F;   // groups per bucket when the fan-out is small
-            for (uint32_t b = q / gpb; b < F; b += 64u / gpb) {
+            constexpr uint32_t NG = WC_THREADS / LINE;      // lane groups per work-group
+            const uint32_t q = tid / LINE, l = tid % LINE;
+            const uint32_t gpb = F >= NG ? 1u : NG / F;     // groups per bucket when the fan-out is small
+            for (uint32_t b = q / gpb; b < F; b += NG / gpb) {
                 const uint32_t e = s_emit[b];
                 if (e == 0) continue;
                 const uint32_t sb = s_start[b], gp = s_gpos[b];
                 const uint32_t lim = FIXED ? slot0 + (b + 1u) * cap : 0xFFFFFFFFu;   // rows past a slot's end are dropped (flag raised below)
-                for (uint32_t k = ((l - gp) & 15u) + 16u * (q % gpb); k < e; k += 16u * gpb) {   // lane l owns global index == l (mod 16)
+                for (uint32_t k = ((l - gp) & (uint32_t)(LINE - 1)) + LINE * (q % gpb); k < e; k += LINE * gpb) {   // lane l owns global index == l (mod LINE)
                     if (!FIXED || gp + k < lim) {
                         out_keys[gp + k] = s_keys[sb + k];
                         out_rids[gp + k] = s_rids[sb + k];
@@ -789,6 +793,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
 }
 static_assert(WC_CAP - 15 * WC_MAX_F >= 512, "a tile must always have room for new rows");
 static_assert(WC_CARRY_PT * WC_THREADS == 16 * WC_MAX_F, "carry slots per thread");
+static_assert((8 * WC_MAX_F) % WC_THREADS == 0, "carry slots per thread (8-row segments)");
 
 // ---------------------------------------------------------------------------
 // join of one sub-partition per work-group, table in LDS.
@@ -1831,6 +1836,7 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
                      : (out->chunks1 >= 512 && n_build / out->chunks1 >= 4 * 24576 ? 1024 * 24 : PT_THREADS * 24);
     out->slots2 = plan.passes.size() < 2 ? 0 : (use_fast_last_pass(plan, false) ? 1 : slots_for(plan.passes[1].G, n_build));
     out->no_histogram_last_pass = use_fast_last_pass(plan, false) ? 1 : 0;
+    out->no_histogram_first_pass = use_reserve_first_pass(plan, n_build, false, false) ? 1 : 0;
     out->table_capacity = JN_CAP;
     out->n_subpartitions = plan.n_sub;
     return GOLAP_OK;

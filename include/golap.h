@@ -336,6 +336,7 @@ typedef struct golap_join_plan {
     uint32_t table_capacity;      /* LDS hash-table rows per sub-partition */
     uint64_t n_subpartitions;
     uint32_t no_histogram_last_pass;   /* 1 when pass 2 writes into pre-provisioned slots */
+    uint32_t no_histogram_first_pass;  /* 1 when pass 1 reserves its bucket ranges by atomics instead of a histogram */
 } golap_join_plan;
 int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners, golap_join_plan* out);
 

@@ -89,8 +89,10 @@ def test_join_plan_is_host_only(lib):
     for n, (b1, b2) in {500_000: (8, 0), 1_000_000: (9, 0), 100_000_000: (8, 7), 1_000_000_000: (9, 9)}.items():
         assert lib.golap_join_plan_get(None, n, 1, C.byref(p)) == 0
         assert (p.bits1, p.bits2) == (b1, b2), n
-        assert p.n_subpartitions == 1 << (b1 + b2) and p.table_capacity == 4096 and p.tile_rows in (4096, 12288)
+        assert p.n_subpartitions == 1 << (b1 + b2) and p.table_capacity == 4096 and p.tile_rows in (4096, 12288, 24576)
         assert p.no_histogram_last_pass == (1 if b2 >= 5 else 0) and p.chunks1 >= 1
+        assert p.no_histogram_first_pass == (1 if n >= 100_000_000 else 0)
+        assert p.tile_rows == (24576 if n >= 100_000_000 else 12288 if b1 >= 7 else 4096)
 
 
 def test_no_device_fails_loudly(lib):
