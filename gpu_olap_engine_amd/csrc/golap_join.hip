@@ -1344,7 +1344,7 @@ static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool h
     if (env && !strcmp(env, "0")) return false;
     if (!use_fast_last_pass(plan, has_segs) || has_rids) return false;
     const uint32_t F = plan.passes[0].cfg.F;
-    if (!use_big_scatter(F, false, false)) return false;
+    if (!use_big_scatter(F, false, false) || F > (uint32_t)WC_MAX_F) return false;   // the stand-by pass uses the write-combining scatter
     uint32_t chunk_rows = 0;
     const uint32_t chunks = first_pass_chunks(n_rows, &chunk_rows);
     if (!(env && !strcmp(env, "1")) && (chunks < 512 || n_rows / chunks < 4 * 24576)) return false;
