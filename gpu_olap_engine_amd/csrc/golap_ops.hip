@@ -207,6 +207,16 @@ __global__ void k_counts_from_stats(const double* __restrict__ stats4, uint32_t 
         out_count[g] = (unsigned long long)stats4[g * 4 + 1];
 }
 
+// slot = (u64)key % n_groups (join_kernels.cuh:230; negative keys wrap like the reference's unsigned arithmetic).
+// Keys below 2^32 -- every non-negative int32 key -- take a 32-bit remainder: the 64-bit one is a ~100-instruction
+// software routine and made the grouped kernels VALU-bound.
+template <typename KeyT>
+__device__ __forceinline__ uint32_t slot_of(KeyT key, uint32_t n_groups) {
+    const unsigned long long u = (unsigned long long)key;
+    if ((u >> 32) == 0) return (uint32_t)u % n_groups;
+    return (uint32_t)(u % n_groups);
+}
+
 // ---------------------------------------------------------------------------
 // grouped aggregate, LDS pre-aggregation (aggregate_kernel.rs:3-6 "phase 1" /
 // "phase 2"): every work-group folds its rows into an LDS table of n_groups
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
         for (int r = 0; r < GR; ++r) {
             const unsigned long long i = base + (unsigned long long)r * blockDim.x + threadIdx.x;
             if (i < hi) {
-                const uint32_t g = (uint32_t)((unsigned long long)k[r] % n_groups);
+                const uint32_t g = slot_of(k[r], n_groups);
                 atomicAdd(&s_sum[g], x[r]);
                 atomicAdd(&s_cnt[g], 1u);
                 if (NEED_MM) {   // MIN / MAX requested by some spec: two more LDS atomics per row
@@ -267,15 +277,36 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
     }
 }
 
-__global__ __launch_bounds__(OP_THREADS) void k_group_fold(const double* __restrict__ slab, uint32_t n_rows_slab, uint32_t n_groups,
-                                                            double* __restrict__ stats4) {
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
-        double sum = 0.0, cnt = 0.0, mn = GOLAP_F64_MAX, mx = -GOLAP_F64_MAX;
-        for (uint32_t b = 0; b < n_rows_slab; ++b) {
+// Fold of the per-work-group partial tables, in a fixed order (reproducible): a 1024-thread block owns 64 groups; wave w
+// folds slabs w, w+16, w+32, ... (independent coalesced loads), then the 16 wave partials are combined in wave order.
+// (One thread per group walking all 512 slabs serially took 0.24 ms of the 2.5 ms C4 run.)
+constexpr int GF_THREADS = 1024;
+constexpr int GF_PARTS = GF_THREADS / 64;
+__global__ __launch_bounds__(GF_THREADS) void k_group_fold(const double* __restrict__ slab, uint32_t n_rows_slab, uint32_t n_groups,
+                                                           double* __restrict__ stats4) {
+    __shared__ double s_part[GF_PARTS][4][64];
+    const uint32_t gl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x * 64 + gl;
+    double sum = 0.0, cnt = 0.0, mn = GOLAP_F64_MAX, mx = -GOLAP_F64_MAX;
+    if (g < n_groups) {
+#pragma unroll 4
+        for (uint32_t b = part; b < n_rows_slab; b += GF_PARTS) {
             const double* row = slab + (size_t)b * 4 * n_groups;
-            sum += row[g]; cnt += row[n_groups + g];
-            mn = row[2 * n_groups + g] < mn ? row[2 * n_groups + g] : mn;
-            mx = row[3 * n_groups + g] > mx ? row[3 * n_groups + g] : mx;
+            const double a0 = row[g], a1 = row[n_groups + g], a2 = row[2 * (size_t)n_groups + g], a3 = row[3 * (size_t)n_groups + g];
+            sum += a0; cnt += a1;
+            mn = a2 < mn ? a2 : mn;
+            mx = a3 > mx ? a3 : mx;
+        }
+    }
+    s_part[part][0][gl] = sum; s_part[part][1][gl] = cnt; s_part[part][2][gl] = mn; s_part[part][3][gl] = mx;
+    __syncthreads();
+    if (part == 0 && g < n_groups) {
+        sum = 0.0; cnt = 0.0; mn = GOLAP_F64_MAX; mx = -GOLAP_F64_MAX;
+#pragma unroll
+        for (int q = 0; q < GF_PARTS; ++q) {
+            sum += s_part[q][0][gl]; cnt += s_part[q][1][gl];
+            mn = s_part[q][2][gl] < mn ? s_part[q][2][gl] : mn;
+            mx = s_part[q][3][gl] > mx ? s_part[q][3][gl] : mx;
         }
         stats4[g * 4 + 0] = sum; stats4[g * 4 + 1] = cnt; stats4[g * 4 + 2] = mn; stats4[g * 4 + 3] = mx;
     }
@@ -315,7 +346,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_hist(const KeyT* __restrict_
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const unsigned long long i = base + (unsigned long long)r * AG_THREADS + threadIdx.x;
-            if (i < hi) atomicAdd(&s_cnt[(uint32_t)((unsigned long long)k[r] % n_groups) / AG_GB], 1u);
+            if (i < hi) atomicAdd(&s_cnt[slot_of(k[r], n_groups) / AG_GB], 1u);
         }
     }
     __syncthreads();
@@ -346,7 +377,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_scatter(const KeyT* __restri
         for (int r = 0; r < AG_RPT; ++r) {   // unconditional loads on clamped indices: all in flight together
             const uint32_t i = r * AG_THREADS + tid;
             const unsigned long long gi = t0 + (i < tn ? i : tn - 1);
-            slot[r] = (uint32_t)((unsigned long long)keys[gi] % n_groups);
+            slot[r] = slot_of(keys[gi], n_groups);
             x[r] = VAL_F64 ? vf[gi] : (double)vi[gi];   // executor.rs:521 `as f64`
         }
         __syncthreads();
@@ -395,6 +426,98 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_scatter(const KeyT* __restri
         }
         __syncthreads();
         for (uint32_t b = tid; b < B; b += AG_THREADS) s_gpos[b] += s_cnt[b];
+    }
+}
+
+// Register-resident big tile (same idea as the join's k_scatter_big): 1024 threads x 16 rows = 16384-row tile held in
+// registers, ranked once, pushed through an 8192-row LDS window in two rounds.  At 512 buckets a bucket's run per tile is
+// 32 rows (256-byte value run, 128-byte slot run) instead of 8 rows with the 4096-row tile above.
+constexpr int AGB_THREADS = 1024;
+constexpr int AGB_RPT = 16;
+constexpr int AGB_TILE = AGB_THREADS * AGB_RPT;
+constexpr int AGB_WIN = 8192;
+constexpr size_t AGB_LDS = (size_t)AGB_WIN * 12 + (size_t)AG_MAX_B * 12 + (AGB_THREADS / 64) * 4 + 16;
+
+template <typename KeyT, bool VAL_F64>
+__global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
+                                                                 uint32_t n_groups, uint32_t chunk_rows, uint32_t S, uint32_t B,
+                                                                 const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
+                                                                 double* __restrict__ out_val) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double* s_val = reinterpret_cast<double*>(s_raw);                          // [AGB_WIN]
+    uint32_t* s_slot = reinterpret_cast<uint32_t*>(s_raw + AGB_WIN * 8);       // [AGB_WIN]
+    uint32_t* s_cnt = s_slot + AGB_WIN;
+    uint32_t* s_start = s_cnt + AG_MAX_B;
+    uint32_t* s_gpos = s_start + AG_MAX_B;
+    uint32_t* s_w = s_gpos + AG_MAX_B;
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
+    if (lo >= n) return;
+    const unsigned long long hi = lo + chunk_rows < n ? lo + chunk_rows : n;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long* vi = (const long long*)val;
+    const double* vf = (const double*)val;
+    for (uint32_t b = tid; b < B; b += AGB_THREADS) s_gpos[b] = scanned[(size_t)b * S + blockIdx.x];
+    for (unsigned long long t0 = lo; t0 < hi; t0 += AGB_TILE) {
+        const uint32_t tn = hi - t0 < (unsigned long long)AGB_TILE ? (uint32_t)(hi - t0) : (uint32_t)AGB_TILE;
+        for (uint32_t b = tid; b < B; b += AGB_THREADS) s_cnt[b] = 0;
+        uint32_t slot[AGB_RPT], br[AGB_RPT];
+        double x[AGB_RPT];
+#pragma unroll
+        for (int r = 0; r < AGB_RPT; ++r) {   // unconditional loads on clamped indices: all in flight together
+            const uint32_t i = r * AGB_THREADS + tid;
+            const unsigned long long gi = t0 + (i < tn ? i : tn - 1);
+            slot[r] = slot_of(keys[gi], n_groups);
+            x[r] = VAL_F64 ? vf[gi] : (double)vi[gi];   // executor.rs:521 `as f64`
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < AGB_RPT; ++r) {
+            const uint32_t i = r * AGB_THREADS + tid;
+            br[r] = 0xFFFFFFFFu;
+            if (i < tn) {
+                const uint32_t b = slot[r] / AG_GB;
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 16384
+            }
+        }
+        lds_barrier();
+        {
+            const uint32_t c = tid < B ? s_cnt[tid] : 0u;
+            const uint32_t inc = wave_inclusive_scan(c);
+            if (lane == 63) s_w[wv] = inc;
+            lds_barrier();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < AGB_THREADS / 64; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            if (tid < B) s_start[tid] = base + inc - c;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < AGB_RPT; ++r)
+            if (br[r] != 0xFFFFFFFFu) br[r] = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
+        for (uint32_t w0 = 0; w0 < tn; w0 += AGB_WIN) {
+#pragma unroll
+            for (int r = 0; r < AGB_RPT; ++r) {
+                const uint32_t pos = br[r] - w0;   // invalid rows and rows of the other window fall outside
+                if (pos < (uint32_t)AGB_WIN) {
+                    s_slot[pos] = slot[r];
+                    s_val[pos] = x[r];
+                }
+            }
+            lds_barrier();
+            const uint32_t wn = tn - w0 < (uint32_t)AGB_WIN ? tn - w0 : (uint32_t)AGB_WIN;
+#pragma unroll 4
+            for (int j = 0; j < AGB_WIN / AGB_THREADS; ++j) {
+                const uint32_t i = j * AGB_THREADS + tid;
+                if (i < wn) {
+                    const uint32_t sl = s_slot[i], b = sl / AG_GB;
+                    const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
+                    out_slot[gp] = sl;
+                    out_val[gp] = s_val[i];
+                }
+            }
+            lds_barrier();
+        }
+        for (uint32_t b = tid; b < B; b += AGB_THREADS) s_gpos[b] += s_cnt[b];
     }
 }
 
@@ -480,7 +603,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_group_global(const KeyT* __restr
     const long long* vi = (const long long*)val;
     const double* vf = (const double*)val;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t g = (uint32_t)((unsigned long long)keys[i] % n_groups);
+        const uint32_t g = slot_of(keys[i], n_groups);
         const double x = VAL_F64 ? vf[i] : (double)vi[i];
         unsafeAtomicAdd(&stats4[g * 4 + 0], x);
         if (need_cnt) unsafeAtomicAdd(&stats4[g * 4 + 1], 1.0);
@@ -684,7 +807,9 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     const bool part_path = grouped && !lds_path && G <= (uint32_t)AG_GB * AG_MAX_B && p->n_rows >= (1ull << 22) && p->n_rows < 0xFFFFFFF0ull &&
                            !(part_env && !strcmp(part_env, "0"));
     const uint32_t pB = part_path ? (uint32_t)ceil_div(G, AG_GB) : 0;
-    const uint32_t pS = part_path ? (uint32_t)std::min<uint64_t>(2048, ceil_div(p->n_rows, AG_TILE)) : 0;
+    // big-tile scatter once every chunk holds >= 4 of its 16384-row tiles and there are >= 512 chunks
+    const bool p_big = part_path && p->n_rows / (4 * AGB_TILE) >= 512;
+    const uint32_t pS = part_path ? (uint32_t)std::min<uint64_t>(2048, p_big ? p->n_rows / (4 * AGB_TILE) : ceil_div(p->n_rows, AG_TILE)) : 0;
     const uint32_t p_chunk = part_path ? (uint32_t)round_up(ceil_div(p->n_rows, pS), AG_TILE) : 0;
     const uint32_t pS2 = part_path ? (uint32_t)ceil_div(p->n_rows, p_chunk) : 0;   // chunks actually used
     const uint32_t pW = part_path ? std::max<uint32_t>(1, std::min<uint32_t>(8, 2048 / pB)) : 0;
@@ -720,6 +845,9 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
         if (!attr2) {
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB * 28 + 16));
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB * 28 + 16));
+            const void* big[] = {(const void*)k_agg_scatter_big<int, true>, (const void*)k_agg_scatter_big<int, false>,
+                                 (const void*)k_agg_scatter_big<long long, true>, (const void*)k_agg_scatter_big<long long, false>};
+            for (const void* f : big) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AGB_LDS));
             attr2 = true;
         }
     }
@@ -775,7 +903,7 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
             }
             {
                 KernelTimer t(ctx, "hash_aggregate_fold", st, 0);
-                hipLaunchKernelGGL(k_group_fold, dim3((uint32_t)ceil_div(G, OP_THREADS)), dim3(OP_THREADS), 0, st, slab, lds_grid, G, stats4);
+                hipLaunchKernelGGL(k_group_fold, dim3((uint32_t)ceil_div(G, 64)), dim3(GF_THREADS), 0, st, slab, lds_grid, G, stats4);
             }
         } else if (part_path) {
             const uint64_t L = (uint64_t)pB * pS2;
@@ -795,9 +923,17 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
 #define GOLAP_AGG_SC(KT, VF)                                                                                                          \
     hipLaunchKernelGGL((k_agg_scatter<KT, VF>), dim3(pS2), dim3(AG_THREADS), 0, st, (const KT*)p->group_key_ptr, val,                 \
                        (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val)
+#define GOLAP_AGG_SCB(KT, VF)                                                                                                         \
+    hipLaunchKernelGGL((k_agg_scatter_big<KT, VF>), dim3(pS2), dim3(AGB_THREADS), AGB_LDS, st, (const KT*)p->group_key_ptr, val,      \
+                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val)
+                if (p_big) {
+                    if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_SCB(int, true); else GOLAP_AGG_SCB(int, false); }
+                    else { if (vf) GOLAP_AGG_SCB(long long, true); else GOLAP_AGG_SCB(long long, false); }
+                } else
                 if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_SC(int, true); else GOLAP_AGG_SC(int, false); }
                 else { if (vf) GOLAP_AGG_SC(long long, true); else GOLAP_AGG_SC(long long, false); }
 #undef GOLAP_AGG_SC
+#undef GOLAP_AGG_SCB
             }
             {
                 KernelTimer t(ctx, "hash_aggregate_lds_buckets", st, 12 * p->n_rows + 12ull * G);

@@ -138,6 +138,26 @@ def test_grouped_aggregate_partitioned_path(ctx, key_dtype, G):
     assert np.array_equal(out2, out)
 
 
+@pytest.mark.parametrize("shape", ["uniform", "skewed"])
+def test_grouped_aggregate_big_tile_partition(ctx, shape):
+    """>= 33.5M rows: the partition pass uses the 1024-thread register-resident tile (k_agg_scatter_big); uniform keys, and a
+    skewed mix (one hot key, a sequential run, a short last chunk) that leaves most buckets of a tile empty."""
+    n, G = 40_000_123, 1_000_003
+    if shape == "uniform":
+        keys = oracle.gen_sm64_mod(81, 0, n, G, np.int32)
+    else:
+        keys = np.concatenate([np.full(n // 2, 777_777, np.int32), (np.arange(n - n // 2, dtype=np.int64) % G).astype(np.int32)])
+    vals = oracle.gen_sm64_mod(82, 0, n, 4096, np.float64) - 2048.0
+    ok, ost = oracle.group_aggregate(keys.astype(np.int64), vals)
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0)]
+    ctx.stats_reset()
+    out, counts = ctx.aggregate(specs, [dev(vals)], group_keys=dev(keys), n_groups=G, want_counts=True)
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    assert "agg_partition_scatter" in ctx.stats()
+    present = counts > 0
+    assert np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
+
+
 def test_grouped_two_value_columns_int_and_float(ctx):
     n, G = 200_000, 300
     keys = oracle.gen_sm64_mod(3, 0, n, G, np.int64)
