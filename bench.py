@@ -166,7 +166,7 @@ def main():
         ach = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not (world > 1 or args.sharded):   # the profiled kernels are those of the direct single-GPU path
             try:
                 tj = json.load(open(tpath))
                 e = tj.get(f"{dom}@{n_total}x{world}")
