@@ -1486,6 +1486,9 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     const uint32_t* prev_scanned = nullptr;
     uint32_t prev_S = 1;
     char name[48];
+    // profile names: the stand-alone partition step (exchange-time, multi-GPU) and the segment-fed local passes behind
+    // it are different kernels/bytes from the single-GPU join's passes
+    const char* pfx = !strcmp(side, "part") ? "partition" : (segs ? "local" : "radix");
     const bool fast_last = use_fast_last_pass(plan, segs != nullptr);
     const bool reserve_first = use_reserve_first_pass(plan, n_rows, segs != nullptr, in_rids != 0);
     const uint32_t* run_if = nullptr;
@@ -1546,7 +1549,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             PassCfg cfg = pp.cfg;
             cfg.S = 1;
             {
-                snprintf(name, sizeof name, "radix_scatter_p%zu", k + 1);
+                snprintf(name, sizeof name, "%s_scatter_p%zu", pfx, k + 1);
                 KernelTimer t(ctx, name, st, 24 * n_rows);
                 hipLaunchKernelGGL((k_scatter_wc<2, true>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F), st, (const long long*)cur_keys,
                                    (const uint32_t*)cur_rids, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
@@ -1589,7 +1592,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
                 hipLaunchKernelGGL(k_setup_from_scan, dim3(gb), dim3(tb), 0, st, groups, pp.G, S, c_off, c_len, run_if);
         }
         {
-            snprintf(name, sizeof name, run_if ? "radix_hist_p%zu_standby" : "radix_hist_p%zu", k + 1);
+            snprintf(name, sizeof name, run_if ? "%s_hist_p%zu_standby" : "%s_hist_p%zu", pfx, k + 1);
             KernelTimer t(ctx, name, st, run_if ? 0 : 8 * n_rows);
             launch_pass_kernel((int)k, true, false, n_chunks, st, (const long long*)cur_keys, nullptr, 0, c_off, c_len, hist, nullptr, nullptr, pp.cfg, run_if);
         }
@@ -1598,7 +1601,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         const uint64_t out_keys = last ? buf.final_keys : buf.tmp_keys[k & 1];
         const uint64_t out_rids = last ? buf.final_rids : buf.tmp_rids[k & 1];
         {
-            snprintf(name, sizeof name, run_if ? "radix_scatter_p%zu_standby" : "radix_scatter_p%zu", k + 1);
+            snprintf(name, sizeof name, run_if ? "%s_scatter_p%zu_standby" : "%s_scatter_p%zu", pfx, k + 1);
             KernelTimer t(ctx, name, st, run_if ? 0 : (cur_rids ? 12 : 8) * n_rows + 12 * n_rows);
             launch_pass_kernel((int)k, false, run_if ? true : use_wc_scatter(pp.cfg.F, pp.G > 1), n_chunks, st, (const long long*)cur_keys,
                                (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg, run_if, n_rows);
@@ -1611,7 +1614,6 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         groups.scanned = hist;
         groups.stride = S;
         if (k > 0) groups.cursor = nullptr;   // only the first pass has a reserved layout
-        (void)side;
     }
     res.off = prev_scanned;
     res.stride = prev_S;
