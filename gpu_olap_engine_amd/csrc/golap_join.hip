@@ -594,7 +594,9 @@ constexpr int WC_MAX_F = 512;                 // carry <= 15 * F = 7680 rows, le
 constexpr int WC_CARRY_PT = 16 * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
 
 // LINE = rows per write-combined segment.  16 (a whole 128-byte key line) is the only instantiation: 8-row segments
-// (64-byte key / 32-byte row-id writes) halve the carry but measured 12.4 -> 14.8 ms at 1B rows -- HBM wants whole lines.
+// (64-byte key / 32-byte row-id writes) halve the carry but measured 12.4 -> 14.8 ms at 1B rows -- HBM wants whole lines;
+// 32-row segments (256-byte key / 128-byte row-id writes) double the carry, which halves the tile that fits next to it
+// in LDS and spills the carry registers: 12.4 -> 27.7 ms.
 template <int PASS_TAG, bool FIXED, int LINE = 16>
 __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __restrict__ in_keys, const uint32_t* __restrict__ in_rids,
                                                            uint32_t rid_base, const uint32_t* __restrict__ chunk_off,
