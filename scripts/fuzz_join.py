@@ -1,0 +1,105 @@
+"""Randomised parity fuzz of golap_join against the CPU oracle (developer tool; test infrastructure, not product).
+usage (GPU box): python scripts/fuzz_join.py SECONDS [SEED]
+
+Every round draws sizes, a key distribution, a join type, a strategy and (sometimes) experiment hooks that force the
+rarely-taken device paths (pass structures, no-histogram passes and their overflow fallbacks), runs the HIP join through the
+C ABI and compares the canonicalised pairs bit for bit with oracle.hash_join_outer.  Prints one line per round; exits 1 on the
+first mismatch with the recipe that reproduces it."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+
+import oracle
+from gpu_olap_engine_amd import _native as N
+from gpu_olap_engine_amd.engine import Context
+from np_twin import canonical
+
+HOOKS = ["GOLAP_PASS_BITS", "GOLAP_RESERVE", "GOLAP_RESERVE_SIGMAS", "GOLAP_SLOT_SIGMAS", "GOLAP_NOHIST", "GOLAP_SCATTER"]
+
+
+def draw_keys(rng, n, kind, domain):
+    if n == 0:
+        return np.empty(0, np.int64)
+    if kind == "uniform":
+        return rng.integers(0, domain, n)
+    if kind == "unique":
+        return rng.permutation(max(domain, n))[:n].astype(np.int64)
+    if kind == "hot":                                   # a few keys carry most rows
+        hot = rng.integers(0, domain, 4)
+        k = rng.integers(0, domain, n)
+        m = rng.random(n) < 0.3
+        k[m] = hot[rng.integers(0, 4, int(m.sum()))]
+        return k
+    if kind == "fold":                                  # keys whose hi^lo fold collides (same hash, distinct keys)
+        i = rng.integers(0, max(2, domain // 64), n).astype(np.int64)
+        return (i << 32) | (i ^ rng.integers(0, 4, n))
+    if kind == "wide":
+        return rng.integers(-2**62, 2**62, n)
+    raise ValueError(kind)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    torch.cuda.set_device(0)
+    ctx = Context(profiling=False, max_gpu_memory=0)
+    t_end = time.time() + budget
+    rnd = 0
+    while time.time() < t_end:
+        rnd += 1
+        big = rng.random() < 0.35
+        nb = int(rng.integers(0, 6_000_000 if big else 200_000))
+        npr = int(rng.integers(0, 6_000_000 if big else 200_000))
+        kind = str(rng.choice(["uniform", "unique", "hot", "fold", "wide"]))
+        domain = int(max(1, rng.choice([nb // 4 + 1, nb + 1, 4 * nb + 1, 97])))
+        jt = int(rng.integers(0, 4))
+        strategy = N.JOIN_RADIX_HASH if (rng.random() < 0.8 or nb > 2_000_000) else N.JOIN_BROADCAST_HASH
+        env = {}
+        if strategy == N.JOIN_RADIX_HASH and rng.random() < 0.7:
+            env["GOLAP_PASS_BITS"] = str(rng.choice(["8,6", "8,5", "9,5", "7,7", "8,4,4", "10,6", "8"]))
+            if rng.random() < 0.6:
+                env["GOLAP_RESERVE"] = "1"
+            if rng.random() < 0.3:
+                env["GOLAP_RESERVE_SIGMAS"] = str(rng.choice(["0", "1"]))
+            if rng.random() < 0.3:
+                env["GOLAP_SLOT_SIGMAS"] = str(rng.choice(["0", "1"]))
+            if rng.random() < 0.1:
+                env["GOLAP_NOHIST"] = "0"
+            if rng.random() < 0.1:
+                env["GOLAP_SCATTER"] = str(rng.choice(["v1", "wc", "big"]))
+        b = draw_keys(rng, nb, kind, domain)
+        p = draw_keys(rng, npr, kind if rng.random() < 0.7 else "uniform", domain)
+        if nb and npr and rng.random() < 0.5:           # make sure something matches
+            take = rng.integers(0, nb, min(npr, 1000))
+            p[:take.size] = b[take]
+        if nb and npr:                                  # quadratic blow-ups are not what this is about: count matches first
+            ub, cb = np.unique(b, return_counts=True)
+            up, cp = np.unique(p, return_counts=True)
+            _, ib, ip = np.intersect1d(ub, up, assume_unique=True, return_indices=True)
+            if int((cb[ib].astype(np.int64) * cp[ip]).sum()) > 30_000_000:
+                continue
+        exp, me = oracle.hash_join_outer(b, p, jt)
+        recipe = f"seed={seed} round={rnd} nb={nb} np={npr} kind={kind} domain={domain} jt={jt} strategy={strategy} env={env}"
+        for k in HOOKS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        bt = torch.from_numpy(np.ascontiguousarray(b, dtype=np.int64)).cuda() if nb else torch.empty(0, dtype=torch.int64, device="cuda")
+        pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)).cuda() if npr else torch.empty(0, dtype=torch.int64, device="cuda")
+        pairs, cnt = ctx.join(bt, pt, max_pairs=max(1, me + 8), strategy=strategy, join_type=jt)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        ok = m == me and np.array_equal(canonical(pairs[:m].cpu().numpy().view(np.uint32)), exp)
+        print(("ok   " if ok else "FAIL ") + recipe + f" matches={me}", flush=True)
+        if not ok:
+            sys.exit(1)
+    print(f"fuzz: {rnd} rounds, all equal to the oracle", flush=True)
+
+
+if __name__ == "__main__":
+    main()
