@@ -383,18 +383,29 @@ constexpr int BT_WIN = 4096;                   // rows staged in LDS at a time (
 // histogram path, standing by with run_if = overflow, then redoes the pass exactly).  Rows within a bucket land in
 // tile-completion order, which the join does not depend on.
 struct ReserveArgs {
-    uint32_t* cursor;     // [F] rows reserved so far per bucket (zeroed)
-    uint32_t cap;         // rows provisioned per bucket
-    uint32_t* overflow;   // set to 1 when a bucket outgrew its range
+    uint32_t* cursor;        // [F] rows reserved so far per bucket (zeroed)
+    uint32_t cap;            // rows provisioned per bucket
+    uint32_t* overflow;      // set to 1 when a bucket outgrew its range
+    uint32_t* wide;          // NARROW: set to 1 when a key does not fit 32 bits (and polled: the work-group stops at once)
+    const uint32_t* run_if;  // when non-null the launch is a no-op unless *run_if != 0
 };
 
-template <int PASS_TAG, int BT_RPT, int NT = PT_THREADS, int WIN = BT_WIN, int WPE = 4, bool PF = false, int WU = 8, bool RESERVE = false>
+// NARROW (optimistic 32-bit keys): the partitioned rows are written as ONE array of 8-byte (key32, row id) tuples instead
+// of an 8-byte key array + a 4-byte row-id array: 8 instead of 12 bytes per row through both partition passes and the
+// join, half as many write streams, and a 16-row segment is exactly one 128-byte line.  The kernel checks every key
+// it reads; the first key outside [0, 2^32) raises rs.wide, every work-group stops at its next tile, the later narrow
+// kernels return at once and the 64-bit pipeline -- launched behind with run_if = wide -- does the join instead.
+// hash_int64(k) == hash_int32((u32)k) for such keys, so both forms partition identically.
+
+template <int PASS_TAG, int BT_RPT, int NT = PT_THREADS, int WIN = BT_WIN, int WPE = 4, bool PF = false, int WU = 8, bool RESERVE = false,
+          bool NARROW = false>
 __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __restrict__ in_keys, uint32_t rid_base,
                                                             const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
                                                             const uint32_t* __restrict__ scanned, long long* __restrict__ out_keys,
                                                             uint32_t* __restrict__ out_rids, PassCfg cfg, ReserveArgs rs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [WIN]
+    uint2* s_rows = reinterpret_cast<uint2*>(s_raw);                         // [WIN] (NARROW: tuples instead of s_keys)
     uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + WIN * 8);         // [WIN]
     uint32_t* s_cnt = s_rids + WIN;
     uint32_t* s_start = s_cnt + cfg.F;
@@ -403,7 +414,10 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
     constexpr int BT_TILE = NT * BT_RPT;   // rows per register-resident tile
     constexpr int NW = NT / 64;
     static_assert(BT_TILE <= 65536, "rank is packed into 16 bits");
+    static_assert(!NARROW || RESERVE, "narrow tuples are only written by the reserving form");
+    uint2* out_rows = reinterpret_cast<uint2*>(out_keys);                    // NARROW
 
+    if (RESERVE && rs.run_if && *rs.run_if == 0) return;
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
     if (len == 0) return;
@@ -435,16 +449,21 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                 key[r] = NT_LOAD(&in_keys[rbase + (i < tn ? i : tn - 1)]);
             }
         }
+        if (NARROW && tid == 0) s_w[NW] = __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lds_barrier();
+        if (NARROW && s_w[NW]) return;   // work-group-uniform: some key somewhere did not fit, the 64-bit pipeline takes over
+        bool wide = false;
 #pragma unroll
         for (int r = 0; r < BT_RPT; ++r) {
             const uint32_t i = r * NT + tid;
             br[r] = 0xFFFFFFFFu;
+            if (NARROW) wide |= ((unsigned long long)key[r] >> 32) != 0ull;   // clamped duplicates are real keys too
             if (i < tn) {
                 const uint32_t b = bucket_of(hash_int64(key[r]), cfg);
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 65536
             }
         }
+        if (NARROW && wide) atomicOr(rs.wide, 1u);
         if (PF) {   // next tile (clamped into the chunk: the last tile re-reads valid rows it then ignores)
 #pragma unroll
             for (int r = 0; r < BT_RPT; ++r) {
@@ -488,8 +507,12 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                 {
                     const uint32_t pos = br[r] - w0;   // invalid rows (0xFFFFFFFF) and rows of other windows fall outside
                     if (pos < (uint32_t)WIN) {
-                        s_keys[pos] = key[r];
-                        s_rids[pos] = rid_base + rbase + r * NT + tid;          // join_kernels.cuh:75
+                        if (NARROW) {
+                            s_rows[pos] = make_uint2((uint32_t)key[r], rid_base + rbase + r * NT + tid);
+                        } else {
+                            s_keys[pos] = key[r];
+                            s_rids[pos] = rid_base + rbase + r * NT + tid;          // join_kernels.cuh:75
+                        }
                     }
                 }
             }
@@ -504,12 +527,19 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
             for (int j = 0; j < WIN / NT; ++j) {
                 const uint32_t i = j * NT + tid;
                 if (i < wn) {
-                    const long long k = s_keys[i];
-                    const uint32_t b = bucket_of(hash_int64(k), cfg);
-                    const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
-                    if (!RESERVE || gp < (b + 1u) * rs.cap) {   // rows past a bucket's range are dropped (overflow raised above)
-                        out_keys[gp] = k;
-                        out_rids[gp] = s_rids[i];
+                    if (NARROW) {
+                        const uint2 row = s_rows[i];
+                        const uint32_t b = bucket_of(hash_int32((int32_t)row.x), cfg);   // == hash_int64 of the zero-extended key
+                        const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
+                        if (gp < (b + 1u) * rs.cap) out_rows[gp] = row;
+                    } else {
+                        const long long k = s_keys[i];
+                        const uint32_t b = bucket_of(hash_int64(k), cfg);
+                        const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
+                        if (!RESERVE || gp < (b + 1u) * rs.cap) {   // rows past a bucket's range are dropped (overflow raised above)
+                            out_keys[gp] = k;
+                            out_rids[gp] = s_rids[i];
+                        }
                     }
                 }
             }
@@ -540,6 +570,7 @@ struct FixedArgs {
     uint32_t* sub_start;            // [G*F] out: first row of sub-partition (g, f)
     uint32_t* sub_len;              // [G*F] out: rows of sub-partition (g, f)
     uint32_t* overflow;             // out: set to 1 when any slot overflowed
+    const uint32_t* skip_if;        // when non-null the launch is a no-op if *skip_if != 0 (narrow pipeline abandoned)
 };
 
 __device__ __forceinline__ uint32_t isqrt_u32(uint32_t x) {
@@ -588,26 +619,35 @@ __global__ __launch_bounds__(1024) void k_slots_setup(GroupSrc gs, uint32_t G, u
 constexpr int WC_THREADS = 1024;
 constexpr int WC_WAVES = WC_THREADS / 64;
 constexpr int WC_RPT = 8;
-constexpr int WC_NEW = WC_THREADS * WC_RPT;   // new rows per tile (max)
 constexpr int WC_CAP = 12288;                 // staging rows (carry + new): 144 KiB
 constexpr int WC_MAX_F = 512;                 // carry <= 15 * F = 7680 rows, leaves >= 512 new rows per tile
 constexpr int WC_CARRY_PT = 16 * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
+constexpr int WCN_RPT = 12;                   // narrow tuples (8 B/row): 12288 new rows per tile ...
+constexpr int WCN_CAP = 18432;                // ... in 144 KiB of staging
 
 // LINE = rows per write-combined segment.  16 (a whole 128-byte key line) is the only instantiation: 8-row segments
 // (64-byte key / 32-byte row-id writes) halve the carry but measured 12.4 -> 14.8 ms at 1B rows -- HBM wants whole lines;
 // 32-row segments (256-byte key / 128-byte row-id writes) double the carry, which halves the tile that fits next to it
 // in LDS and spills the carry registers: 12.4 -> 27.7 ms.
-template <int PASS_TAG, bool FIXED, int LINE = 16>
+// RPT / CAP: rows per thread per tile and staging rows (the 8-byte narrow tuples leave room for 12 x 1024-row tiles).
+template <bool NARROW> struct JoinKeyFwd { using type = long long; };
+template <> struct JoinKeyFwd<true> { using type = uint32_t; };
+
+template <int PASS_TAG, bool FIXED, int LINE = 16, bool NARROW = false, int RPT = WC_RPT, int CAP = WC_CAP>
 __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __restrict__ in_keys, const uint32_t* __restrict__ in_rids,
                                                            uint32_t rid_base, const uint32_t* __restrict__ chunk_off,
                                                            const uint32_t* __restrict__ chunk_len, const uint32_t* __restrict__ scanned,
                                                            long long* __restrict__ out_keys, uint32_t* __restrict__ out_rids, PassCfg cfg,
                                                            FixedArgs fx, const uint32_t* __restrict__ run_if) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [WC_CAP]
-    uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + WC_CAP * 8);      // [WC_CAP]
+    long long* s_keys = reinterpret_cast<long long*>(s_raw);                 // [CAP]
+    uint2* s_rows = reinterpret_cast<uint2*>(s_raw);                         // [CAP] (NARROW: (key32, row id) tuples, see ReserveArgs)
+    uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + CAP * 8);      // [CAP]
+    const uint2* in_rows = reinterpret_cast<const uint2*>(in_keys);
+    uint2* out_rows = reinterpret_cast<uint2*>(out_keys);
+    static_assert(!NARROW || FIXED, "narrow tuples only flow through the no-histogram pass");
     const uint32_t F = cfg.F;
-    uint32_t* s_cnt = s_rids + WC_CAP;     // rows of bucket in staging this tile (carry + new)
+    uint32_t* s_cnt = NARROW ? s_rids : s_rids + CAP;   // rows of bucket in staging this tile (carry + new); no row-id plane when NARROW
     uint32_t* s_start = s_cnt + F;         // staging offset of the bucket
     uint32_t* s_gpos = s_start + F;        // global cursor of the bucket (index of its first staged row)
     uint32_t* s_carry = s_gpos + F;        // rows carried into this tile
@@ -616,7 +656,9 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
     uint32_t* s_w = s_emit + F;            // [WC_WAVES]
     uint32_t* s_misc = s_w + WC_WAVES;     // [0] carry total of the next tile
 
+    static_assert(CAP - 15 * WC_MAX_F >= 512, "a tile must always have room for new rows");
     if (run_if && *run_if == 0) return;
+    if (FIXED && fx.skip_if && *fx.skip_if != 0) return;
     const uint32_t chunk = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t len, off, slot0 = 0, cap = 0;
@@ -641,23 +683,30 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         }
     }
     uint32_t consumed = 0;
-    uint32_t t_eff = len < (uint32_t)WC_NEW ? len : (uint32_t)WC_NEW;
-    long long key[WC_RPT];
-    uint32_t rid[WC_RPT];
+    uint32_t t_eff = len < (uint32_t)(RPT * WC_THREADS) ? len : (uint32_t)(RPT * WC_THREADS);
+    typename JoinKeyFwd<NARROW>::type key[RPT];   // 32-bit registers for narrow tuples
+    uint32_t rid[RPT];
 #pragma unroll
-    for (int r = 0; r < WC_RPT; ++r) {   // unconditional loads on clamped indices (t_eff >= 1): all in flight together
+    for (int r = 0; r < RPT; ++r) {   // unconditional loads on clamped indices (t_eff >= 1): all in flight together
         const uint32_t i = r * WC_THREADS + tid;
-        key[r] = NT_LOAD(&in_keys[off + (i < t_eff ? i : t_eff - 1)]);
+        if (NARROW) {
+            const uint2 t = in_rows[off + (i < t_eff ? i : t_eff - 1)];
+            key[r] = t.x;
+            rid[r] = t.y;
+        } else {
+            key[r] = (typename JoinKeyFwd<NARROW>::type)NT_LOAD(&in_keys[off + (i < t_eff ? i : t_eff - 1)]);
+        }
     }
-    if (in_rids) {
+    if (NARROW) {
+    } else if (in_rids) {
 #pragma unroll
-        for (int r = 0; r < WC_RPT; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             const uint32_t i = r * WC_THREADS + tid;
             rid[r] = NT_LOAD(&in_rids[off + (i < t_eff ? i : t_eff - 1)]);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < WC_RPT; ++r) rid[r] = rid_base + off + r * WC_THREADS + tid;   // join_kernels.cuh:75
+        for (int r = 0; r < RPT; ++r) rid[r] = rid_base + off + r * WC_THREADS + tid;   // join_kernels.cuh:75
     }
     for (;;) {
         consumed += t_eff;
@@ -665,12 +714,12 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         if (tid < F) s_cnt[tid] = s_carry[tid];
         if (tid == 0) s_misc[0] = 0;
         lds_barrier();
-        uint32_t br[WC_RPT];
+        uint32_t br[RPT];
 #pragma unroll
-        for (int r = 0; r < WC_RPT; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             const uint32_t i = r * WC_THREADS + tid;
             if (i < t_eff) {
-                const uint32_t b = bucket_of(hash_int64(key[r]), cfg);
+                const uint32_t b = bucket_of(NARROW ? hash_int32((int32_t)key[r]) : hash_int64((long long)key[r]), cfg);
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // rank continues after the carried rows
             }
         }
@@ -698,8 +747,8 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         lds_barrier();
         // carried rows: old staging position -> registers -> new staging position
         constexpr int CARRY_PT = LINE * WC_MAX_F / WC_THREADS;   // carry slots inspected per thread
-        long long ck[CARRY_PT];
-        uint32_t cr[CARRY_PT], cdst[CARRY_PT];
+        long long ck[CARRY_PT];   // NARROW: the tuple's 8 bytes
+        uint32_t cr[NARROW ? 1 : CARRY_PT], cdst[CARRY_PT];
 #pragma unroll
         for (int c8 = 0; c8 < CARRY_PT; ++c8) {
             const uint32_t j = c8 * WC_THREADS + tid, b = j / LINE, k = j % LINE;
@@ -707,7 +756,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
             if (b < F && k < s_carry[b]) {
                 const uint32_t src = s_csrc[b] + k;
                 ck[c8] = s_keys[src];
-                cr[c8] = s_rids[src];
+                if (!NARROW) cr[c8] = s_rids[src];
                 cdst[c8] = s_start[b] + k;
             }
         }
@@ -716,43 +765,54 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         for (int c8 = 0; c8 < CARRY_PT; ++c8) {
             if (cdst[c8] != 0xFFFFFFFFu) {
                 s_keys[cdst[c8]] = ck[c8];
-                s_rids[cdst[c8]] = cr[c8];
+                if (!NARROW) s_rids[cdst[c8]] = cr[c8];
             }
         }
 #pragma unroll
-        for (int r = 0; r < WC_RPT; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             const uint32_t i = r * WC_THREADS + tid;
             if (i < t_eff) {
                 const uint32_t pos = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
-                s_keys[pos] = key[r];
-                s_rids[pos] = rid[r];
+                if (NARROW) {
+                    s_rows[pos] = make_uint2((uint32_t)key[r], rid[r]);
+                } else {
+                    s_keys[pos] = (long long)key[r];
+                    s_rids[pos] = rid[r];
+                }
             }
         }
         lds_barrier();
         // prefetch the next tile while this one is written out
-        const uint32_t room = (uint32_t)WC_CAP - s_misc[0];
+        const uint32_t room = (uint32_t)CAP - s_misc[0];
         uint32_t t_next = 0;
         if (!last) {
             t_next = len - consumed;
-            if (t_next > (uint32_t)WC_NEW) t_next = WC_NEW;
+            if (t_next > (uint32_t)(RPT * WC_THREADS)) t_next = RPT * WC_THREADS;
             if (t_next > room) t_next = room;
         }
         if (t_next) {   // wave-uniform
             const uint32_t nb = off + consumed;
 #pragma unroll
-            for (int r = 0; r < WC_RPT; ++r) {
+            for (int r = 0; r < RPT; ++r) {
                 const uint32_t i = r * WC_THREADS + tid;
-                key[r] = NT_LOAD(&in_keys[nb + (i < t_next ? i : t_next - 1)]);
+                if (NARROW) {
+                    const uint2 t = in_rows[nb + (i < t_next ? i : t_next - 1)];
+                    key[r] = t.x;
+                    rid[r] = t.y;
+                } else {
+                    key[r] = (typename JoinKeyFwd<NARROW>::type)NT_LOAD(&in_keys[nb + (i < t_next ? i : t_next - 1)]);
+                }
             }
-            if (in_rids) {
+            if (NARROW) {
+            } else if (in_rids) {
 #pragma unroll
-                for (int r = 0; r < WC_RPT; ++r) {
+                for (int r = 0; r < RPT; ++r) {
                     const uint32_t i = r * WC_THREADS + tid;
                     rid[r] = NT_LOAD(&in_rids[nb + (i < t_next ? i : t_next - 1)]);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < WC_RPT; ++r) rid[r] = rid_base + nb + r * WC_THREADS + tid;
+                for (int r = 0; r < RPT; ++r) rid[r] = rid_base + nb + r * WC_THREADS + tid;
             }
         }
         // write out: one 16-lane group per 128-byte key line
@@ -767,8 +827,12 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
                 const uint32_t lim = FIXED ? slot0 + (b + 1u) * cap : 0xFFFFFFFFu;   // rows past a slot's end are dropped (flag raised below)
                 for (uint32_t k = ((l - gp) & (uint32_t)(LINE - 1)) + LINE * (q % gpb); k < e; k += LINE * gpb) {   // lane l owns global index == l (mod LINE)
                     if (!FIXED || gp + k < lim) {
-                        out_keys[gp + k] = s_keys[sb + k];
-                        out_rids[gp + k] = s_rids[sb + k];
+                        if (NARROW) {
+                            out_rows[gp + k] = s_rows[sb + k];   // 16 lanes x 8 B = one 128-byte line
+                        } else {
+                            out_keys[gp + k] = s_keys[sb + k];
+                            out_rids[gp + k] = s_rids[sb + k];
+                        }
                     }
                 }
             }
@@ -826,6 +890,25 @@ __device__ __forceinline__ void side_bounds(const JoinSide& S, uint32_t sp, uint
 
 constexpr uint32_t JN_NULL = 0xFFFFFFFFu;   // row id of the missing side of an unmatched row (outer joins)
 
+// row access for the two partitioned layouts: key array + row-id array, or (NARROW) one array of (key32, row id) tuples
+template <bool NARROW> struct JoinKey { using type = long long; };
+template <> struct JoinKey<true> { using type = uint32_t; };
+template <bool NARROW>
+__device__ __forceinline__ void jn_load(const JoinSide& S, uint32_t i, typename JoinKey<NARROW>::type& key, uint32_t& rid) {
+    if (NARROW) {
+        const uint2 t = reinterpret_cast<const uint2*>(S.keys)[i];
+        key = (typename JoinKey<NARROW>::type)t.x;
+        rid = t.y;
+    } else {
+        key = (typename JoinKey<NARROW>::type)S.keys[i];
+        rid = S.rids[i];
+    }
+}
+template <bool NARROW>
+__device__ __forceinline__ uint32_t jn_rid(const JoinSide& S, uint32_t i) {
+    return NARROW ? reinterpret_cast<const uint2*>(S.keys)[i].y : S.rids[i];
+}
+
 // work-group-wide reservation of the output range for one batch: per-slice wave totals are already in
 // s_wt[slice * JN_WAVES + wave]; after the call s_wt holds their exclusive offsets and the return value is the
 // batch's base position (ONE global atomic per batch).  All threads must call it.
@@ -847,14 +930,23 @@ __device__ __forceinline__ unsigned long long jn_reserve(uint32_t* s_wt, unsigne
 // JT: golap_join_type (0 Inner, 1 Left = keep unmatched build rows, 2 Right = keep unmatched probe rows, 3 Full).
 // probe_hit: global bitmap over probe positions, only touched when a sub-partition's build side needs more
 // than one table chunk (then "unmatched" is only known after the last chunk).
-template <int JT>
+// NARROW: both sides are (key32, row id) tuple arrays (see ReserveArgs); gate/gate_skip: run_if / skip_if on the
+// device word that says whether the narrow pipeline was abandoned.
+template <int JT, bool NARROW = false>
 __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
                                                          unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
-                                                         uint32_t* __restrict__ probe_hit) {
+                                                         uint32_t* __restrict__ probe_hit, const uint32_t* __restrict__ run_if,
+                                                         const uint32_t* __restrict__ skip_if) {
     constexpr bool KEEP_B = (JT & 1) != 0, KEEP_P = (JT & 2) != 0;
-    __shared__ long long t_keys[JN_CAP];
+    using KeyT = typename JoinKey<NARROW>::type;
+    // chain heads: 4096 for the 72 KiB wide table (two work-groups per CU either way); 2048 for the narrow one, whose
+    // 48 KiB then fit three work-groups per CU -- the kernel is bound by per-work-group latency chains, not by LDS reads
+    constexpr int LOG2S = NARROW ? JN_LOG2_SLOTS - 1 : JN_LOG2_SLOTS;
+    if (run_if && *run_if == 0) return;
+    if (skip_if && *skip_if != 0) return;
+    __shared__ KeyT t_keys[JN_CAP];
     __shared__ uint32_t t_rids[JN_CAP];
-    __shared__ uint32_t heads[1 << JN_LOG2_SLOTS];
+    __shared__ uint32_t heads[1 << LOG2S];
     __shared__ uint16_t t_next[JN_CAP];
     __shared__ uint8_t t_hit[KEEP_B ? JN_CAP : 4];
     __shared__ uint32_t s_wt[JN_R * JN_WAVES];
@@ -886,7 +978,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 const uint32_t i = c + r * JN_THREADS + tid;
                 if (v[r]) {
                     const unsigned long long pos = base + s_wt[r * JN_WAVES + wv] + lane;   // full waves except the last: lanes are dense
-                    const uint32_t rid = S.rids[i];
+                    const uint32_t rid = jn_rid<NARROW>(S, i);
                     if (pos < max_pairs) out_pairs[pos] = (b1 == b0) ? make_uint2(JN_NULL, rid) : make_uint2(rid, JN_NULL);
                 }
             }
@@ -897,30 +989,28 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
     const bool multi_chunk = b1 - b0 > (uint32_t)JN_CAP;
 
     // the first probe batch is fetched before the table is built: its HBM latency hides behind the build
-    long long pk[JN_R];
+    KeyT pk[JN_R];
     uint32_t prid[JN_R];
 #pragma unroll
     for (int r = 0; r < JN_R; ++r) {   // unconditional loads on clamped indices (p1 > p0): all in flight together
         const uint32_t i = p0 + r * JN_THREADS + tid;
         const uint32_t ic = i < p1 ? i : p1 - 1;
-        pk[r] = P.keys[ic];
-        prid[r] = P.rids[ic];
+        jn_load<NARROW>(P, ic, pk[r], prid[r]);
     }
     for (uint32_t bc = b0; bc < b1; bc += JN_CAP) {
         const uint32_t nb = b1 - bc < (uint32_t)JN_CAP ? b1 - bc : (uint32_t)JN_CAP;
-        for (uint32_t h = tid; h < (1u << JN_LOG2_SLOTS); h += JN_THREADS) heads[h] = JN_EMPTY;
+        for (uint32_t h = tid; h < (1u << LOG2S); h += JN_THREADS) heads[h] = JN_EMPTY;
         if (KEEP_B)
             for (uint32_t h = tid; h < (uint32_t)JN_CAP; h += JN_THREADS) t_hit[h] = 0;
         lds_barrier();
         {
-            long long bk[JN_CAP / JN_THREADS];
+            KeyT bk[JN_CAP / JN_THREADS];
             uint32_t brd[JN_CAP / JN_THREADS];
 #pragma unroll
             for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {   // the whole table chunk is requested before the first insert
                 const uint32_t i = r * JN_THREADS + tid;
                 const uint32_t ic = bc + (i < nb ? i : nb - 1);
-                bk[r] = B.keys[ic];
-                brd[r] = B.rids[ic];
+                jn_load<NARROW>(B, ic, bk[r], brd[r]);
             }
 #pragma unroll
             for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {
@@ -928,7 +1018,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 if (i < nb) {
                     t_keys[i] = bk[r];
                     t_rids[i] = brd[r];
-                    const uint32_t old = atomicExch(&heads[slot_hash(bk[r], JN_LOG2_SLOTS)], i);   // join_kernels.cuh:109
+                    const uint32_t old = atomicExch(&heads[slot_hash((long long)bk[r], LOG2S)], i);   // join_kernels.cuh:109
                     t_next[i] = (uint16_t)old;                                                     // :110 (0xFFFFFFFF -> 0xFFFF)
                 }
             }
@@ -944,8 +1034,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 const bool ok = i < p1;
                 if (reload) {   // wave-uniform; clamped like the preload
                     const uint32_t ic = ok ? i : p1 - 1;
-                    pk[r] = P.keys[ic];
-                    prid[r] = P.rids[ic];
+                    jn_load<NARROW>(P, ic, pk[r], prid[r]);
                 }
                 first[r] = ok ? 0u : JN_EMPTY;   // marks invalid rows until the head is read
             }
@@ -955,7 +1044,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 uint32_t c = 0, f = 0xFFFFu;
                 const bool valid = first[r] != JN_EMPTY;
                 if (valid) {
-                    uint32_t e = heads[slot_hash(pk[r], JN_LOG2_SLOTS)] & 0xFFFFu;
+                    uint32_t e = heads[slot_hash((long long)pk[r], LOG2S)] & 0xFFFFu;
                     while (e != 0xFFFFu) {
                         if (t_keys[e] == pk[r]) {   // full-key compare (:152-153)
                             if (c == 0) f = e;
@@ -1049,7 +1138,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 const uint32_t i = pc + r * JN_THREADS + tid;
                 if (v[r]) {
                     const unsigned long long pos = base + s_wt[r * JN_WAVES + wv] + lpb[r];
-                    if (pos < max_pairs) out_pairs[pos] = make_uint2(JN_NULL, P.rids[i]);
+                    if (pos < max_pairs) out_pairs[pos] = make_uint2(JN_NULL, jn_rid<NARROW>(P, i));
                 }
             }
             lds_barrier();
@@ -1372,7 +1461,7 @@ struct SegTable {
 };
 
 static size_t scatter_lds_bytes(uint32_t F) { return (size_t)PT_TILE * 12 + (size_t)F * 12 + PT_WAVES * 4 + 16; }
-static size_t scatter_wc_lds_bytes(uint32_t F) { return (size_t)WC_CAP * 12 + (size_t)F * 24 + WC_WAVES * 4 + 64; }
+static size_t scatter_wc_lds_bytes(uint32_t F, uint32_t cap = WC_CAP, uint32_t row_bytes = 12) { return (size_t)cap * row_bytes + (size_t)F * 24 + WC_WAVES * 4 + 64; }
 
 // write-combining scatter for fan-outs where a tile's runs are short; the plain tile scatter otherwise
 // Measured on MI355X (1B rows, fan-out 512): the write-combining scatter wins when a work-group's
@@ -1481,8 +1570,12 @@ static uint64_t side_small_bytes(const JoinPlan& plan, uint64_t n_rows, uint32_t
 
 // Runs all passes for one side.  `in_keys`/`in_rids` describe pass 0's input; when
 // `segs` is non-null pass 0's groups are the local partition slots fed by segments.
+// `gate` (device word, may be null): when non-null this whole side only does work if *gate != 0 -- the 64-bit pipeline
+// standing by behind the optimistic narrow one (run_side_narrow); only valid for the reserving + no-histogram flow, whose
+// every non-stand-by kernel takes a run_if.
 static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPlan& plan, uint64_t in_keys, uint64_t in_rids,
-                        uint32_t rid_base, uint64_t n_rows, const SegTable* segs, const SideBuffers& buf, SideResult& res) {
+                        uint32_t rid_base, uint64_t n_rows, const SegTable* segs, const SideBuffers& buf, SideResult& res,
+                        const uint32_t* gate = nullptr) {
     const size_t np = plan.passes.size();
     uint64_t cur_keys = in_keys, cur_rids = in_rids;
     const uint32_t* prev_scanned = nullptr;
@@ -1493,6 +1586,8 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     const char* pfx = !strcmp(side, "part") ? "partition" : (segs ? "local" : "radix");
     const bool fast_last = use_fast_last_pass(plan, segs != nullptr);
     const bool reserve_first = use_reserve_first_pass(plan, n_rows, segs != nullptr, in_rids != 0);
+    if (gate && !(fast_last && reserve_first)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "gated side without the no-histogram flow");
+    const char* sfx = gate ? "_wide" : "";
     const uint32_t* run_if = nullptr;
     GroupSrc groups{};   // how the current pass finds its groups in the previous pass's output
     for (size_t k = 0; k < np; ++k) {
@@ -1516,11 +1611,12 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             PassCfg cfg = pp.cfg;
             cfg.S = nc;
             {
-                KernelTimer t(ctx, "radix_scatter_p1", st, 20 * n_rows);
+                snprintf(name, sizeof name, "radix_scatter_p1%s", sfx);
+                KernelTimer t(ctx, name, st, gate ? 0 : 20 * n_rows);
 #define GOLAP_RSV(RPT, WIN, WU)                                                                                                            \
     hipLaunchKernelGGL((k_scatter_big<1, RPT, 1024, WIN, 4, false, WU, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F, WIN, 1024), st,      \
                        (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,         \
-                       (long long*)buf.tmp_keys[0], (uint32_t*)buf.tmp_rids[0], cfg, ReserveArgs{cursor, cap, flag1})
+                       (long long*)buf.tmp_keys[0], (uint32_t*)buf.tmp_rids[0], cfg, ReserveArgs{cursor, cap, flag1, nullptr, gate})
                 const char* e = getenv("GOLAP_RESERVE");   // A/B hook: kernel variant
                 const int v = e ? atoi(e) : 3;
                 if (v == 2) GOLAP_RSV(24, 12288, 2);
@@ -1547,15 +1643,15 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             uint32_t sigmas = 6, pad = 48;
             if (const char* env = getenv("GOLAP_SLOT_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }   // test hook: 0 forces overflows
             hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F, sigmas, pad, slot_base, slot_cap);
-            FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, flag};
+            FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, flag, nullptr};
             PassCfg cfg = pp.cfg;
             cfg.S = 1;
             {
-                snprintf(name, sizeof name, "%s_scatter_p%zu", pfx, k + 1);
-                KernelTimer t(ctx, name, st, 24 * n_rows);
+                snprintf(name, sizeof name, "%s_scatter_p%zu%s", pfx, k + 1, sfx);
+                KernelTimer t(ctx, name, st, gate ? 0 : 24 * n_rows);
                 hipLaunchKernelGGL((k_scatter_wc<2, true>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F), st, (const long long*)cur_keys,
                                    (const uint32_t*)cur_rids, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                   (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, (const uint32_t*)nullptr);
+                                   (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, gate);
             }
             GOLAP_HIP_TRY(ctx, hipGetLastError());
             res.alt_start = sub_start;
@@ -1644,6 +1740,7 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_BIG_ATTR(16, 768, 6144, 6, false);
     GOLAP_BIG_ATTR(20, 640, 5120, 5, false);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, true);
+    GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, true, true);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 2, true);
     GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 5, true);
     GOLAP_BIG_ATTR(18, 1024, 9216, 4, false);
@@ -1661,6 +1758,8 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     {
         const void* wcs[] = {(const void*)k_scatter_wc<1, false>, (const void*)k_scatter_wc<2, false>, (const void*)k_scatter_wc<3, false>,
                              (const void*)k_scatter_wc<2, true>};
+        GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<2, true, 16, true, WCN_RPT, WCN_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)scatter_wc_lds_bytes(WC_MAX_F, WCN_CAP, 8)));
         for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
     }
     done = true;
@@ -1679,33 +1778,109 @@ static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint
     const uint64_t tmax = std::max(pass1_rows(plan, n_build, has_segs), pass1_rows(plan, n_probe, has_segs));
     bytes += n_tmp * (round_up(tmax * 8, 256) + round_up(tmax * 4, 256));
     bytes += 2 * (round_up((uint64_t)PT_MAX_F * 4, 256) + 512);   // first-pass reservation cursors + flags
+    if (np == 2)                                                   // narrow pipeline: cursors, chunk descriptors, slot arrays (both sides)
+        bytes += 2 * (round_up((uint64_t)PT_MAX_F * 4, 256) + 2 * round_up(2048 * 4, 256) + 2 * round_up((uint64_t)(plan.passes[1].G + 1) * 4, 256) +
+                      2 * round_up((uint64_t)plan.passes[1].G * plan.passes[1].cfg.F * 4, 256)) + 4096;
     bytes += side_small_bytes(plan, n_build, n_src, has_segs) + side_small_bytes(plan, n_probe, n_src, has_segs);
     bytes += 2 * round_up((uint64_t)4096 * 4 * 2, 256);   // segment tables
     return bytes + (1 << 20);
 }
 
-// shared tail: both sides partitioned -> LDS join
+// shared tail: both sides partitioned -> LDS join.  narrow: both sides are (key32, row id) tuple arrays; run_if / skip_if:
+// device gates of the narrow-then-wide scheme (see ReserveArgs); probe_hit_shared: bitmap allocated by the caller.
 static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, const SideResult& b, const SideResult& p, uint64_t n_build,
-                               uint64_t n_probe, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, int32_t join_type = 0) {
+                               uint64_t n_probe, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, int32_t join_type = 0,
+                               bool narrow = false, const uint32_t* run_if = nullptr, const uint32_t* skip_if = nullptr,
+                               uint32_t* probe_hit_shared = nullptr) {
     JoinSide B{b.keys, b.rids, b.off, b.stride, b.alt_start, b.alt_len, b.flag}, P{p.keys, p.rids, p.off, p.stride, p.alt_start, p.alt_len, p.flag};
-    uint32_t* probe_hit = nullptr;
-    if (join_type & 2) {   // Right / Full: bitmap over probe positions for the (rare) multi-chunk sub-partitions
+    uint32_t* probe_hit = probe_hit_shared;
+    if ((join_type & 2) && !probe_hit) {   // Right / Full: bitmap over probe positions for the (rare) multi-chunk sub-partitions
         const uint64_t words = ceil_div(std::max<uint64_t>(1, std::max(n_probe, p.positions)), 32) + 1;
         probe_hit = (uint32_t*)ws_take(ctx, words * 4);
         if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (probe bitmap)");
         GOLAP_TRY(zero_async(ctx, st, (void*)(probe_hit), words * 4));
     }
-    KernelTimer t(ctx, "join_build_probe_lds", st, 12 * (n_build + n_probe));
+    const uint64_t row_bytes = narrow ? 8 : 12;
+    KernelTimer t(ctx, run_if ? "join_build_probe_lds_wide" : "join_build_probe_lds", st, run_if ? 0 : row_bytes * (n_build + n_probe));
     const dim3 grid((uint32_t)plan.n_sub), block(JN_THREADS);
     unsigned long long* oc = (unsigned long long*)out_count;
+#define GOLAP_JN(JT)                                                                                                                     \
+    if (narrow)                                                                                                                          \
+        hipLaunchKernelGGL((k_join_lds<JT, true>), grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, \
+                           run_if, skip_if);                                                                                             \
+    else                                                                                                                                 \
+        hipLaunchKernelGGL((k_join_lds<JT, false>), grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, \
+                           run_if, skip_if)
     switch (join_type) {
-        case 0: hipLaunchKernelGGL(k_join_lds<0>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
-        case 1: hipLaunchKernelGGL(k_join_lds<1>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
-        case 2: hipLaunchKernelGGL(k_join_lds<2>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
-        default: hipLaunchKernelGGL(k_join_lds<3>, grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit); break;
+        case 0: GOLAP_JN(0); break;
+        case 1: GOLAP_JN(1); break;
+        case 2: GOLAP_JN(2); break;
+        default: GOLAP_JN(3); break;
     }
+#undef GOLAP_JN
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     return GOLAP_OK;
+}
+
+// Optimistic narrow pipeline for one side (see ReserveArgs): reserving first pass + no-histogram second pass over
+// (key32, row id) tuples.  Anything that does not fit -- a key outside [0, 2^32), a bucket or slot overflow -- raises
+// *wide and the 64-bit pipeline behind takes over; there is no stand-by path of its own.
+static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, uint64_t in_keys, uint32_t rid_base, uint64_t n_rows,
+                               uint64_t tmp_rows, uint64_t final_rows_ptr, uint32_t* wide, const uint32_t* zero_word, SideResult& res) {
+    const PassPlan& p1 = plan.passes[0];
+    const PassPlan& p2 = plan.passes[1];
+    const uint32_t F1 = p1.cfg.F, G = p2.G, F2 = p2.cfg.F;
+    const uint32_t cap1 = (uint32_t)reserve_cap(n_rows, F1);
+    uint32_t chunk_rows = 0;
+    const uint32_t nc = first_pass_chunks(n_rows, &chunk_rows);
+    uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F1 * 4);
+    uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
+    uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
+    uint32_t* slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(G + 1) * 4);
+    uint32_t* slot_cap = (uint32_t*)ws_take(ctx, (uint64_t)G * 4);
+    uint32_t* sub_start = (uint32_t*)ws_take(ctx, (uint64_t)G * F2 * 4);
+    uint32_t* sub_len = (uint32_t*)ws_take(ctx, (uint64_t)G * F2 * 4);
+    if (!cursor || !c_off || !c_len || !slot_base || !slot_cap || !sub_start || !sub_len)
+        return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (narrow pipeline arrays)");
+    GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F1 * 4));
+    hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_rows, chunk_rows, nc, c_off, c_len);
+    {
+        PassCfg cfg = p1.cfg;
+        cfg.S = nc;
+        KernelTimer t(ctx, "radix_scatter_p1", st, 16 * n_rows);
+        hipLaunchKernelGGL((k_scatter_big<1, 24, 1024, 12288, 4, false, 3, true, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F1, 12288, 1024), st,
+                           (const long long*)in_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,
+                           (long long*)tmp_rows, (uint32_t*)nullptr, cfg, ReserveArgs{cursor, cap1, wide, wide, nullptr});
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    GroupSrc groups{nullptr, 0, cursor, cap1, zero_word};
+    uint32_t sigmas = 6, pad = 48;
+    if (const char* env = getenv("GOLAP_SLOT_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }
+    hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F2, sigmas, pad, slot_base, slot_cap);
+    {
+        FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, wide, wide};
+        PassCfg cfg = p2.cfg;
+        cfg.S = 1;
+        KernelTimer t(ctx, "radix_scatter_p2", st, 16 * n_rows);
+        hipLaunchKernelGGL((k_scatter_wc<2, true, 16, true, WCN_RPT, WCN_CAP>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F2, WCN_CAP, 8), st, (const long long*)tmp_rows,
+                           (const uint32_t*)nullptr, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                           (long long*)final_rows_ptr, (uint32_t*)nullptr, cfg, fx, (const uint32_t*)nullptr);
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    res = SideResult();
+    res.keys = (const long long*)final_rows_ptr;
+    res.alt_start = sub_start;
+    res.alt_len = sub_len;
+    res.flag = zero_word;
+    res.positions = final_rows(plan, n_rows, false);
+    return GOLAP_OK;
+}
+
+// Narrow keys are tried when both sides take the reserving + no-histogram flow (large two-pass joins).
+static bool use_narrow_keys(const JoinPlan& plan, uint64_t n_build, uint64_t n_probe) {
+    const char* env = getenv("GOLAP_NARROW");   // "0" disables (A/B hook)
+    if (env && !strcmp(env, "0")) return false;
+    return use_reserve_first_pass(plan, n_build, false, false) && use_reserve_first_pass(plan, n_probe, false, false);
 }
 
 static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipStream_t st) {
@@ -1734,9 +1909,30 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     // number of non-final passes beyond 2 the k&1 indexing below stays within the 2 temps.
     JoinPlan plan_b = plan, plan_p = plan;
     SideResult rb, rp;
-    GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build_key_ptr, 0, p->build_rid_base, p->n_build, nullptr, bb, rb));
-    GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe_key_ptr, 0, p->probe_rid_base, p->n_probe, nullptr, pb, rp));
-    GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type));
+    const uint32_t* gate = nullptr;
+    uint32_t* probe_hit = nullptr;
+    if (use_narrow_keys(plan, p->n_build, p->n_probe)) {
+        // optimistic 32-bit pipeline first (its big buffers alias the 64-bit pipeline's: only one of the two does any work)
+        uint32_t* words = (uint32_t*)ws_take(ctx, 8);   // [0] wide flag, [1] constant 0
+        if (!words) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+        GOLAP_TRY(zero_async(ctx, st, (void*)words, 8));
+        if (p->join_type & 2) {
+            const uint64_t nw = ceil_div(std::max<uint64_t>(1, std::max(p->n_probe, fp)), 32) + 1;
+            probe_hit = (uint32_t*)ws_take(ctx, nw * 4);
+            if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (probe bitmap)");
+            GOLAP_TRY(zero_async(ctx, st, (void*)probe_hit, nw * 4));
+        }
+        SideResult nb_, np_;
+        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->build_key_ptr, p->build_rid_base, p->n_build, bb.tmp_keys[0], bb.final_keys, words, words + 1, nb_));
+        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->probe_key_ptr, p->probe_rid_base, p->n_probe, pb.tmp_keys[0], pb.final_keys, words, words + 1, np_));
+        GOLAP_TRY(launch_lds_join(ctx, st, plan, nb_, np_, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type,
+                                  true, nullptr, words, probe_hit));
+        gate = words;
+    }
+    GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build_key_ptr, 0, p->build_rid_base, p->n_build, nullptr, bb, rb, gate));
+    GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe_key_ptr, 0, p->probe_rid_base, p->n_probe, nullptr, pb, rp, gate));
+    GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type, false, gate,
+                              nullptr, probe_hit));
     ws_end(ctx, st);
     return GOLAP_OK;
 }
