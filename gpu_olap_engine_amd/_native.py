@@ -114,7 +114,8 @@ class Stats(C.Structure):
 class JoinPlan(C.Structure):
     _fields_ = [("bits1", C.c_uint32), ("bits2", C.c_uint32), ("tile_rows", C.c_uint32), ("chunks1", C.c_uint32),
                 ("slots2", C.c_uint32), ("table_capacity", C.c_uint32), ("n_subpartitions", C.c_uint64),
-                ("no_histogram_last_pass", C.c_uint32), ("no_histogram_first_pass", C.c_uint32)]
+                ("no_histogram_last_pass", C.c_uint32), ("no_histogram_first_pass", C.c_uint32),
+                ("optimistic_narrow_keys", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 # every symbol include/golap.h declares: name -> (restype, argtypes)

@@ -932,18 +932,15 @@ __device__ __forceinline__ unsigned long long jn_reserve(uint32_t* s_wt, unsigne
 // than one table chunk (then "unmatched" is only known after the last chunk).
 // NARROW: both sides are (key32, row id) tuple arrays (see ReserveArgs); gate/gate_skip: run_if / skip_if on the
 // device word that says whether the narrow pipeline was abandoned.
-template <int JT, bool NARROW = false>
-__global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
-                                                         unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
-                                                         uint32_t* __restrict__ probe_hit, const uint32_t* __restrict__ run_if,
-                                                         const uint32_t* __restrict__ skip_if) {
+template <int JT, bool NARROW>
+__device__ __forceinline__ void join_sub_partition(const uint32_t sp, const JoinSide& B, const JoinSide& P, uint2* __restrict__ out_pairs,
+                                                   unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
+                                                   uint32_t* __restrict__ probe_hit) {
     constexpr bool KEEP_B = (JT & 1) != 0, KEEP_P = (JT & 2) != 0;
     using KeyT = typename JoinKey<NARROW>::type;
     // chain heads: 4096 for the 72 KiB wide table (two work-groups per CU either way); 2048 for the narrow one, whose
     // 48 KiB then fit three work-groups per CU -- the kernel is bound by per-work-group latency chains, not by LDS reads
     constexpr int LOG2S = NARROW ? JN_LOG2_SLOTS - 1 : JN_LOG2_SLOTS;
-    if (run_if && *run_if == 0) return;
-    if (skip_if && *skip_if != 0) return;
     __shared__ KeyT t_keys[JN_CAP];
     __shared__ uint32_t t_rids[JN_CAP];
     __shared__ uint32_t heads[1 << LOG2S];
@@ -952,7 +949,6 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
     __shared__ uint32_t s_wt[JN_R * JN_WAVES];
     __shared__ unsigned long long s_base;
 
-    const uint32_t sp = blockIdx.x;
     uint32_t b0, b1, p0, p1;
     side_bounds(B, sp, b0, b1);
     side_bounds(P, sp, p0, p1);
@@ -1142,6 +1138,26 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
                 }
             }
             lds_barrier();
+        }
+    }
+}
+
+// One sub-partition per work-group in the normal launch (grid = number of sub-partitions: the hardware dispatcher
+// balances them); the gated 64-bit stand-by launch uses a small grid that strides, so that standing by costs a few
+// microseconds instead of dispatching 262144 empty work-groups (0.11 ms).
+template <int JT, bool NARROW = false, bool STRIDE = false>
+__global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
+                                                         unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
+                                                         uint32_t* __restrict__ probe_hit, uint32_t n_sub, const uint32_t* __restrict__ run_if,
+                                                         const uint32_t* __restrict__ skip_if) {
+    if (run_if && *run_if == 0) return;
+    if (skip_if && *skip_if != 0) return;
+    if (!STRIDE) {
+        join_sub_partition<JT, NARROW>(blockIdx.x, B, P, out_pairs, out_count, max_pairs, probe_hit);
+    } else {
+        for (uint32_t sp = blockIdx.x; sp < n_sub; sp += gridDim.x) {
+            join_sub_partition<JT, NARROW>(sp, B, P, out_pairs, out_count, max_pairs, probe_hit);
+            if (sp + gridDim.x < n_sub) lds_barrier();   // the LDS table is reused by the next sub-partition (no wait for the stores in flight)
         }
     }
 }
@@ -1802,15 +1818,19 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     }
     const uint64_t row_bytes = narrow ? 8 : 12;
     KernelTimer t(ctx, run_if ? "join_build_probe_lds_wide" : "join_build_probe_lds", st, run_if ? 0 : row_bytes * (n_build + n_probe));
-    const dim3 grid((uint32_t)plan.n_sub), block(JN_THREADS);
+    const uint32_t n_sub = (uint32_t)plan.n_sub;
+    uint32_t stride_grid = 4096u;
+    if (const char* e = getenv("GOLAP_JOIN_STRIDE_GRID")) stride_grid = (uint32_t)std::max(1, atoi(e));   // debug hook
+    const dim3 grid(run_if ? std::min<uint32_t>(n_sub, stride_grid) : n_sub), block(JN_THREADS);   // stand-by launch: small striding grid
     unsigned long long* oc = (unsigned long long*)out_count;
-#define GOLAP_JN(JT)                                                                                                                     \
-    if (narrow)                                                                                                                          \
-        hipLaunchKernelGGL((k_join_lds<JT, true>), grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, \
-                           run_if, skip_if);                                                                                             \
-    else                                                                                                                                 \
-        hipLaunchKernelGGL((k_join_lds<JT, false>), grid, block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, \
-                           run_if, skip_if)
+#define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if
+#define GOLAP_JN(JT)                                                                                          \
+    if (narrow)                                                                                               \
+        hipLaunchKernelGGL((k_join_lds<JT, true, false>), grid, block, 0, st, GOLAP_JN_ARGS);                 \
+    else if (run_if)                                                                                          \
+        hipLaunchKernelGGL((k_join_lds<JT, false, true>), grid, block, 0, st, GOLAP_JN_ARGS);                 \
+    else                                                                                                      \
+        hipLaunchKernelGGL((k_join_lds<JT, false, false>), grid, block, 0, st, GOLAP_JN_ARGS)
     switch (join_type) {
         case 0: GOLAP_JN(0); break;
         case 1: GOLAP_JN(1); break;
@@ -1818,6 +1838,7 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
         default: GOLAP_JN(3); break;
     }
 #undef GOLAP_JN
+#undef GOLAP_JN_ARGS
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     return GOLAP_OK;
 }
@@ -2037,6 +2058,7 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
     out->slots2 = plan.passes.size() < 2 ? 0 : (use_fast_last_pass(plan, false) ? 1 : slots_for(plan.passes[1].G, n_build));
     out->no_histogram_last_pass = use_fast_last_pass(plan, false) ? 1 : 0;
     out->no_histogram_first_pass = use_reserve_first_pass(plan, n_build, false, false) ? 1 : 0;
+    out->optimistic_narrow_keys = use_narrow_keys(plan, n_build, n_build) ? 1 : 0;   // (for a probe side of the same size class)
     out->table_capacity = JN_CAP;
     out->n_subpartitions = plan.n_sub;
     return GOLAP_OK;

@@ -120,7 +120,7 @@ class Context:
     def join_plan(self, n_build, n_owners=1):
         p = N.JoinPlan()
         self._ck(self._lib.golap_join_plan_get(self._h, n_build, n_owners, C.byref(p)))
-        return {f: getattr(p, f) for f, _ in p._fields_}
+        return {f: getattr(p, f) for f, _ in p._fields_ if not f.startswith("reserved")}
 
     def join_scratch_bytes(self, n_build, n_probe):
         return self._lib.golap_join_scratch_bytes(self._h, n_build, n_probe)

@@ -337,6 +337,9 @@ typedef struct golap_join_plan {
     uint64_t n_subpartitions;
     uint32_t no_histogram_last_pass;   /* 1 when pass 2 writes into pre-provisioned slots */
     uint32_t no_histogram_first_pass;  /* 1 when pass 1 reserves its bucket ranges by atomics instead of a histogram */
+    uint32_t optimistic_narrow_keys;   /* 1 when the join first tries 8-byte (key32, row id) tuples; a key outside [0, 2^32)
+                                          hands over to the 64-bit pipeline on the device */
+    uint32_t reserved0;
 } golap_join_plan;
 int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners, golap_join_plan* out);
 

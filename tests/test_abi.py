@@ -91,7 +91,7 @@ def test_join_plan_is_host_only(lib):
         assert (p.bits1, p.bits2) == (b1, b2), n
         assert p.n_subpartitions == 1 << (b1 + b2) and p.table_capacity == 4096 and p.tile_rows in (4096, 12288, 24576)
         assert p.no_histogram_last_pass == (1 if b2 >= 5 else 0) and p.chunks1 >= 1
-        assert p.no_histogram_first_pass == (1 if n >= 100_000_000 else 0)
+        assert p.no_histogram_first_pass == (1 if n >= 100_000_000 else 0) and p.optimistic_narrow_keys == p.no_histogram_first_pass
         assert p.tile_rows == (24576 if n >= 100_000_000 else 12288 if b1 >= 7 else 4096)
 
 

@@ -306,6 +306,37 @@ def test_asymmetric_sides_mix_first_pass_forms(ctx, nb, npr):
     assert int(cnt.item()) == npr and int(v[0]) == npr and int(v[2]) == npr * (npr - 1) // 2
 
 
+@pytest.mark.parametrize("shape", ["narrow", "all_wide", "one_wide_key_last", "negative_key_first"])
+def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
+    """Large joins first try 8-byte (key32, row id) tuples; any key outside [0, 2^32) -- in the first tile or in the very last
+    row -- must hand the whole join over to the 64-bit pipeline on the device, with identical results (checked on the device:
+    every pair key-equal, probe ids a permutation)."""
+    n = 60_000_000
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    orphans = 0
+    if shape == "all_wide":
+        bt += 1 << 40
+        pt += 1 << 40
+    elif shape != "narrow":
+        idx, key = (n - 1, (1 << 35) + 7) if shape == "one_wide_key_last" else (0, -5)
+        old = int(bt[idx].item())
+        bt[idx] = key
+        pt[idx] = key                                                  # the planted pair
+        orphans = int((pt == old).sum().item())                        # probe rows whose build key is gone now
+    out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    ctx.stats_reset()
+    pairs, cnt = ctx.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
+    m = int(cnt.item())
+    v = ctx.verify_pairs(pairs, m, bt, pt).cpu().numpy().view(np.uint64)
+    st = ctx.stats()
+    assert int(v[0]) == m and m == n - orphans                         # every emitted pair joins equal keys; none missing
+    if orphans == 0:
+        assert int(v[2]) == n * (n - 1) // 2                           # every probe row exactly once
+    wide_ms, narrow_ms = st["join_build_probe_lds_wide"]["total_ms"], st["join_build_probe_lds"]["total_ms"]
+    assert (wide_ms < narrow_ms) if shape == "narrow" else (wide_ms > narrow_ms)   # which pipeline did the work (the other returns at once)
+
+
 @pytest.mark.parametrize("bits", ["8,4,4", "10,6", "8,7"])
 def test_forced_pass_structures(ctx, bits):
     """every pass structure must give the same pairs (GOLAP_PASS_BITS experiment hook)."""
