@@ -10,12 +10,16 @@
 //   * the per-row global atomicAdd of :72 is replaced by histogram -> flat exclusive scan -> LDS-staged
 //     scatter; three scatter kernels, chosen per pass:
 //       k_scatter      4096-row LDS tile, rows regrouped by bucket, contiguous runs       (small fan-outs)
-//       k_scatter_big  register-resident 12288-row tile pushed through the LDS window     (global first pass)
+//       k_scatter_big  register-resident 12288/24576-row tile pushed through the LDS window (global first pass)
 //       k_scatter_wc   line-aligned write combining: per-bucket carries in LDS, every     (local passes)
 //                      128-byte key line written once, whole, by one 16-lane group
 //   * partitioning is applied repeatedly (radix_shift, :53, is the hook the reference leaves for that)
-//     until a sub-partition's build side fits a 4096-row LDS table; the last of two passes needs no
-//     histogram (one work-group per group, slot-provisioned sub-partitions, device-side overflow fallback);
+//     until a sub-partition's build side fits a 4096-row LDS table; large two-pass joins read no histogram
+//     at all: the first pass reserves its bucket ranges with per-tile atomics (RESERVE), the second writes
+//     into slot-provisioned sub-partitions (FIXED), each with a device-side overflow flag and the exact
+//     histogram path standing by behind it (run_if);
+//   * optimistic narrow keys (NARROW): those joins first run on 8-byte (key32, row id) tuples; the first key
+//     outside [0, 2^32) flips a device word and the 64-bit pipeline, enqueued behind, does the join instead;
 //   * build/probe run on LDS tables (ds atomics), matches are counted first, the output range is
 //     reserved with ONE global atomic per work-group batch and the pairs are written with wavefront
 //     ballot/prefix compaction -- not one global atomic per match (:155); Left/Right/Full variants;

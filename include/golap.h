@@ -182,9 +182,11 @@ typedef struct golap_join_params {
                                  row is row id 0xFFFFFFFF.  The reference's kernels are inner-only.  */
 } golap_join_params;
 
-/* Inner join on int64 keys; row ids are 0-based positions + *_rid_base.  Pair
+/* Join on int64 keys; row ids are 0-based positions + *_rid_base.  Pair
  * order is unspecified (as in the reference, join_kernels.cuh:155); compare
- * after sorting by (probe_row_id, build_row_id). */
+ * after sorting by (probe_row_id, build_row_id).  Any int64 key is accepted;
+ * when every key of a large join lies in [0, 2^32) the partitioned rows travel
+ * as 8-byte (key32, row id) tuples -- decided on the device, invisible here. */
 int32_t golap_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_join_params* params, void* stream);
 
 /* Scratch bytes golap_join(RadixHashJoin) will take from the slab allocator. */
