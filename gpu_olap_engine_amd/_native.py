@@ -72,7 +72,7 @@ class JoinParams(C.Structure):
 class PartitionParams(C.Structure):
     _fields_ = [("key_ptr", C.c_uint64), ("row_id_ptr", C.c_uint64), ("n_rows", C.c_uint64), ("rid_base", C.c_uint32),
                 ("n_owners", C.c_uint32), ("extra_bits", C.c_uint32), ("out_key_ptr", C.c_uint64), ("out_row_id_ptr", C.c_uint64),
-                ("out_offsets_ptr", C.c_uint64)]
+                ("out_offsets_ptr", C.c_uint64), ("narrow", C.c_uint32), ("reserved0", C.c_uint32), ("wide_flag_ptr", C.c_uint64)]
 
 
 class PartitionedSide(C.Structure):
@@ -88,7 +88,7 @@ class JoinPartitionedParams(C.Structure):
 
 class JoinPartitionedPlan(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("n_sources", C.c_uint32), ("pre_bits", C.c_uint32), ("total_build_rows_hint", C.c_uint64),
-                ("build_rows", C.c_uint64), ("probe_rows", C.c_uint64)]
+                ("build_rows", C.c_uint64), ("probe_rows", C.c_uint64), ("narrow", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class AggregateSpec(C.Structure):
@@ -146,6 +146,7 @@ SIGNATURES = {
     "golap_radix_partition": (C.c_int32, [_VP, _P(PartitionParams), _VP]),
     "golap_join_partitioned": (C.c_int32, [_VP, _P(JoinPartitionedParams), _VP]),
     "golap_join_partitioned_begin": (C.c_int32, [_VP, _P(JoinPartitionedPlan), _VP]),
+    "golap_join_partitioned_narrow_ok": (C.c_int32, [_P(JoinPartitionedPlan)]),
     "golap_join_partitioned_side": (C.c_int32, [_VP, C.c_int32, _P(PartitionedSide), _VP]),
     "golap_join_partitioned_finish": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_agg_identity_value": (C.c_int64, [C.c_int32]),

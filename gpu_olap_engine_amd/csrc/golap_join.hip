@@ -145,10 +145,12 @@ __global__ void k_setup_from_segments(const uint32_t* __restrict__ seg_off, cons
 // bucket-major so that ONE flat exclusive scan yields every output position.
 //   hist[(g*F + f)*S + s]
 // ---------------------------------------------------------------------------
-template <int PASS_TAG>   // only gives each pass its own kernel name in profiles
+// NARROW_IN: the input is an array of (key32, row id) tuples (see ReserveArgs).  wide_flag (int64 input only, may be
+// null): set to 1 when a key lies outside [0, 2^32) -- the caller then must not use a narrow scatter of these rows.
+template <int PASS_TAG, bool NARROW_IN = false>   // PASS_TAG only gives each pass its own kernel name in profiles
 __global__ __launch_bounds__(PT_THREADS) void k_hist(const long long* __restrict__ in_keys, const uint32_t* __restrict__ chunk_off,
                                                      const uint32_t* __restrict__ chunk_len, uint32_t* __restrict__ hist, PassCfg cfg,
-                                                     const uint32_t* __restrict__ run_if = nullptr) {
+                                                     const uint32_t* __restrict__ run_if = nullptr, uint32_t* __restrict__ wide_flag = nullptr) {
     __shared__ uint32_t s_cnt[PT_MAX_F];
     if (run_if && *run_if == 0) return;
     const uint32_t chunk = blockIdx.x;
@@ -158,17 +160,37 @@ __global__ __launch_bounds__(PT_THREADS) void k_hist(const long long* __restrict
     const uint32_t tid = threadIdx.x;
     for (uint32_t f = tid; f < cfg.F; f += PT_THREADS) s_cnt[f] = 0;
     lds_barrier();
-    const long long* __restrict__ k = in_keys + off;
     uint32_t i = tid;
-    // 8 independent loads in flight per thread
-    for (; i + 7 * PT_THREADS < len; i += 8 * PT_THREADS) {
-        long long v[8];
+    if (NARROW_IN) {
+        const uint2* __restrict__ t = reinterpret_cast<const uint2*>(in_keys) + off;
+        for (; i + 7 * PT_THREADS < len; i += 8 * PT_THREADS) {
+            uint32_t v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = k[i + r * PT_THREADS];
+            for (int r = 0; r < 8; ++r) v[r] = t[i + r * PT_THREADS].x;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) atomicAdd(&s_cnt[bucket_of(hash_int64(v[r]), cfg)], 1u);
+            for (int r = 0; r < 8; ++r) atomicAdd(&s_cnt[bucket_of(hash_int32((int32_t)v[r]), cfg)], 1u);
+        }
+        for (; i < len; i += PT_THREADS) atomicAdd(&s_cnt[bucket_of(hash_int32((int32_t)t[i].x), cfg)], 1u);
+    } else {
+        const long long* __restrict__ k = in_keys + off;
+        unsigned long long hi = 0;
+        // 8 independent loads in flight per thread
+        for (; i + 7 * PT_THREADS < len; i += 8 * PT_THREADS) {
+            long long v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = k[i + r * PT_THREADS];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                hi |= (unsigned long long)v[r];
+                atomicAdd(&s_cnt[bucket_of(hash_int64(v[r]), cfg)], 1u);
+            }
+        }
+        for (; i < len; i += PT_THREADS) {
+            hi |= (unsigned long long)k[i];
+            atomicAdd(&s_cnt[bucket_of(hash_int64(k[i]), cfg)], 1u);
+        }
+        if (wide_flag && (hi >> 32)) atomicOr(wide_flag, 1u);
     }
-    for (; i < len; i += PT_THREADS) atomicAdd(&s_cnt[bucket_of(hash_int64(k[i]), cfg)], 1u);
     lds_barrier();
     const uint32_t g = chunk / cfg.S, s = chunk % cfg.S;
     for (uint32_t f = tid; f < cfg.F; f += PT_THREADS) hist[((size_t)g * cfg.F + f) * cfg.S + s] = s_cnt[f];
@@ -418,7 +440,6 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
     constexpr int BT_TILE = NT * BT_RPT;   // rows per register-resident tile
     constexpr int NW = NT / 64;
     static_assert(BT_TILE <= 65536, "rank is packed into 16 bits");
-    static_assert(!NARROW || RESERVE, "narrow tuples are only written by the reserving form");
     uint2* out_rows = reinterpret_cast<uint2*>(out_keys);                    // NARROW
 
     if (RESERVE && rs.run_if && *rs.run_if == 0) return;
@@ -453,21 +474,21 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                 key[r] = NT_LOAD(&in_keys[rbase + (i < tn ? i : tn - 1)]);
             }
         }
-        if (NARROW && tid == 0) s_w[NW] = __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (NARROW && RESERVE && tid == 0) s_w[NW] = __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lds_barrier();
-        if (NARROW && s_w[NW]) return;   // work-group-uniform: some key somewhere did not fit, the 64-bit pipeline takes over
+        if (NARROW && RESERVE && s_w[NW]) return;   // work-group-uniform: some key somewhere did not fit, the 64-bit pipeline takes over
         bool wide = false;
 #pragma unroll
         for (int r = 0; r < BT_RPT; ++r) {
             const uint32_t i = r * NT + tid;
             br[r] = 0xFFFFFFFFu;
-            if (NARROW) wide |= ((unsigned long long)key[r] >> 32) != 0ull;   // clamped duplicates are real keys too
+            if (NARROW && RESERVE) wide |= ((unsigned long long)key[r] >> 32) != 0ull;   // clamped duplicates are real keys too
             if (i < tn) {
                 const uint32_t b = bucket_of(hash_int64(key[r]), cfg);
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 65536
             }
         }
-        if (NARROW && wide) atomicOr(rs.wide, 1u);
+        if (NARROW && RESERVE && wide) atomicOr(rs.wide, 1u);   // (the histogram form was checked by its k_hist)
         if (PF) {   // next tile (clamped into the chunk: the last tile re-reads valid rows it then ignores)
 #pragma unroll
             for (int r = 0; r < BT_RPT; ++r) {
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                         const uint2 row = s_rows[i];
                         const uint32_t b = bucket_of(hash_int32((int32_t)row.x), cfg);   // == hash_int64 of the zero-extended key
                         const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
-                        if (gp < (b + 1u) * rs.cap) out_rows[gp] = row;
+                        if (!RESERVE || gp < (b + 1u) * rs.cap) out_rows[gp] = row;
                     } else {
                         const long long k = s_keys[i];
                         const uint32_t b = bucket_of(hash_int64(k), cfg);
@@ -649,7 +670,6 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
     uint32_t* s_rids = reinterpret_cast<uint32_t*>(s_raw + CAP * 8);      // [CAP]
     const uint2* in_rows = reinterpret_cast<const uint2*>(in_keys);
     uint2* out_rows = reinterpret_cast<uint2*>(out_keys);
-    static_assert(!NARROW || FIXED, "narrow tuples only flow through the no-histogram pass");
     const uint32_t F = cfg.F;
     uint32_t* s_cnt = NARROW ? s_rids : s_rids + CAP;   // rows of bucket in staging this tile (carry + new); no row-id plane when NARROW
     uint32_t* s_start = s_cnt + F;         // staging offset of the bucket
@@ -1510,8 +1530,25 @@ static bool use_big_scatter(uint32_t F, bool local_pass, bool has_rids) {
 template <int TAG>
 static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids, uint32_t rid_base,
                                 const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys, uint32_t* out_rids,
-                                const PassCfg& cfg, const uint32_t* run_if, uint64_t n_rows) {
-    if (hist) {
+                                const PassCfg& cfg, const uint32_t* run_if, uint64_t n_rows, int narrow, uint32_t* wide_flag) {
+    // narrow: 0 = 64-bit rows; 1 = int64 keys in, (key32, row id) tuples out (exchange-time partition: big-tile scatter);
+    //         2 = tuples in and out (segment-fed local passes: write-combining scatter).  Callers check *_narrow_ok first.
+    if (narrow && hist) {
+        if (narrow == 1)
+            hipLaunchKernelGGL((k_hist<TAG, false>), dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if, wide_flag);
+        else
+            hipLaunchKernelGGL((k_hist<TAG, true>), dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if, (uint32_t*)nullptr);
+    } else if (narrow == 1) {
+        if (n_chunks >= 512 && n_rows / n_chunks >= 4 * 24576)
+            hipLaunchKernelGGL((k_scatter_big<1, 24, 1024, 12288, 4, false, 3, false, true>), dim3(n_chunks), dim3(1024), scatter_big_lds_bytes(cfg.F, 12288, 1024),
+                               st, keys, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, ReserveArgs{});
+        else
+            hipLaunchKernelGGL((k_scatter_big<1, 24, 512, 4096, 4, false, 8, false, true>), dim3(n_chunks), dim3(512), scatter_big_lds_bytes(cfg.F, 4096, 512), st,
+                               keys, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, ReserveArgs{});
+    } else if (narrow == 2) {
+        hipLaunchKernelGGL((k_scatter_wc<TAG, false, 16, true>), dim3(n_chunks), dim3(WC_THREADS), scatter_wc_lds_bytes(cfg.F, WC_CAP, 8), st, keys,
+                           (const uint32_t*)nullptr, rid_base, c_off, c_len, hist_arr, out_keys, (uint32_t*)nullptr, cfg, FixedArgs{}, run_if);
+    } else if (hist) {
         hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if);
     } else if (!wc && use_big_scatter(cfg.F, false, rids != nullptr) && TAG == 1) {
         const char* e = getenv("GOLAP_BIG_RPT");   // A/B hook: "<variant>"
@@ -1555,11 +1592,12 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
 
 static void launch_pass_kernel(int tag, bool hist, bool wc, uint32_t n_chunks, hipStream_t st, const long long* keys, const uint32_t* rids,
                                uint32_t rid_base, const uint32_t* c_off, const uint32_t* c_len, uint32_t* hist_arr, long long* out_keys,
-                               uint32_t* out_rids, const PassCfg& cfg, const uint32_t* run_if = nullptr, uint64_t n_rows = 0) {
+                               uint32_t* out_rids, const PassCfg& cfg, const uint32_t* run_if = nullptr, uint64_t n_rows = 0, int narrow = 0,
+                               uint32_t* wide_flag = nullptr) {
     switch (tag) {
-        case 0: launch_hist_scatter<1>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows); break;
-        case 1: launch_hist_scatter<2>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows); break;
-        default: launch_hist_scatter<3>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows); break;
+        case 0: launch_hist_scatter<1>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows, narrow, wide_flag); break;
+        case 1: launch_hist_scatter<2>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows, narrow, wide_flag); break;
+        default: launch_hist_scatter<3>(hist, wc, n_chunks, st, keys, rids, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, run_if, n_rows, narrow, wide_flag); break;
     }
 }
 
@@ -1595,7 +1633,7 @@ static uint64_t side_small_bytes(const JoinPlan& plan, uint64_t n_rows, uint32_t
 // every non-stand-by kernel takes a run_if.
 static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPlan& plan, uint64_t in_keys, uint64_t in_rids,
                         uint32_t rid_base, uint64_t n_rows, const SegTable* segs, const SideBuffers& buf, SideResult& res,
-                        const uint32_t* gate = nullptr) {
+                        const uint32_t* gate = nullptr, int narrow = 0, uint32_t* wide_flag = nullptr) {
     const size_t np = plan.passes.size();
     uint64_t cur_keys = in_keys, cur_rids = in_rids;
     const uint32_t* prev_scanned = nullptr;
@@ -1604,8 +1642,8 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     // profile names: the stand-alone partition step (exchange-time, multi-GPU) and the segment-fed local passes behind
     // it are different kernels/bytes from the single-GPU join's passes
     const char* pfx = !strcmp(side, "part") ? "partition" : (segs ? "local" : "radix");
-    const bool fast_last = use_fast_last_pass(plan, segs != nullptr);
-    const bool reserve_first = use_reserve_first_pass(plan, n_rows, segs != nullptr, in_rids != 0);
+    const bool fast_last = !narrow && use_fast_last_pass(plan, segs != nullptr);
+    const bool reserve_first = !narrow && use_reserve_first_pass(plan, n_rows, segs != nullptr, in_rids != 0);
     if (gate && !(fast_last && reserve_first)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "gated side without the no-histogram flow");
     const char* sfx = gate ? "_wide" : "";
     const uint32_t* run_if = nullptr;
@@ -1712,7 +1750,8 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         {
             snprintf(name, sizeof name, run_if ? "%s_hist_p%zu_standby" : "%s_hist_p%zu", pfx, k + 1);
             KernelTimer t(ctx, name, st, run_if ? 0 : 8 * n_rows);
-            launch_pass_kernel((int)k, true, false, n_chunks, st, (const long long*)cur_keys, nullptr, 0, c_off, c_len, hist, nullptr, nullptr, pp.cfg, run_if);
+            launch_pass_kernel((int)k, true, false, n_chunks, st, (const long long*)cur_keys, nullptr, 0, c_off, c_len, hist, nullptr, nullptr, pp.cfg, run_if, 0,
+                               narrow ? (narrow == 1 && k == 0 ? 1 : 2) : 0, wide_flag);
         }
         GOLAP_TRY(flat_scan(ctx, st, hist, (uint32_t)(L + 1), bsums, run_if));
         const bool last = k + 1 == np;
@@ -1720,9 +1759,11 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         const uint64_t out_rids = last ? buf.final_rids : buf.tmp_rids[k & 1];
         {
             snprintf(name, sizeof name, run_if ? "%s_scatter_p%zu_standby" : "%s_scatter_p%zu", pfx, k + 1);
-            KernelTimer t(ctx, name, st, run_if ? 0 : (cur_rids ? 12 : 8) * n_rows + 12 * n_rows);
+            const int nm = narrow ? (narrow == 1 && k == 0 ? 1 : 2) : 0;
+            KernelTimer t(ctx, name, st, run_if ? 0 : (nm ? 16 : (cur_rids ? 12 : 8) + 12) * n_rows);
             launch_pass_kernel((int)k, false, run_if ? true : use_wc_scatter(pp.cfg.F, pp.G > 1), n_chunks, st, (const long long*)cur_keys,
-                               (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg, run_if, n_rows);
+                               (const uint32_t*)cur_rids, rid_base, c_off, c_len, hist, (long long*)out_keys, (uint32_t*)out_rids, pp.cfg, run_if, n_rows, nm,
+                               wide_flag);
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
         cur_keys = out_keys;
@@ -1761,6 +1802,8 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_BIG_ATTR(20, 640, 5120, 5, false);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, true);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, true, true);
+    GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, false, true);
+    GOLAP_BIG_ATTR(24, 512, 4096, 4, false, 8, false, true);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 2, true);
     GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 5, true);
     GOLAP_BIG_ATTR(18, 1024, 9216, 4, false);
@@ -1781,6 +1824,10 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
         GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<2, true, 16, true, WCN_RPT, WCN_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)scatter_wc_lds_bytes(WC_MAX_F, WCN_CAP, 8)));
         for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
+        const void* wcn[] = {(const void*)k_scatter_wc<1, false, 16, true>, (const void*)k_scatter_wc<2, false, 16, true>,
+                             (const void*)k_scatter_wc<3, false, 16, true>};
+        for (const void* f : wcn)
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F, WC_CAP, 8)));
     }
     done = true;
     return GOLAP_OK;
@@ -1899,6 +1946,15 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     res.flag = zero_word;
     res.positions = final_rows(plan, n_rows, false);
     return GOLAP_OK;
+}
+
+// narrow tuples through the exchange-time partition / the segment-fed local passes need the kernels that have a tuple form
+static bool partition_narrow_ok(uint32_t F, bool has_rids) { return use_big_scatter(F, false, has_rids); }
+static bool local_narrow_ok(const JoinPlan& plan) {
+    for (const PassPlan& pp : plan.passes)
+        if (pp.cfg.F < 32 || pp.cfg.F > (uint32_t)WC_MAX_F) return false;
+    const char* env = getenv("GOLAP_SCATTER");
+    return !(env && !strcmp(env, "v1"));
 }
 
 // Narrow keys are tried when both sides take the reserving + no-histogram flow (large two-pass joins).
@@ -2073,7 +2129,8 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
 int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* p, void* stream) {
     if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (!p->out_offsets_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_offsets_ptr is null");
-    if (p->n_rows && (!p->key_ptr || !p->out_key_ptr || !p->out_row_id_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
+    if (p->n_rows && (!p->key_ptr || !p->out_key_ptr || (!p->out_row_id_ptr && !p->narrow))) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
+    if (p->narrow && (p->row_id_ptr || !p->wide_flag_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "narrow partition needs implicit row ids and a wide_flag_ptr");
     if (p->n_owners == 0 || (p->n_owners & (p->n_owners - 1)) || p->n_owners > 256)
         return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_owners must be a power of two <= 256");
     if (p->extra_bits > 2) return fail(ctx, GOLAP_ERR_INVALID_ARG, "extra_bits must be 0..2");
@@ -2104,7 +2161,9 @@ int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* p, v
     buf.final_keys = p->out_key_ptr;
     buf.final_rids = p->out_row_id_ptr;
     SideResult res;
-    GOLAP_TRY(run_side(ctx, st, "part", plan, p->key_ptr, p->row_id_ptr, p->rid_base, p->n_rows, nullptr, buf, res));
+    if (p->narrow && !partition_narrow_ok(F, false)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "no tuple form of this partition pass");
+    GOLAP_TRY(run_side(ctx, st, "part", plan, p->key_ptr, p->row_id_ptr, p->rid_base, p->n_rows, nullptr, buf, res, nullptr, p->narrow ? 1 : 0,
+                       (uint32_t*)p->wide_flag_ptr));
     // offsets[s] = scanned[s * S] for s in 0..F (the scan carries the total in its last slot)
     GOLAP_HIP_TRY(ctx, hipMemcpy2DAsync((void*)p->out_offsets_ptr, 4, res.off, (size_t)res.stride * 4, 4, F + 1, hipMemcpyDeviceToDevice, st));
     ws_end(ctx, st);
@@ -2124,6 +2183,7 @@ struct PartJoinState {
     SideBuffers buf[2];
     SideResult res[2];
     bool done[2] = {false, false};
+    bool narrow = false;
 };
 
 static PartJoinState& pjs_of(golap_ctx* ctx) {
@@ -2131,18 +2191,8 @@ static PartJoinState& pjs_of(golap_ctx* ctx) {
     return *(PartJoinState*)ctx->pjs.get();
 }
 
-static int32_t part_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, hipStream_t st) {
-    if (p->n_groups == 0 || p->n_groups > 1024 || (p->n_groups & (p->n_groups - 1))) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_groups must be a power of two <= 1024");
-    if (p->n_sources == 0 || p->n_sources > 64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_sources must be in 1..64");
-    if (p->pre_bits < 8 || p->pre_bits > 12) return fail(ctx, GOLAP_ERR_INVALID_ARG, "pre_bits must be in 8..12");
-    if (p->build_rows >= 0xFFFFFFF0ull || p->probe_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "too many rows for u32 offsets");
-    PartJoinState& S = pjs_of(ctx);
-    S = PartJoinState();
-    S.n_groups = p->n_groups;
-    S.n_sources = p->n_sources;
-    S.rows[0] = p->build_rows;
-    S.rows[1] = p->probe_rows;
-    GOLAP_TRY(ensure_scatter_lds(ctx));
+static void make_local_plan(const golap_join_partitioned_plan* p, JoinPlan& plan) {
+    plan = JoinPlan();
     // Sub-partition fan-out: the rows of one group already share pre_bits hash bits (the exchange-time
     // radix partition), so the local passes start at shift pre_bits.
     const uint64_t hint = p->total_build_rows_hint ? p->total_build_rows_hint : std::max<uint64_t>(1, p->build_rows);
@@ -2169,14 +2219,31 @@ static int32_t part_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, 
             pp.cfg.shift = shift;
             pp.cfg.mode = 0;
             pp.G = G;
-            S.plan.passes.push_back(pp);
+            plan.passes.push_back(pp);
             shift += b;
             G *= pp.cfg.F;
             rest -= b;
         }
-        S.plan.total_bits = shift;
-        S.plan.n_sub = G;
+        plan.total_bits = shift;
+        plan.n_sub = G;
     }
+}
+
+static int32_t part_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, hipStream_t st) {
+    if (p->n_groups == 0 || p->n_groups > 1024 || (p->n_groups & (p->n_groups - 1))) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_groups must be a power of two <= 1024");
+    if (p->n_sources == 0 || p->n_sources > 64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_sources must be in 1..64");
+    if (p->pre_bits < 8 || p->pre_bits > 12) return fail(ctx, GOLAP_ERR_INVALID_ARG, "pre_bits must be in 8..12");
+    if (p->build_rows >= 0xFFFFFFF0ull || p->probe_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "too many rows for u32 offsets");
+    PartJoinState& S = pjs_of(ctx);
+    S = PartJoinState();
+    S.n_groups = p->n_groups;
+    S.n_sources = p->n_sources;
+    S.rows[0] = p->build_rows;
+    S.rows[1] = p->probe_rows;
+    GOLAP_TRY(ensure_scatter_lds(ctx));
+    make_local_plan(p, S.plan);
+    S.narrow = p->narrow != 0;
+    if (S.narrow && !local_narrow_ok(S.plan)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "no tuple form of the local passes (golap_join_partitioned_narrow_ok)");
     const size_t np = S.plan.passes.size();
     GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(S.plan, std::max<uint64_t>(1, p->build_rows), std::max<uint64_t>(1, p->probe_rows), p->n_sources, true) +
                                 (uint64_t)p->n_groups * p->n_sources * 32 + 4096, st));
@@ -2219,7 +2286,8 @@ static int32_t part_side(golap_ctx* ctx, int32_t which, const golap_partitioned_
     GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)d_seg, h_stage.data(), (size_t)nseg * 8, hipMemcpyHostToDevice, st));
     SegTable seg{d_seg, d_seg + (uint64_t)nseg * 4, S.n_sources};
     JoinPlan plan_side = S.plan;
-    GOLAP_TRY(run_side(ctx, st, which ? "probe" : "build", plan_side, side->key_ptr, side->row_id_ptr, 0, side->n_rows, &seg, S.buf[which], S.res[which]));
+    GOLAP_TRY(run_side(ctx, st, which ? "probe" : "build", plan_side, side->key_ptr, S.narrow ? 0 : side->row_id_ptr, 0, side->n_rows, &seg, S.buf[which],
+                       S.res[which], nullptr, S.narrow ? 2 : 0, nullptr));
     return GOLAP_OK;
 }
 
@@ -2229,7 +2297,7 @@ static int32_t part_finish(golap_ctx* ctx, uint64_t out_pairs, uint64_t out_coun
     GOLAP_TRY(zero_async(ctx, st, (void*)((void*)out_count), 8));
     S.active = false;
     if (S.rows[0] == 0 || S.rows[1] == 0) return GOLAP_OK;
-    GOLAP_TRY(launch_lds_join(ctx, st, S.plan, S.res[0], S.res[1], S.rows[0], S.rows[1], out_pairs, out_count, max_pairs));
+    GOLAP_TRY(launch_lds_join(ctx, st, S.plan, S.res[0], S.res[1], S.rows[0], S.rows[1], out_pairs, out_count, max_pairs, 0, S.narrow));
     ws_end(ctx, st);
     return GOLAP_OK;
 }
@@ -2237,6 +2305,15 @@ static int32_t part_finish(golap_ctx* ctx, uint64_t out_pairs, uint64_t out_coun
 }  // namespace golap
 
 extern "C" {
+
+int32_t golap_join_partitioned_narrow_ok(const golap_join_partitioned_plan* p) {
+    if (!p || p->n_groups == 0 || p->pre_bits < 8 || p->pre_bits > 12) return 0;
+    const char* env = getenv("GOLAP_NARROW");
+    if (env && !strcmp(env, "0")) return 0;
+    JoinPlan plan;
+    make_local_plan(p, plan);
+    return local_narrow_ok(plan) && partition_narrow_ok(1u << p->pre_bits, false) ? 1 : 0;
+}
 
 int32_t golap_join_partitioned_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, void* stream) {
     if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");

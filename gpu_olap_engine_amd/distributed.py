@@ -46,11 +46,15 @@ class HipBackend:
         pl = self.ctx.join_plan(max(1, n_build_total))
         return pl["bits1"] + pl["bits2"]
 
-    def radix_partition(self, keys, rid_base, n_owners, extra_bits):
-        return self.ctx.radix_partition(keys, rid_base=rid_base, n_owners=n_owners, extra_bits=extra_bits)
+    def radix_partition(self, keys, rid_base, n_owners, extra_bits, narrow=False):
+        return self.ctx.radix_partition(keys, rid_base=rid_base, n_owners=n_owners, extra_bits=extra_bits, narrow=narrow)
 
-    def join_begin(self, n_groups, n_sources, pre_bits, hint, build_rows, probe_rows):
-        self.ctx.join_partitioned_begin(n_groups, n_sources, pre_bits, hint, build_rows, probe_rows)
+    def narrow_ok(self, n_groups, n_sources, pre_bits, hint):
+        """can the whole partition -> exchange -> local passes -> join flow run on 8-byte (key32, row id) tuples?"""
+        return self.ctx.join_partitioned_narrow_ok(n_groups, n_sources, pre_bits, hint)
+
+    def join_begin(self, n_groups, n_sources, pre_bits, hint, build_rows, probe_rows, narrow=False):
+        self.ctx.join_partitioned_begin(n_groups, n_sources, pre_bits, hint, build_rows, probe_rows, narrow=narrow)
 
     def join_side(self, which, keys, rids, seg_off, seg_len, rows):
         self.ctx.join_partitioned_side(which, keys, rids, seg_off, seg_len, rows)
@@ -70,6 +74,7 @@ class _Exchange:
         self.keys = self.rids = None
         self.n_recv = 0
         self.seg_off, self.seg_len = [], []
+        self.any_wide = False      # narrow exchange only: some rank saw a key outside [0, 2^32) -> nothing was sent
 
     def wait(self):
         for w in self.works:
@@ -78,11 +83,12 @@ class _Exchange:
 
 
 class ShardedJoin:
-    def __init__(self, backend, group=None, max_msg_bytes=1 << 30, extra_bits=None):
+    def __init__(self, backend, group=None, max_msg_bytes=1 << 30, extra_bits=None, narrow=True):
         self.backend = backend
         self.group = group
         self.max_msg_bytes = max_msg_bytes
         self.forced_extra_bits = extra_bits
+        self.narrow = narrow          # try 8-byte (key32, row id) tuples through the exchange (a third less over xGMI)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         if N_PARTITIONS % self.world or self.world & (self.world - 1):
@@ -95,7 +101,7 @@ class ShardedJoin:
             return self.forced_extra_bits
         return max(0, min(2, self.backend.total_bits(n_build_total) - 8 - 9))
 
-    def _exchange_start(self, keys, rids, offs_host, e1, rows_hint):
+    def _exchange_start(self, keys, rids, offs_host, e1, rows_hint, wide_flag=None):
         """keys/rids are partitioned owner-major into (256 << e1) buckets; offs_host are the bucket offsets.
         Starts the all-to-all (async) and returns an _Exchange whose segment table is indexed [group][source],
         group = local bucket index in [0, (256/P) << e1).
@@ -105,28 +111,39 @@ class ShardedJoin:
         every peer's rows one contiguous slice, so nothing is packed; the rank's own partitions are copied on
         the device.  It runs in `rounds` over consecutive bucket ranges so that no single message exceeds
         max_msg_bytes (one 8 GB RCCL message was observed to deliver wrong data on this stack; bounded rounds
-        are also what lets rounds pipeline)."""
+        are also what lets rounds pipeline).
+
+        Narrow exchange (rids is None): `keys` holds (key32, row id) tuples and is the only array sent.  wide_flag (0/1,
+        this rank's partition saw a key outside [0, 2^32)) rides along with the size exchange, so every rank learns the
+        OR over all ranks without another collective; if it is set nothing is sent and x.any_wide tells the caller to
+        start over with 64-bit rows."""
         P = self.world
         per = (N_PARTITIONS // P) << e1
         nb = N_PARTITIONS << e1
         dev = keys.device
         offs = [int(v) for v in offs_host]
         x = _Exchange()
-        sizes = torch.tensor([[offs[r * per + s + 1] - offs[r * per + s] for s in range(per)] for r in range(P)], dtype=torch.int64)
+        narrow = rids is None
+        sizes = torch.tensor([[offs[r * per + s + 1] - offs[r * per + s] for s in range(per)] + [int(bool(wide_flag))] for r in range(P)],
+                             dtype=torch.int64)
         sz_dev = sizes.to(dev).reshape(-1)
         rsz_dev = torch.empty_like(sz_dev)
-        dist.all_to_all_single(rsz_dev, sz_dev, group=self.group)           # sizes[src][bucket] of what I receive
-        rsz = rsz_dev.cpu().reshape(P, per)
+        dist.all_to_all_single(rsz_dev, sz_dev, group=self.group)           # sizes[src][bucket] of what I receive (+ src's flag)
+        rsz_all = rsz_dev.cpu().reshape(P, per + 1)
+        x.any_wide = bool(rsz_all[:, per].any())
+        if x.any_wide:
+            return x
+        rsz = rsz_all[:, :per]
         x.n_recv = int(rsz.sum())
         x.keys = self.backend.empty(max(x.n_recv, 1), torch.int64, keys)
-        x.rids = self.backend.empty(max(x.n_recv, 1), torch.int32, keys)
+        x.rids = None if narrow else self.backend.empty(max(x.n_recv, 1), torch.int32, keys)
         # rounds: every rank must agree WITHOUT another collective -> a bound every rank can compute: no message
         # can carry more rows than one rank holds (rows_hint = global rows / P, identical everywhere)
-        rounds = max(1, min(per, -(-(int(rows_hint) + P) * 8 // self.max_msg_bytes)))
+        rounds = max(1, min(per, -(-(int(rows_hint) + P) * 8 // self.max_msg_bytes)))   # (tuples are 8 bytes as well)
         bounds = [per * j // rounds for j in range(rounds + 1)]
         x.seg_off = [0] * (per * P)
         x.seg_len = [0] * (per * P)
-        x.keep += [keys, rids]
+        x.keep += [keys] if narrow else [keys, rids]
         pos = 0
         me = self.rank
         for j in range(rounds):
@@ -143,15 +160,18 @@ class ShardedJoin:
                     # own partitions never touch the collective: a plain device copy on the compute stream
                     if n_from_r:
                         x.keys[src_base:src_base + n_from_r].copy_(keys[a:b])
-                        x.rids[src_base:src_base + n_from_r].copy_(rids[a:b])
+                        if not narrow:
+                            x.rids[src_base:src_base + n_from_r].copy_(rids[a:b])
                 else:
                     peer = r if self.group is None else dist.get_global_rank(self.group, r)
                     if b > a:
                         ops.append(dist.P2POp(dist.isend, keys[a:b], peer, self.group))
-                        ops.append(dist.P2POp(dist.isend, rids[a:b], peer, self.group))
+                        if not narrow:
+                            ops.append(dist.P2POp(dist.isend, rids[a:b], peer, self.group))
                     if n_from_r:
                         ops.append(dist.P2POp(dist.irecv, x.keys[src_base:src_base + n_from_r], peer, self.group))
-                        ops.append(dist.P2POp(dist.irecv, x.rids[src_base:src_base + n_from_r], peer, self.group))
+                        if not narrow:
+                            ops.append(dist.P2POp(dist.irecv, x.rids[src_base:src_base + n_from_r], peer, self.group))
                 within = 0
                 for s_ in range(s0, s1):
                     x.seg_off[s_ * P + r] = src_base + within
@@ -164,7 +184,7 @@ class ShardedJoin:
         return x
 
     def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs=None, max_pairs=None,
-             n_probe_total=None):
+             n_probe_total=None, _narrow=None):
         """Local shard of the global join -> (pairs [m,2] int32 view of u32 GLOBAL row ids, count tensor, rows received per side).
 
         Schedule (one compute stream + the collective's own stream):
@@ -174,12 +194,34 @@ class ShardedJoin:
         if n_probe_total is None:
             n_probe_total = n_build_total
         e1 = self.extra_bits(n_build_total)
-        bk, br, boff = self.backend.radix_partition(build_keys, build_rid_base, P, e1)
-        xb = self._exchange_start(bk, br, boff.cpu().numpy(), e1, -(-n_build_total // P))
-        pk, pr, poff = self.backend.radix_partition(probe_keys, probe_rid_base, P, e1)
-        xp = self._exchange_start(pk, pr, poff.cpu().numpy(), e1, -(-n_probe_total // P))
         n_groups = (N_PARTITIONS // P) << e1
-        self.backend.join_begin(n_groups, P, 8 + e1, max(1, n_build_total // P), xb.n_recv, xp.n_recv)
+        hint = max(1, n_build_total // P)
+        narrow = self.narrow if _narrow is None else _narrow
+        narrow = bool(narrow) and hasattr(self.backend, "narrow_ok") and self.backend.narrow_ok(n_groups, P, 8 + e1, hint)
+        if narrow:
+            # 8-byte (key32, row id) tuples: valid only if no rank holds a key outside [0, 2^32).  Every rank learns the OR of
+            # all ranks' flags with the size exchange; if it is set, all ranks start over with 64-bit rows (same decision
+            # everywhere, so the collectives stay matched).
+            bk, br, boff, bflag = self.backend.radix_partition(build_keys, build_rid_base, P, e1, narrow=True)
+            boff_h = boff.cpu().numpy()                      # (the flag is final once the offsets are: same stream)
+            xb = self._exchange_start(bk, None, boff_h, e1, -(-n_build_total // P), int(bflag.cpu().item()))
+            if xb.any_wide:
+                return self.join(build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs, max_pairs, n_probe_total, _narrow=False)
+            pk, pr, poff, pflag = self.backend.radix_partition(probe_keys, probe_rid_base, P, e1, narrow=True)
+            poff_h = poff.cpu().numpy()
+            xp = self._exchange_start(pk, None, poff_h, e1, -(-n_probe_total // P), int(pflag.cpu().item()))
+            if xp.any_wide:
+                xb.wait()                                    # the build-side transfers in flight must land before their buffers go
+                return self.join(build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, out_pairs, max_pairs, n_probe_total, _narrow=False)
+        else:
+            bk, br, boff = self.backend.radix_partition(build_keys, build_rid_base, P, e1)
+            xb = self._exchange_start(bk, br, boff.cpu().numpy(), e1, -(-n_build_total // P))
+            pk, pr, poff = self.backend.radix_partition(probe_keys, probe_rid_base, P, e1)
+            xp = self._exchange_start(pk, pr, poff.cpu().numpy(), e1, -(-n_probe_total // P))
+        if narrow:
+            self.backend.join_begin(n_groups, P, 8 + e1, hint, xb.n_recv, xp.n_recv, narrow=True)
+        else:
+            self.backend.join_begin(n_groups, P, 8 + e1, hint, xb.n_recv, xp.n_recv)
         xb.wait()
         self.backend.join_side(0, xb.keys, xb.rids, xb.seg_off, xb.seg_len, xb.n_recv)
         xp.wait()

@@ -213,17 +213,24 @@ class Context:
         self._ck(self._lib.golap_join(self._h, strategy, C.byref(prm), _stream()))
         return out_pairs, out_count
 
-    def radix_partition(self, keys, row_ids=None, rid_base=0, n_owners=1, out_keys=None, out_rids=None, extra_bits=0):
-        """radix_partition_kernel as a stand-alone step -> (keys, row_ids(int32 view of u32), offsets int32[(256<<extra_bits)+1] by slot)."""
+    def radix_partition(self, keys, row_ids=None, rid_base=0, n_owners=1, out_keys=None, out_rids=None, extra_bits=0, narrow=False):
+        """radix_partition_kernel as a stand-alone step -> (keys, row_ids(int32 view of u32), offsets int32[(256<<extra_bits)+1] by slot).
+
+        narrow=True -> (tuples, None, offsets, wide_flag): the rows as ONE int64 tensor of (key32 | row id << 32) tuples; only
+        valid when wide_flag (device int32[1]) reads 0 afterwards (every key in [0, 2^32))."""
         _chk_tensor(keys, torch.int64, "keys")
         n = keys.numel()
         if out_keys is None:
             out_keys = torch.empty(max(n, 1), dtype=torch.int64, device=keys.device)
-        if out_rids is None:
+        if out_rids is None and not narrow:
             out_rids = torch.empty(max(n, 1), dtype=torch.int32, device=keys.device)
         offs = torch.zeros((256 << extra_bits) + 1, dtype=torch.int32, device=keys.device)
-        prm = N.PartitionParams(_ptr(keys), _ptr(row_ids), n, rid_base, n_owners, extra_bits, _ptr(out_keys), _ptr(out_rids), _ptr(offs))
+        flag = torch.zeros(1, dtype=torch.int32, device=keys.device) if narrow else None
+        prm = N.PartitionParams(_ptr(keys), _ptr(row_ids), n, rid_base, n_owners, extra_bits, _ptr(out_keys), _ptr(out_rids), _ptr(offs),
+                                1 if narrow else 0, 0, _ptr(flag))
         self._ck(self._lib.golap_radix_partition(self._h, C.byref(prm), _stream()))
+        if narrow:
+            return out_keys, None, offs, flag
         return out_keys, out_rids, offs
 
     @staticmethod
@@ -247,9 +254,13 @@ class Context:
         self._ck(self._lib.golap_join_partitioned(self._h, C.byref(prm), _stream()))
         return out_pairs, out_count
 
-    def join_partitioned_begin(self, n_groups, n_sources, pre_bits, total_build_rows_hint, build_rows, probe_rows):
-        pl = N.JoinPartitionedPlan(n_groups, n_sources, pre_bits, total_build_rows_hint, build_rows, probe_rows)
+    def join_partitioned_begin(self, n_groups, n_sources, pre_bits, total_build_rows_hint, build_rows, probe_rows, narrow=False):
+        pl = N.JoinPartitionedPlan(n_groups, n_sources, pre_bits, total_build_rows_hint, build_rows, probe_rows, 1 if narrow else 0, 0)
         self._ck(self._lib.golap_join_partitioned_begin(self._h, C.byref(pl), _stream()))
+
+    def join_partitioned_narrow_ok(self, n_groups, n_sources, pre_bits, total_build_rows_hint):
+        pl = N.JoinPartitionedPlan(n_groups, n_sources, pre_bits, total_build_rows_hint, 0, 0, 1, 0)
+        return bool(self._lib.golap_join_partitioned_narrow_ok(C.byref(pl)))
 
     def join_partitioned_side(self, which, keys, rids, seg_off, seg_len, rows=None):
         side = self._side(keys, rids, seg_off, seg_len, rows)

@@ -207,9 +207,16 @@ typedef struct golap_partition_params {
     uint32_t n_owners;         /* 1, 2, 4, 8, ... divides 256 */
     uint32_t extra_bits;       /* 0..2: refine every partition by this many further hash bits (bucket = slot << extra_bits | bits);
                                   out_offsets then has (256 << extra_bits) + 1 entries */
-    uint64_t out_key_ptr;      /* device int64[n_rows] */
-    uint64_t out_row_id_ptr;   /* device u32[n_rows]   */
+    uint64_t out_key_ptr;      /* device int64[n_rows] (narrow: the (key32, row id) tuples, 8 bytes per row) */
+    uint64_t out_row_id_ptr;   /* device u32[n_rows]   (narrow: unused, may be 0) */
     uint64_t out_offsets_ptr;  /* device u32[(256 << extra_bits) + 1] */
+    /* narrow rows for the partition exchange: when `narrow` != 0 the partitioned rows are written as ONE array of 8-byte
+     * (key32, row id) tuples (x = low 32 key bits, y = row id) -- a third less to send over xGMI.  Only valid when every key
+     * lies in [0, 2^32): the call sets *wide_flag_ptr (device u32, zeroed by the caller) to 1 otherwise, and the caller must
+     * then discard the output and partition again with narrow = 0.  Needs row_id_ptr == 0. */
+    uint32_t narrow;
+    uint32_t reserved0;
+    uint64_t wide_flag_ptr;
 } golap_partition_params;
 int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* params, void* stream);
 
@@ -243,7 +250,11 @@ typedef struct golap_join_partitioned_plan {
     uint32_t pre_bits;     /* 8 + extra_bits */
     uint64_t total_build_rows_hint;
     uint64_t build_rows, probe_rows;   /* rows this rank holds after the exchange */
+    uint32_t narrow;       /* != 0: both sides arrive as (key32, row id) tuples in key_ptr (golap_partition_params.narrow); row_id_ptr unused */
+    uint32_t reserved0;
 } golap_join_partitioned_plan;
+/* 1 when the local passes this plan needs exist in tuple form (host-only; ask before partitioning with narrow = 1). */
+int32_t golap_join_partitioned_narrow_ok(const golap_join_partitioned_plan* plan);
 int32_t golap_join_partitioned_begin(golap_ctx* ctx, const golap_join_partitioned_plan* plan, void* stream);
 int32_t golap_join_partitioned_side(golap_ctx* ctx, int32_t which, const golap_partitioned_side* side, void* stream);
 int32_t golap_join_partitioned_finish(golap_ctx* ctx, uint64_t out_pairs_ptr, uint64_t out_count_ptr, uint64_t max_pairs, void* stream);

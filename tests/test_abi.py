@@ -52,7 +52,8 @@ def test_struct_layouts_match_ctypes(tmp_path, lib):
              "golap_filter_predicate": N.FilterPredicate, "golap_filter_params": N.FilterParams, "golap_join_params": N.JoinParams,
              "golap_partition_params": N.PartitionParams, "golap_partitioned_side": N.PartitionedSide,
              "golap_join_partitioned_params": N.JoinPartitionedParams, "golap_aggregate_spec": N.AggregateSpec,
-             "golap_aggregate_params": N.AggregateParams, "golap_kernel_stat": N.KernelStat, "golap_stats": N.Stats, "golap_join_plan": N.JoinPlan}
+             "golap_aggregate_params": N.AggregateParams, "golap_kernel_stat": N.KernelStat, "golap_stats": N.Stats, "golap_join_plan": N.JoinPlan,
+             "golap_join_partitioned_plan": N.JoinPartitionedPlan}
     body = "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names)
     c = tmp_path / "s.c"
     c.write_text(f'#include <stdio.h>\n#include "golap.h"\nint main(void){{{body} return 0;}}\n')

@@ -21,7 +21,10 @@ class OracleBackend:
     def total_bits(self, n_build_total):
         return 17
 
-    def radix_partition(self, keys, rid_base, n_owners, extra_bits):
+    def narrow_ok(self, n_groups, n_sources, pre_bits, hint):
+        return True
+
+    def radix_partition(self, keys, rid_base, n_owners, extra_bits, narrow=False):
         import oracle
         k = keys.numpy()
         h = oracle.hash_int64_array(k).astype(np.int64)
@@ -33,14 +36,26 @@ class OracleBackend:
         nb = 256 << extra_bits
         offs = np.concatenate([[0], np.cumsum(np.bincount(bucket, minlength=nb))])
         rr = (order.astype(np.int64) + rid_base).astype(np.uint32).view(np.int32)
+        if narrow:   # (key32 | row id << 32) tuples + "a key outside [0, 2^32) was seen" (golap_partition_params.narrow)
+            wide = bool(((k < 0) | (k >= (1 << 32))).any())
+            tup = (k[order].astype(np.uint64) & np.uint64(0xFFFFFFFF)) | (rr.view(np.uint32).astype(np.uint64) << np.uint64(32))
+            return torch.from_numpy(tup.view(np.int64).copy()), None, torch.tensor(offs, dtype=torch.int32), torch.tensor([int(wide)], dtype=torch.int32)
         return torch.from_numpy(k[order].copy()), torch.from_numpy(rr.copy()), torch.tensor(offs, dtype=torch.int32)
 
-    def join_begin(self, n_groups, n_sources, pre_bits, hint, build_rows, probe_rows):
+    def join_begin(self, n_groups, n_sources, pre_bits, hint, build_rows, probe_rows, narrow=False):
         self.cfg = (n_groups, n_sources, pre_bits)
         self.sides = {}
+        self.narrow = narrow
+        self.narrow_joins = getattr(self, "narrow_joins", 0) + int(narrow)
 
     def join_side(self, which, keys, rids, seg_off, seg_len, rows):
-        self.sides[which] = (keys[:rows].numpy().copy(), rids[:rows].numpy().view(np.uint32).copy(), list(seg_off), list(seg_len))
+        if self.narrow:
+            assert rids is None
+            t = keys[:rows].numpy().view(np.uint64)
+            k, r = (t & np.uint64(0xFFFFFFFF)).astype(np.int64), (t >> np.uint64(32)).astype(np.uint32)
+        else:
+            k, r = keys[:rows].numpy().copy(), rids[:rows].numpy().view(np.uint32).copy()
+        self.sides[which] = (k, r, list(seg_off), list(seg_len))
 
     def join_finish(self, out_pairs):
         import oracle
@@ -76,7 +91,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, variant, q, max_msg=1 << 30, e1=0):
+def _widen_some(b, p, lo, hi, n, wide):
+    """wide = "" (all keys narrow), "build_last_rank" / "probe_rank0": ONE rank holds ONE key outside [0, 2^32) on one side
+    (the other ranks only learn it through the exchange), "all": every key shifted by 2^40."""
+    b, p = b.copy(), p.copy()
+    if wide == "all":
+        b += 1 << 40
+        p += 1 << 40
+    elif wide == "build_last_rank" and hi == n:
+        b[-1] = -7                                   # an unmatched negative key in the last rank's build shard
+    elif wide == "probe_rank0" and lo == 0:
+        p[0] = (1 << 33) + 5
+    return b, p
+
+
+def _worker(rank, world, port, n, variant, q, max_msg=1 << 30, e1=0, wide=""):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -92,10 +121,14 @@ def _worker(rank, world, port, n, variant, q, max_msg=1 << 30, e1=0):
         else:   # duplicates on both sides + rank 1 holds an empty-ish tail
             b = oracle.gen_sm64_mod(11, lo, hi - lo, n // 2)
             p = oracle.gen_sm64_mod(12, lo, hi - lo, n // 2)
-        sj = ShardedJoin(OracleBackend(), max_msg_bytes=max_msg, extra_bits=e1)
+        b, p = _widen_some(b, p, lo, hi, n, wide)
+        be = OracleBackend()
+        sj = ShardedJoin(be, max_msg_bytes=max_msg, extra_bits=e1)
         out = torch.empty((4 * n, 2), dtype=torch.int32)
         pairs, cnt, nb, npr = sj.join(torch.from_numpy(b), torch.from_numpy(p), lo, lo, n, out_pairs=out)
         m = int(cnt.item())
+        # tuples travelled iff no rank held a key outside [0, 2^32); otherwise every rank fell back together
+        assert be.narrow_joins == (0 if wide else 1)
         # every build/probe row this rank received belongs to a partition it owns (p % world == rank)
         q.put((rank, pairs[:m].numpy().view(np.uint32).copy(), nb, npr))
         dist.barrier()
@@ -103,10 +136,14 @@ def _worker(rank, world, port, n, variant, q, max_msg=1 << 30, e1=0):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,variant,max_msg,e1", [(2, "unique", 1 << 30, 0), (2, "dups", 1 << 30, 1), (4, "unique", 1 << 30, 0),
-                                                        (2, "unique", 20_000, 1), (4, "dups", 7_000, 2)])
-def test_sharded_join_gloo(world, variant, max_msg, e1):
-    """max_msg small -> the exchange runs in several bounded rounds over slot ranges."""
+@pytest.mark.parametrize("world,variant,max_msg,e1,wide", [(2, "unique", 1 << 30, 0, ""), (2, "dups", 1 << 30, 1, ""), (4, "unique", 1 << 30, 0, ""),
+                                                             (2, "unique", 20_000, 1, ""), (4, "dups", 7_000, 2, ""),
+                                                             (2, "unique", 1 << 30, 1, "all"), (4, "dups", 1 << 30, 0, "build_last_rank"),
+                                                             (2, "dups", 9_000, 1, "probe_rank0")])
+def test_sharded_join_gloo(world, variant, max_msg, e1, wide):
+    """max_msg small -> the exchange runs in several bounded rounds over slot ranges.  Rows travel as 8-byte (key32, row id)
+    tuples unless some rank holds a key outside [0, 2^32): then every rank learns it with the size exchange and all fall
+    back to 64-bit rows together (`wide` cases: the offending key sits on one rank only, build or probe side)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     from np_twin import canonical
@@ -114,7 +151,7 @@ def test_sharded_join_gloo(world, variant, max_msg, e1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, variant, q, max_msg, e1)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, variant, q, max_msg, e1, wide)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
@@ -125,6 +162,7 @@ def test_sharded_join_gloo(world, variant, max_msg, e1):
         b, pr = oracle.gen_build_keys(0, n, n), oracle.gen_probe_keys(0, n, n)
     else:
         b, pr = oracle.gen_sm64_mod(11, 0, n, n // 2), oracle.gen_sm64_mod(12, 0, n, n // 2)
+    b, pr = _widen_some(b, pr, 0, n, n, wide)
     exp, me = oracle.hash_join(b, pr)
     got = canonical(np.concatenate([r[1] for r in res]))
     assert got.shape[0] == me and np.array_equal(got, exp)

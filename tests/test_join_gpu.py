@@ -410,8 +410,39 @@ def test_radix_partition_extra_bits(ctx, extra_bits):
     assert np.array_equal(keys[(orr.cpu().numpy().view(np.uint32) - 7).astype(np.int64)], gk)
 
 
-def test_join_partitioned_split_api_with_extra_bits(ctx):
-    """begin / side / side / finish over buckets of 8+1 bits, 2 sources, equals the plain join."""
+def test_radix_partition_narrow_tuples(ctx):
+    """narrow = 1: the same partition written as ONE array of (key32 | row id << 32) tuples; wide_flag reports keys outside [0, 2^32)."""
+    n, P, e1 = 400_000, 4, 1
+    keys = oracle.gen_sm64_mod(35, 0, n, 3_000_000_000)              # needs all 32 bits, but no more
+    kt = torch.from_numpy(keys).cuda()
+    ok, orr, off = ctx.radix_partition(kt, n_owners=P, extra_bits=e1, rid_base=11)
+    tup, none, off2, flag = ctx.radix_partition(kt, n_owners=P, extra_bits=e1, rid_base=11, narrow=True)
+    torch.cuda.synchronize()
+    assert none is None and int(flag.item()) == 0 and torch.equal(off, off2)
+    t = tup.cpu().numpy().view(np.uint64)
+    w = ok.cpu().numpy().astype(np.uint64) | (orr.cpu().numpy().view(np.uint32).astype(np.uint64) << np.uint64(32))
+    bid = np.repeat(np.arange(off.numel() - 1), np.diff(off.cpu().numpy().astype(np.int64)))
+    # the same rows in the same buckets (the order inside a bucket is that of the tile's LDS ranks: not fixed)
+    assert np.array_equal(t[np.lexsort((t, bid))], w[np.lexsort((w, bid))])
+    for bad in (-1, 1 << 32):
+        k2 = kt.clone()
+        k2[n // 2] = bad
+        assert int(ctx.radix_partition(k2, n_owners=P, extra_bits=e1, narrow=True)[3].item()) == 1
+
+
+@pytest.mark.parametrize("narrow", [False, True])
+def test_join_partitioned_split_api_with_extra_bits(ctx, narrow):
+    """begin / side / side / finish over buckets of 8+1 bits, 2 sources, equals the plain join; also with the rows as tuples
+    (the tuple form exists for local fan-outs >= 32, which real inputs reach from ~25M rows per rank: forced here)."""
+    if narrow:
+        os.environ["GOLAP_LOCAL_BITS"] = "6"
+    try:
+        _split_api_case(ctx, narrow)
+    finally:
+        os.environ.pop("GOLAP_LOCAL_BITS", None)
+
+
+def _split_api_case(ctx, narrow):
     n, P, e1 = 500_000, 2, 1
     b = oracle.gen_build_keys(0, n, n)
     p = oracle.gen_probe_keys(0, n, n)
@@ -420,8 +451,10 @@ def test_join_partitioned_split_api_with_extra_bits(ctx):
     h = n // P
     parts = {}
     for name, keys in (("b", b), ("p", p)):
-        parts[name] = [ctx.radix_partition(torch.from_numpy(keys[r * h:(r + 1) * h]).cuda(), rid_base=r * h, n_owners=P, extra_bits=e1) for r in range(P)]
+        parts[name] = [ctx.radix_partition(torch.from_numpy(keys[r * h:(r + 1) * h]).cuda(), rid_base=r * h, n_owners=P, extra_bits=e1, narrow=narrow)
+                       for r in range(P)]
     torch.cuda.synchronize()
+    assert not narrow or ctx.join_partitioned_narrow_ok(((256 // P) << e1), P, 8 + e1, n // P)
     allpairs = []
     for owner in range(P):
         sides = {}
@@ -430,14 +463,16 @@ def test_join_partitioned_split_api_with_extra_bits(ctx):
             ks, rs, so, sl, pos, srcpos = [], [], [], [], 0, []
             for r in range(P):
                 lo, hi = offs[r][owner * per], offs[r][(owner + 1) * per]
-                ks.append(parts[name][r][0][lo:hi]); rs.append(parts[name][r][1][lo:hi]); srcpos.append(pos); pos += hi - lo
+                ks.append(parts[name][r][0][lo:hi]); srcpos.append(pos); pos += hi - lo
+                if not narrow:
+                    rs.append(parts[name][r][1][lo:hi])
             for s_ in range(per):
                 for r in range(P):
                     so.append(int(srcpos[r] + offs[r][owner * per + s_] - offs[r][owner * per]))
                     sl.append(int(offs[r][owner * per + s_ + 1] - offs[r][owner * per + s_]))
-            sides[name] = (torch.cat(ks).contiguous(), torch.cat(rs).contiguous(), so, sl)
+            sides[name] = (torch.cat(ks).contiguous(), None if narrow else torch.cat(rs).contiguous(), so, sl)
         nb_, np_ = sides["b"][0].numel(), sides["p"][0].numel()
-        ctx.join_partitioned_begin(per, P, 8 + e1, n // P, nb_, np_)
+        ctx.join_partitioned_begin(per, P, 8 + e1, n // P, nb_, np_, narrow=narrow)
         ctx.join_partitioned_side(1, *sides["p"], rows=np_)     # probe side first: order must not matter
         ctx.join_partitioned_side(0, *sides["b"], rows=nb_)
         out = torch.empty((np_ + 16, 2), dtype=torch.int32, device="cuda")
