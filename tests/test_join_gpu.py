@@ -594,6 +594,34 @@ def test_join_is_hip_graph_capturable(ctx, strategy):
         assert np.array_equal(canonical(out[:m].cpu().numpy().view(np.uint32)), exp)
 
 
+def test_large_join_graph_replays_pick_the_pipeline_on_the_device(ctx):
+    """The narrow-then-64-bit scheme decides on the device, so ONE captured graph serves both: replayed over narrow keys the
+    tuple pipeline does the join, replayed after the same buffers were refilled with wide keys the 64-bit pipeline does."""
+    n = 60_000_000
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH, out_count=cnt)   # warms the workspace
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        ctx.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH, out_count=cnt)
+    torch.cuda.synchronize()
+    for shift in (0, 1 << 40, 0):
+        bt += shift
+        pt += shift
+        out.zero_(); cnt.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        v = ctx.verify_pairs(out, n, bt, pt).cpu().numpy().view(np.uint64)
+        assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2, shift
+        bt -= shift
+        pt -= shift
+
+
 EDGE_SIZES = [1, 63, 64, 65, 511, 512, 4095, 4096, 4097, 8191, 8192, 8193, 12287, 12288, 12289, 24576, 49153, 131071, 262145]
 
 
