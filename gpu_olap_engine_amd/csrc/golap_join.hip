@@ -1325,6 +1325,7 @@ struct JoinPlan {
     std::vector<PassPlan> passes;
     uint32_t total_bits = 8;
     uint64_t n_sub = 256;
+    bool allow_slots = true;   // false: the slot-padded (no-histogram) layouts would not fit u32 positions for this input
 };
 
 static uint32_t ilog2(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) ++l; return l; }
@@ -1446,7 +1447,7 @@ struct SideResult {
 static bool use_fast_last_pass(const JoinPlan& plan, bool has_segs) {
     const char* env = getenv("GOLAP_NOHIST");   // "0" disables (A/B hook)
     if (env && !strcmp(env, "0")) return false;
-    if (has_segs || plan.passes.size() != 2) return false;
+    if (!plan.allow_slots || has_segs || plan.passes.size() != 2) return false;
     const PassPlan& pp = plan.passes[1];
     return pp.G <= 1024 && pp.cfg.F >= 32 && pp.cfg.F <= (uint32_t)WC_MAX_F;
 }
@@ -1967,9 +1968,13 @@ static bool use_narrow_keys(const JoinPlan& plan, uint64_t n_build, uint64_t n_p
 static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipStream_t st) {
     if (p->n_build >= 0xFFFFFFF0ull || p->n_probe >= 0xFFFFFFF0ull)
         return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32 (join_kernels.cuh:48): at most 2^32-16 rows per side");
+    if ((uint64_t)p->build_rid_base + p->n_build > 0xFFFFFFFFull || (uint64_t)p->probe_rid_base + p->n_probe > 0xFFFFFFFFull)
+        return fail(ctx, GOLAP_ERR_UNSUPPORTED, "rid_base + rows exceeds the u32 row-id range (0xFFFFFFFF is the NULL row id)");
     GOLAP_TRY(ensure_scatter_lds(ctx));
     JoinPlan plan;
     make_plan(p->n_build, 0, true, plan);
+    // positions inside the slot-padded layouts are u32 as well: near 2^32 rows fall back to the dense (histogram) layouts
+    if (final_rows(plan, std::max(p->n_build, p->n_probe), false) >= 0xFFFFFFF0ull) plan.allow_slots = false;
     const size_t np = plan.passes.size();
     GOLAP_TRY(ws_begin(ctx, radix_join_ws_bytes(plan, p->n_build, p->n_probe, 1, false) + final_rows(plan, p->n_probe, false) / 8 + 4096, st));
     SideBuffers bb, pb;
@@ -2108,6 +2113,7 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
     if (n_owners == 0 || (n_owners & (n_owners - 1)) || n_owners > 256) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_owners must be a power of two <= 256");
     JoinPlan plan;
     make_plan(n_build, ilog2(n_owners), true, plan);
+    if (final_rows(plan, n_build, false) >= 0xFFFFFFF0ull) plan.allow_slots = false;
     memset(out, 0, sizeof *out);
     out->bits1 = plan.passes[0].bits;
     out->bits2 = plan.total_bits - plan.passes[0].bits;

@@ -120,6 +120,10 @@ def test_rid_bases(ctx, strategy):
     b = rng.integers(0, 5000, 10000)
     p = rng.integers(0, 5000, 12000)
     check(ctx, b, p, strategy, build_rid_base=1_000_000, probe_rid_base=4_000_000_000)
+    if strategy == N.JOIN_RADIX_HASH:
+        from gpu_olap_engine_amd.engine import GolapError
+        with pytest.raises(GolapError):      # row ids are u32 and 0xFFFFFFFF is the NULL id: base + rows must stay below it
+            run_join(ctx, b, p, strategy, probe_rid_base=0xFFFFFFFF - 5000)
 
 
 @pytest.mark.parametrize("strategy", STRATS)
