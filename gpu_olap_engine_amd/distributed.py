@@ -71,6 +71,7 @@ class _Exchange:
 
     def __init__(self):
         self.works, self.keep = [], []
+        self.staged = []           # (host buffer, device slice): rehearsal transport, see ShardedJoin._exchange_start
         self.keys = self.rids = None
         self.n_recv = 0
         self.seg_off, self.seg_len = [], []
@@ -79,7 +80,9 @@ class _Exchange:
     def wait(self):
         for w in self.works:
             w.wait()          # NCCL: makes the current stream wait; gloo: blocks the host
-        self.works, self.keep = [], []
+        for host_buf, dst in self.staged:
+            dst.copy_(host_buf)
+        self.works, self.keep, self.staged = [], [], []
 
 
 class ShardedJoin:
@@ -126,7 +129,10 @@ class ShardedJoin:
         narrow = rids is None
         sizes = torch.tensor([[offs[r * per + s + 1] - offs[r * per + s] for s in range(per)] + [int(bool(wide_flag))] for r in range(P)],
                              dtype=torch.int64)
-        sz_dev = sizes.to(dev).reshape(-1)
+        # Rehearsal transport: under the gloo backend device tensors are staged through host buffers, so that several
+        # ranks can drive the real kernels on ONE GPU (tests); on RCCL ("nccl") nothing is staged.
+        staged = dev.type == "cuda" and dist.get_backend(self.group) == "gloo"
+        sz_dev = sizes.reshape(-1) if staged else sizes.to(dev).reshape(-1)
         rsz_dev = torch.empty_like(sz_dev)
         dist.all_to_all_single(rsz_dev, sz_dev, group=self.group)           # sizes[src][bucket] of what I receive (+ src's flag)
         rsz_all = rsz_dev.cpu().reshape(P, per + 1)
@@ -164,14 +170,28 @@ class ShardedJoin:
                             x.rids[src_base:src_base + n_from_r].copy_(rids[a:b])
                 else:
                     peer = r if self.group is None else dist.get_global_rank(self.group, r)
+
+                    def out_buf(t):
+                        if not staged:
+                            return t
+                        h = t.cpu()
+                        x.keep.append(h)
+                        return h
+
+                    def in_buf(t):
+                        if not staged:
+                            return t
+                        h = torch.empty(t.shape, dtype=t.dtype)
+                        x.staged.append((h, t))
+                        return h
                     if b > a:
-                        ops.append(dist.P2POp(dist.isend, keys[a:b], peer, self.group))
+                        ops.append(dist.P2POp(dist.isend, out_buf(keys[a:b]), peer, self.group))
                         if not narrow:
-                            ops.append(dist.P2POp(dist.isend, rids[a:b], peer, self.group))
+                            ops.append(dist.P2POp(dist.isend, out_buf(rids[a:b]), peer, self.group))
                     if n_from_r:
-                        ops.append(dist.P2POp(dist.irecv, x.keys[src_base:src_base + n_from_r], peer, self.group))
+                        ops.append(dist.P2POp(dist.irecv, in_buf(x.keys[src_base:src_base + n_from_r]), peer, self.group))
                         if not narrow:
-                            ops.append(dist.P2POp(dist.irecv, x.rids[src_base:src_base + n_from_r], peer, self.group))
+                            ops.append(dist.P2POp(dist.irecv, in_buf(x.rids[src_base:src_base + n_from_r]), peer, self.group))
                 within = 0
                 for s_ in range(s0, s1):
                     x.seg_off[s_ * P + r] = src_base + within

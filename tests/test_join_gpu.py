@@ -504,6 +504,65 @@ def test_bench_sharded_path_single_rank():
     assert d["verify"]["matches"] == 20_000_000 and d["verify"]["probe_id_sum_ok"] and d["verify"]["equal_key_pairs"] == 20_000_000
 
 
+def _gloo_gpu_worker(rank, world, port, n, wide, local_bits, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if local_bits:
+        os.environ["GOLAP_LOCAL_BITS"] = str(local_bits)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as orc
+        from gpu_olap_engine_amd.distributed import HipBackend, ShardedJoin, shard_range
+        from gpu_olap_engine_amd.engine import Context
+        torch.cuda.set_device(0)
+        c = Context(max_gpu_memory=0)
+        lo, hi = shard_range(n, rank, world)
+        b = orc.gen_sm64_mod(11, lo, hi - lo, n // 2)
+        p = orc.gen_sm64_mod(12, lo, hi - lo, n // 2)
+        if wide and rank == world - 1:
+            b[-1] = -3                                                # ONE wide key on ONE rank: everybody must fall back together
+        sj = ShardedJoin(HipBackend(c))
+        out = torch.empty((4 * n, 2), dtype=torch.int32, device="cuda")      # duplicates on both sides: E[M] ~ 2N
+        pairs, cnt, nb, npr = sj.join(torch.from_numpy(b).cuda(), torch.from_numpy(p).cuda(), lo, lo, n, out_pairs=out)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        q.put((rank, pairs[:m].cpu().numpy().view(np.uint32).copy(), nb, npr))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,wide,local_bits", [(2, False, 0), (2, False, 6), (4, False, 6), (2, True, 6)])
+def test_sharded_join_ranks_share_one_gpu_over_gloo(world, wide, local_bits):
+    """Several ranks drive the REAL kernels on this one GPU (HipBackend per rank; the exchange is staged through host memory
+    under gloo): owner-major slices, multi-source segments, global row ids, and -- with local fan-out forced to 64 so that
+    the tuple forms apply at this size -- the narrow exchange and its joint fall-back, bit-exact against the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    n = 3_000_000
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_gloo_gpu_worker, args=(r, world, port, n, wide, local_bits, q)) for r in range(world)]
+    for pr_ in procs:
+        pr_.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for pr_ in procs:
+        pr_.join(timeout=60)
+        assert pr_.exitcode == 0
+    b, p = oracle.gen_sm64_mod(11, 0, n, n // 2), oracle.gen_sm64_mod(12, 0, n, n // 2)
+    if wide:
+        b[-1] = -3
+    exp, me = oracle.hash_join(b, p)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+    assert sum(r[2] for r in res) == n and sum(r[3] for r in res) == n
+
+
 def test_join_partitioned_two_sources(ctx):
     """post-exchange path: 2 sources x 128 slots on one device must equal the plain join."""
     n = 600_000
