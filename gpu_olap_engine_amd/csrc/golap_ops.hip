@@ -37,11 +37,23 @@ __device__ __forceinline__ bool cmp_i64(int op, long long l, long long r) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(OP_THREADS) void k_filter_mask4(const longlong2* __restrict__ col2, unsigned long long n4, int op, long long lit,
                                                              uint32_t* __restrict__ mask4) {
-    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (unsigned long long)gridDim.x * blockDim.x) {
-        const longlong2 a = col2[2 * q], b = col2[2 * q + 1];
-        uint32_t m = (cmp_i64(op, a.x, lit) ? 1u : 0u) | (cmp_i64(op, a.y, lit) ? 1u << 8 : 0u) | (cmp_i64(op, b.x, lit) ? 1u << 16 : 0u) |
-                     (cmp_i64(op, b.y, lit) ? 1u << 24 : 0u);
-        mask4[q] = m;
+    // 4 quads per thread per round, all eight 16-byte loads issued before the first compare (clamped, unconditional)
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long q0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < n4; q0 += 4 * stride) {
+        longlong2 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long q = q0 + u * stride, qc = q < n4 ? q : n4 - 1;
+            a[u] = col2[2 * qc];
+            b[u] = col2[2 * qc + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long q = q0 + u * stride;
+            const uint32_t m = (cmp_i64(op, a[u].x, lit) ? 1u : 0u) | (cmp_i64(op, a[u].y, lit) ? 1u << 8 : 0u) |
+                               (cmp_i64(op, b[u].x, lit) ? 1u << 16 : 0u) | (cmp_i64(op, b[u].y, lit) ? 1u << 24 : 0u);
+            if (q < n4) mask4[q] = m;
+        }
     }
 }
 
