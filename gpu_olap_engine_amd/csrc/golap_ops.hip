@@ -178,14 +178,27 @@ __global__ __launch_bounds__(OP_THREADS) void k_reduce_partials(const long long*
     Acc4 a{0.0, 0.0, GOLAP_F64_MAX, -GOLAP_F64_MAX};   // executor.rs:308-311 seeds
     const long long* vi = (const long long*)val;
     const double* vf = (const double*)val;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        bool keep = true;
-        if (HAS_PRED) keep = cmp_i64(op, key[i], lit);
-        if (keep) {
-            const double x = VAL_F64 ? vf[i] : (double)vi[i];   // executor.rs:521 `as f64`
-            a.sum += x; a.cnt += 1.0;                            // :317-318
-            a.mn = x < a.mn ? x : a.mn;                          // :319-321
-            a.mx = x > a.mx ? x : a.mx;                          // :322-324
+    // 8 rows per thread per round, every load issued before the first use (clamped, unconditional); a thread still folds
+    // its rows in increasing row order, so the partials are bit-identical to a one-row-per-round loop
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 8 * stride) {
+        long long k[8];
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long i = i0 + u * stride, ic = i < n ? i : n - 1;
+            if (HAS_PRED) k[u] = key[ic];
+            x[u] = VAL_F64 ? vf[ic] : (double)vi[ic];   // executor.rs:521 `as f64`
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bool keep = i0 + u * stride < n;
+            if (HAS_PRED) keep = keep && cmp_i64(op, k[u], lit);
+            if (keep) {
+                a.sum += x[u]; a.cnt += 1.0;                       // :317-318
+                a.mn = x[u] < a.mn ? x[u] : a.mn;                  // :319-321
+                a.mx = x[u] > a.mx ? x[u] : a.mx;                  // :322-324
+            }
         }
     }
     block_reduce_acc(a, s);
