@@ -1562,23 +1562,8 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
         switch (v) {
             case 20: GOLAP_BIG(20, 512, 4096, 4, false); break;
             case 16: GOLAP_BIG(16, 512, 4096, 4, false); break;
-            case 1016: GOLAP_BIG(16, 1024, 8192, 4, true); break;    // 16384-row tile, 1 WG/CU, prefetch
             case 1116: GOLAP_BIG(16, 1024, 8192, 4, false); break;
-            case 1024: GOLAP_BIG(24, 1024, 8192, 4, false); break;   // 24576-row tile
-            case 1020: GOLAP_BIG(20, 1024, 8192, 4, false); break;
-            case 768: GOLAP_BIG(16, 768, 6144, 6, false); break;     // 12288-row tile, 80 VGPRs, 2 WG/CU
-            case 640: GOLAP_BIG(20, 640, 5120, 5, false); break;     // 12800-row tile, 96 VGPRs
-            case 1118: GOLAP_BIG(18, 1024, 9216, 4, false); break;   // 18432-row tile, two window rounds
-            case 1120: GOLAP_BIG(20, 1024, 10240, 4, false, 2); break;
-            case 1220: GOLAP_BIG(20, 1024, 10240, 4, false, 5); break;
-            case 1124: GOLAP_BIG(24, 1024, 8192, 4, false, 2); break;
             case 1224: GOLAP_BIG(24, 1024, 12288, 4, false, 3); break;
-            case 1216: GOLAP_BIG(16, 1024, 8192, 4, false, 4); break;
-            case 1316: GOLAP_BIG(16, 1024, 8192, 4, false, 2); break;
-            case 548: GOLAP_BIG(48, 512, 8192, 2, false); break;     // 24576-row tile, 256 VGPRs, 1 WG/CU
-            case 532: GOLAP_BIG(32, 512, 8192, 2, true); break;      // 16384-row tile + prefetch
-            case 248: GOLAP_BIG(48, 256, 4096, 2, false); break;     // 12288-row tile, 256 VGPRs, 2 WG/CU
-            case 232: GOLAP_BIG(32, 256, 4096, 2, true); break;      // 8192-row tile + prefetch, 2 WG/CU
             default: GOLAP_BIG(24, 512, 4096, 4, false); break;
         }
 #undef GOLAP_BIG
@@ -1676,11 +1661,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     hipLaunchKernelGGL((k_scatter_big<1, RPT, 1024, WIN, 4, false, WU, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F, WIN, 1024), st,      \
                        (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,         \
                        (long long*)buf.tmp_keys[0], (uint32_t*)buf.tmp_rids[0], cfg, ReserveArgs{cursor, cap, flag1, nullptr, gate})
-                const char* e = getenv("GOLAP_RESERVE");   // A/B hook: kernel variant
-                const int v = e ? atoi(e) : 3;
-                if (v == 2) GOLAP_RSV(24, 12288, 2);
-                else if (v == 20) GOLAP_RSV(20, 10240, 5);
-                else GOLAP_RSV(24, 12288, 3);
+                GOLAP_RSV(24, 12288, 3);
 #undef GOLAP_RSV
             }
             GOLAP_HIP_TRY(ctx, hipGetLastError());
@@ -1795,29 +1776,12 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
     GOLAP_BIG_ATTR(24, 512, 4096, 4, false);
     GOLAP_BIG_ATTR(20, 512, 4096, 4, false);
     GOLAP_BIG_ATTR(16, 512, 4096, 4, false);
-    GOLAP_BIG_ATTR(16, 1024, 8192, 4, true);
     GOLAP_BIG_ATTR(16, 1024, 8192, 4, false);
-    GOLAP_BIG_ATTR(24, 1024, 8192, 4, false);
-    GOLAP_BIG_ATTR(20, 1024, 8192, 4, false);
-    GOLAP_BIG_ATTR(16, 768, 6144, 6, false);
-    GOLAP_BIG_ATTR(20, 640, 5120, 5, false);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, true);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, true, true);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3, false, true);
     GOLAP_BIG_ATTR(24, 512, 4096, 4, false, 8, false, true);
-    GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 2, true);
-    GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 5, true);
-    GOLAP_BIG_ATTR(18, 1024, 9216, 4, false);
-    GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 2);
-    GOLAP_BIG_ATTR(20, 1024, 10240, 4, false, 5);
-    GOLAP_BIG_ATTR(24, 1024, 8192, 4, false, 2);
     GOLAP_BIG_ATTR(24, 1024, 12288, 4, false, 3);
-    GOLAP_BIG_ATTR(16, 1024, 8192, 4, false, 4);
-    GOLAP_BIG_ATTR(16, 1024, 8192, 4, false, 2);
-    GOLAP_BIG_ATTR(48, 512, 8192, 2, false);
-    GOLAP_BIG_ATTR(32, 512, 8192, 2, true);
-    GOLAP_BIG_ATTR(48, 256, 4096, 2, false);
-    GOLAP_BIG_ATTR(32, 256, 4096, 2, true);
 #undef GOLAP_BIG_ATTR
     {
         const void* wcs[] = {(const void*)k_scatter_wc<1, false>, (const void*)k_scatter_wc<2, false>, (const void*)k_scatter_wc<3, false>,
