@@ -298,16 +298,19 @@ def test_no_histogram_pass_is_taken_and_flag_stays_clear(ctx):
     assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2
 
 
-@pytest.mark.parametrize("nb,npr", [(60_000_000, 1_000_000), (52_000_000, 70_000_000)])
+@pytest.mark.parametrize("nb,npr", [(60_000_000, 1_000_000), (52_000_000, 70_000_000), (60_000_000, 0), (0, 60_000_000), (60_000_000, 1)])
 def test_asymmetric_sides_mix_first_pass_forms(ctx, nb, npr):
     """each side picks its first-pass form by its own size: a 60M-row build side reserves (no histogram) while a 1M-row probe
     side takes the histogram path, and vice versa; checked on the device (every pair key-equal, probe ids a permutation)."""
-    bt = ctx.generate(N.GEN_BUILD_KEYS, nb, modulus=nb)
-    pt = ctx.generate(N.GEN_SM64_MOD_I64, npr, modulus=nb, seed=47)
-    out = torch.empty((npr, 2), dtype=torch.int32, device="cuda")
-    pairs, cnt = ctx.join(bt, pt, out_pairs=out, max_pairs=npr, strategy=N.JOIN_RADIX_HASH)
-    v = ctx.verify_pairs(pairs, npr, bt, pt).cpu().numpy().view(np.uint64)
-    assert int(cnt.item()) == npr and int(v[0]) == npr and int(v[2]) == npr * (npr - 1) // 2
+    bt = ctx.generate(N.GEN_BUILD_KEYS, nb, modulus=max(nb, 1)) if nb else torch.empty(0, dtype=torch.int64, device="cuda")
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, npr, modulus=max(nb, 1), seed=47) if npr else torch.empty(0, dtype=torch.int64, device="cuda")
+    m_exp = npr if nb else 0                                           # an empty side joins to nothing
+    out = torch.empty((max(npr, 1), 2), dtype=torch.int32, device="cuda")
+    pairs, cnt = ctx.join(bt, pt, out_pairs=out, max_pairs=max(npr, 1), strategy=N.JOIN_RADIX_HASH)
+    assert int(cnt.item()) == m_exp
+    if m_exp:
+        v = ctx.verify_pairs(pairs, npr, bt, pt).cpu().numpy().view(np.uint64)
+        assert int(v[0]) == npr and int(v[2]) == npr * (npr - 1) // 2
 
 
 @pytest.mark.parametrize("shape", ["narrow", "all_wide", "one_wide_key_last", "negative_key_first"])
