@@ -855,7 +855,9 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     uint32_t lds_grid = 0;
     uint64_t rows_per_block = 0;
     if (lds_path) {
-        lds_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 2, ceil_div(std::max<uint64_t>(1, p->n_rows), 4096)));
+        uint32_t per_cu = 2;
+        if (const char* e = getenv("GOLAP_AGG_WGS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));   // A/B hook
+        lds_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * per_cu, ceil_div(std::max<uint64_t>(1, p->n_rows), 4096)));
         rows_per_block = ceil_div(std::max<uint64_t>(1, p->n_rows), lds_grid);
     }
     const uint32_t red_grid = stream_grid(ctx, p->n_rows, OP_THREADS * 8);
