@@ -1391,7 +1391,7 @@ static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) {
     const uint64_t n = std::max<uint64_t>(1, n_rows);
     uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n, PT_TILE)));
     const uint64_t big = n / (4 * 24576);
-    if (big >= 512) c1 = std::min<uint64_t>(2048, big);
+    if (big >= 256) c1 = std::min<uint64_t>(2048, big / 256 * 256);   // whole rounds of one 1024-thread work-group per CU (256 CUs)
     const uint32_t chunk_rows = (uint32_t)round_up(ceil_div(n, c1), PT_TILE);
     if (chunk_rows_out) *chunk_rows_out = chunk_rows;
     return (uint32_t)std::max<uint64_t>(1, ceil_div(n, chunk_rows));
@@ -1479,7 +1479,7 @@ static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool h
     if (!use_big_scatter(F, false, false) || F > (uint32_t)WC_MAX_F) return false;   // the stand-by pass uses the write-combining scatter
     uint32_t chunk_rows = 0;
     const uint32_t chunks = first_pass_chunks(n_rows, &chunk_rows);
-    if (!(env && !strcmp(env, "1")) && (chunks < 512 || n_rows / chunks < 4 * 24576)) return false;
+    if (!(env && !strcmp(env, "1")) && (chunks < 224 || n_rows / chunks < 4 * 24576)) return false;   // (rounding chunk rows up to whole 4096-row tiles can leave a few fewer than 256)
     return reserve_cap(n_rows, F) * F < 0xFFFFFFF0ull;
 }
 
@@ -1540,7 +1540,7 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
         else
             hipLaunchKernelGGL((k_hist<TAG, true>), dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if, (uint32_t*)nullptr);
     } else if (narrow == 1) {
-        if (n_chunks >= 512 && n_rows / n_chunks >= 4 * 24576)
+        if (n_chunks >= 224 && n_rows / n_chunks >= 4 * 24576)
             hipLaunchKernelGGL((k_scatter_big<1, 24, 1024, 12288, 4, false, 3, false, true>), dim3(n_chunks), dim3(1024), scatter_big_lds_bytes(cfg.F, 12288, 1024),
                                st, keys, rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, ReserveArgs{});
         else
@@ -1555,7 +1555,7 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
         const char* e = getenv("GOLAP_BIG_RPT");   // A/B hook: "<variant>"
         // default: 1024 threads x 24 keys (24576-row tile, one work-group per CU) once there are enough chunks of several
         // tiles to give every CU a few; the 512-thread tile (two work-groups per CU) for mid-sized inputs
-        const int v = e ? atoi(e) : (n_chunks >= 512 && n_rows / n_chunks >= 4 * 24576 ? 1224 : 24);
+        const int v = e ? atoi(e) : (n_chunks >= 224 && n_rows / n_chunks >= 4 * 24576 ? 1224 : 24);
 #define GOLAP_BIG(RPT, NT, WIN, WPE, PF, ...)                                                                                             \
     hipLaunchKernelGGL((k_scatter_big<1, RPT, NT, WIN, WPE, PF, ##__VA_ARGS__>), dim3(n_chunks), dim3(NT), scatter_big_lds_bytes(cfg.F, WIN, NT), st, keys, \
                        rid_base, c_off, c_len, hist_arr, out_keys, out_rids, cfg, ReserveArgs{})
@@ -2084,7 +2084,7 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
     out->chunks1 = first_pass_chunks(n_build, nullptr);
     // first-pass tile: big-tile kernel = 24 keys per thread, 1024 threads for large inputs (launch_hist_scatter)
     out->tile_rows = !use_big_scatter(plan.passes[0].cfg.F, false, false) ? PT_TILE
-                     : (out->chunks1 >= 512 && n_build / out->chunks1 >= 4 * 24576 ? 1024 * 24 : PT_THREADS * 24);
+                     : (out->chunks1 >= 224 && n_build / out->chunks1 >= 4 * 24576 ? 1024 * 24 : PT_THREADS * 24);
     out->slots2 = plan.passes.size() < 2 ? 0 : (use_fast_last_pass(plan, false) ? 1 : slots_for(plan.passes[1].G, n_build));
     out->no_histogram_last_pass = use_fast_last_pass(plan, false) ? 1 : 0;
     out->no_histogram_first_pass = use_reserve_first_pass(plan, n_build, false, false) ? 1 : 0;
