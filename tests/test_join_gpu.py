@@ -298,7 +298,8 @@ def test_no_histogram_pass_is_taken_and_flag_stays_clear(ctx):
     assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2
 
 
-@pytest.mark.parametrize("nb,npr", [(60_000_000, 1_000_000), (52_000_000, 70_000_000), (60_000_000, 0), (0, 60_000_000), (60_000_000, 1)])
+@pytest.mark.parametrize("nb,npr", [(60_000_000, 1_000_000), (52_000_000, 70_000_000), (60_000_000, 0), (0, 60_000_000), (60_000_000, 1),
+                                    (30_000_000, 27_000_000), (26_000_000, 24_000_000)])
 def test_asymmetric_sides_mix_first_pass_forms(ctx, nb, npr):
     """each side picks its first-pass form by its own size: a 60M-row build side reserves (no histogram) while a 1M-row probe
     side takes the histogram path, and vice versa; checked on the device (every pair key-equal, probe ids a permutation)."""
