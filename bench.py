@@ -4,14 +4,18 @@
 
     python bench.py --gpus 1 --steps K --warmup W          (single GPU: the whole 1B x 1B join on one device)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+    python bench.py --config C3|C4|C4L|C1                  (the other BASELINE configs, same JSON shape, one GPU)
 
-A "step" is one complete join of the synthetic tables (device-resident inputs -> device-resident
-row-id pairs): radix histogram + scatter passes, [partition exchange over xGMI when N > 1,]
-LDS build/probe, pair output.  value = (n_build + n_probe) rows of the WHOLE job / max-over-ranks
-time per step; scaling is "strong" (the 1B x 1B table pair is fixed, N GPUs share it).
-Rank 0 prints ONE JSON line.
+A "step" is one complete pass of the operator over the synthetic, device-resident input (join: radix passes, [partition
+exchange over xGMI when N > 1,] LDS build/probe, pair output).  value = rows of the WHOLE job / max-over-ranks time per
+step; join scaling is "strong" (the 1B x 1B table pair is fixed, N GPUs share it).  Rank 0 prints ONE JSON line.
+
+The default C5 run also times the same join with genuinely 64-bit keys (both key columns + 2^40, `wide_keys` in the line):
+BASELINE's generators emit keys below 2^32, which take the 8-byte tuple pipeline; any key outside [0, 2^32) takes the
+64-bit-row pipeline instead.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,16 +32,60 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per side of the WHOLE job (default: config C5, 1B)")
-    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="rows per side of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--config", default="C5", choices=["C5", "C3", "C4", "C4L", "C1"],
+                    help="C5 1Bx1B join (default) | C3 100Mx100M join | C4 1B-row GROUP BY int32 -> SUM(f64), 1024 groups | C4L the same "
+                         "with 1048576 groups | C1 SELECT sum(v) WHERE k<c on a 1M-row batch")
+    ap.add_argument("--rows", type=int, default=0, help="rows per side / per column of the WHOLE job (0 = the config's size)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="rows of the bounded CPU-baseline sample (-1 = the config's default, 0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (ShardedJoin) even with 1 rank")
+    ap.add_argument("--no-wide", action="store_true", help="C5: skip the second timed leg with 64-bit keys")
+    ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (golap_sharded_join) even with 1 rank")
     return ap.parse_args()
 
 
-def cpu_baseline(sample, rank):
-    """Oracle timed on the host cores: single-thread faithful port (executor.rs:238-253 + probe) on a
-    bounded sample of the same generators, plus the multi-threaded radix variant for context."""
+def kernel_source_hash():
+    """sha256 over the kernel sources: ties profiles/pmc_traffic.json to the code it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gpu_olap_engine_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, rows, world):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes -- only when they were taken on exactly these kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tj = json.load(open(path))
+        if tj.get("kernel_source_sha") != kernel_source_hash():
+            return None
+        e = tj.get(f"{kernel}@{rows}x{world}")
+        return e["hbm_bytes_per_launch"] if e else None
+    except Exception:
+        return None
+
+
+def roofline_of(stats, rows, world, direct):
+    """the dominant kernel (by accumulated device time): algorithmic bytes per launch / mean launch duration (hipEvents on the
+    launch stream, recorded inside the library)"""
+    kern = {k: v for k, v in stats.items() if v["launches"] and k != "scan_offsets"}
+    if not kern:
+        return None
+    dom = max(kern, key=lambda k: kern[k]["total_ms"])
+    s = kern[dom]
+    per_launch = s["bytes"] / s["launches"]
+    avg_ms = s["total_ms"] / s["launches"]
+    ach = per_launch / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+            "traffic": pmc_traffic(dom, rows, world) if direct else None, "alg_bytes_per_launch": int(per_launch),
+            "avg_launch_ms": round(avg_ms, 4), "launches": s["launches"]}
+
+
+def cpu_join_baseline(sample, rank):
+    """Oracle timed on the host cores: single-thread faithful port (executor.rs:238-253 + probe) on a bounded sample of the
+    same generators, plus the multi-threaded radix variant for context."""
     if sample <= 0 or rank != 0:
         return None
     import oracle
@@ -57,76 +105,98 @@ def cpu_baseline(sample, rank):
             "fair_note": f"radix-partitioned, std::thread over all {cores} host cores; {t2 - t1:.2f} s"}
 
 
-def main():
-    args = parse_args()
-    import numpy as np
+def device_block(info):
+    return {"name": info["name"], "arch": info["gcn_arch"], "cus": info["compute_units"], "hbm_bus_bits": info["memory_bus_bits"],
+            "mem_clock_mhz": info["memory_clock_mhz"]}
+
+
+def timed(step, steps, warmup, barrier, ctx):
+    for _ in range(warmup):
+        res = step()
+    barrier()
+    ctx.stats_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    barrier()
+    return res, time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# joins: C5 (default, 1/2/4/8 GPUs) and C3
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_join(args, n_total, label):
     import torch
     import torch.distributed as dist
 
     from gpu_olap_engine_amd import _native as N
-    from gpu_olap_engine_amd.engine import Context
+    from gpu_olap_engine_amd.engine import Context, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.sharded:
+    sharded = world > 1 or args.sharded
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-
-    n_total = args.rows
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # barrier / max-over-ranks only; the join's own
+                                                                                       # exchange is the library's RCCL communicator
     ctx = Context(profiling=True, max_gpu_memory=0)
     info = ctx.device_info()
 
-    # ---- synthetic, device-resident inputs (counter-based) -------------
-    from gpu_olap_engine_amd.distributed import HipBackend, ShardedJoin, shard_range
+    # ---- synthetic, device-resident inputs (counter-based: every rank generates its own shard) ----
     lo, hi = shard_range(n_total, rank, world)
     n_local = hi - lo
     bkeys = ctx.generate(N.GEN_BUILD_KEYS, n_local, modulus=n_total, first=lo)
     pkeys = ctx.generate(N.GEN_SM64_MOD_I64, n_local, modulus=n_total, seed=43, first=lo)
     torch.cuda.synchronize()
-
-    if world == 1 and not args.sharded:
+    join_info = None
+    if not sharded:
         cap = n_total
         out_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
         out_count = torch.zeros(1, dtype=torch.int64, device=dev)
 
         def step():
             ctx.join(bkeys, pkeys, out_pairs=out_pairs, max_pairs=cap, strategy=N.JOIN_RADIX_HASH, out_count=out_count)
-            return out_pairs, out_count, n_local, n_local
+            return out_pairs, out_count
     else:
-        sj = ShardedJoin(HipBackend(ctx))
+        if world > 1:
+            from gpu_olap_engine_amd.distributed import NativeShardedJoin
+            sj = NativeShardedJoin(ctx, transport="rccl")
+            comm = sj.comm
+        else:
+            from gpu_olap_engine_amd.engine import comm_unique_id
+            comm = ctx.comm_create_rccl(comm_unique_id(), 1, 0)
         cap = int(n_local * 1.25) + 65536
         out_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        out_count = torch.zeros(1, dtype=torch.int64, device=dev)
 
         def step():
-            return sj.join(bkeys, pkeys, lo, lo, n_total, out_pairs=out_pairs)
+            comm.sharded_join(bkeys, pkeys, lo, lo, n_total, out_pairs=out_pairs, max_pairs=cap, out_count=out_count)
+            return out_pairs, out_count
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    ctx.stats_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    (pairs, count), dt = timed(step, args.steps, args.warmup, barrier, ctx)
+    dt = max_over_ranks(dt)
     ms_per_step = dt / args.steps * 1e3
-    pairs, count = res[0], res[1]
+    stats = ctx.stats()
+    if sharded:
+        join_info = comm.info()
     m_local = int(count.item())
 
     # ---- size-independent correctness properties (every run, untimed) -------------------------
@@ -137,11 +207,7 @@ def main():
             dist.all_reduce(m_tot)
         verify["matches"] = int(m_tot.item())
         assert verify["matches"] == n_total, f"expected exactly one match per probe row: {verify['matches']} != {n_total}"
-        # sum / xor of probe row ids over all pairs == those of 0..N-1  (every probe row exactly once)
-        import ctypes as C
-        v = torch.zeros(4, dtype=torch.int64, device=dev)
-        # key equality needs both key columns on one device: check it on 1 GPU, id coverage everywhere
-        if world == 1:
+        if world == 1:   # key equality needs both key columns on one device
             v = ctx.verify_pairs(pairs, m_local, bkeys, pkeys)
             assert int(v[0].item()) == m_local, "emitted pairs with unequal keys"
             verify["equal_key_pairs"] = int(v[0].item())
@@ -154,33 +220,10 @@ def main():
         assert psum == (n_total * (n_total - 1) // 2) & (2**64 - 1), "probe row ids are not a permutation of 0..N-1"
         verify["probe_id_sum_ok"] = True
 
-    stats = ctx.stats()
-    # ---- roofline of the dominant kernel (by accumulated device time) -------------------------
-    kern = {k: v for k, v in stats.items() if v["launches"] and k != "scan_offsets"}
-    dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
-    roof = None
-    if dom:
-        s = kern[dom]
-        per_launch_bytes = s["bytes"] / s["launches"]
-        avg_ms = s["total_ms"] / s["launches"]
-        ach = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and not (world > 1 or args.sharded):   # the profiled kernels are those of the direct single-GPU path
-            try:
-                tj = json.load(open(tpath))
-                e = tj.get(f"{dom}@{n_total}x{world}")
-                traffic = e["hbm_bytes_per_launch"] if e else None
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "alg_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 4), "launches": s["launches"]}
-    # whole-join algorithmic bytes, SURVEY 8(d): 40*(Nb+Np) + 8*M
-    alg_join = 40 * 2 * n_total + 8 * n_total
+    alg_join = 40 * 2 * n_total + 8 * n_total          # 40*(Nb+Np) + 8*M
     join_gbps = alg_join / (ms_per_step * 1e-3) / 1e9
     line = {
-        "metric": "join rows/sec, 1Bx1B int64 radix hash join",
+        "metric": "join rows/sec, 1Bx1B int64 radix hash join" if label == "C5" else "join rows/sec, 100Mx100M int64 radix hash join",
         "value": round(2 * n_total / (ms_per_step * 1e-3), 1),
         "unit": "rows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,27 +233,165 @@ def main():
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
-        "config": {"workload": f"C5 radix hash join {n_total} x {n_total} int64 keys, 256 radix partitions, unique build keys, M = N_probe",
-                   "n_build": n_total, "n_probe": n_total, "rows_per_gpu_per_side": n_local,
-                   "parallelism": f"partition-sharded x{world}" + (" + RCCL all_to_all" if world > 1 else ""),
+        "config": {"workload": f"{label} radix hash join {n_total} x {n_total} int64 keys (all below 2^32: the 8-byte tuple pipeline), 256 radix "
+                               f"partitions, unique build keys, M = N_probe",
+                   "n_build": n_total, "n_probe": n_total, "rows_per_gpu_per_side": n_local, "narrow_keys": True,
+                   "parallelism": f"partition-sharded x{world}" + (" + RCCL grouped send/recv (golap_sharded_join)" if sharded else ""),
                    "plan": ctx.join_plan(n_total if world == 1 else max(1, n_total // world))},
         "probe_rows_per_s": round(n_total / (ms_per_step * 1e-3), 1),
         "join_alg_GBps": round(join_gbps, 1),
         "join_roofline_frac": round(join_gbps / (HBM_PEAK_GBPS * world), 4),
-        "roofline": roof,
+        "roofline": roofline_of(stats, n_total, world, not sharded),
         "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in stats.items()},
         "verify": verify,
-        "device": {"name": info["name"], "arch": info["gcn_arch"], "cus": info["compute_units"],
-                   "hbm_bus_bits": info["memory_bus_bits"], "mem_clock_mhz": info["memory_clock_mhz"]},
+        "device": device_block(info),
     }
-    cb = cpu_baseline(args.cpu_sample, rank) if world == 1 else None
+    if join_info:
+        line["sharded_join"] = join_info
+
+    # ---- second leg: the same join with genuinely 64-bit keys (the 64-bit-row pipeline) -------
+    if label == "C5" and not args.no_wide and not sharded:
+        bkeys += 1 << 40
+        pkeys += 1 << 40
+        torch.cuda.synchronize()
+        (pairs, count), dtw = timed(step, args.steps, args.warmup, barrier, ctx)
+        msw = max_over_ranks(dtw) / args.steps * 1e3
+        statsw = ctx.stats()
+        mw = int(count.item())
+        assert mw == n_total, f"64-bit-key leg: {mw} matches"
+        if not args.no_verify:
+            v = ctx.verify_pairs(pairs, mw, bkeys, pkeys)
+            assert int(v[0].item()) == mw, "64-bit-key leg emitted pairs with unequal keys"
+        gb = alg_join / (msw * 1e-3) / 1e9
+        line["wide_keys"] = {"ms_per_step": round(msw, 3), "value": round(2 * n_total / (msw * 1e-3), 1), "unit": "rows/s",
+                             "join_alg_GBps": round(gb, 1), "join_roofline_frac": round(gb / HBM_PEAK_GBPS, 4),
+                             "roofline": roofline_of(statsw, n_total, 1, False),
+                             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in statsw.items() if v["total_ms"] / args.steps > 0.02},
+                             "workload": "the same generators + 2^40 on both key columns (every key outside [0, 2^32))"}
+    sample = args.cpu_sample if args.cpu_sample >= 0 else 32_000_000
+    cb = cpu_join_baseline(min(sample, n_total), rank) if world == 1 else None
     if cb:
         line["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1 or args.sharded:
+    if world > 1:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C4 / C4L: 1B-row GROUP BY int32 key SUM(float64)
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_group_by(args, n, groups, label):
+    import numpy as np
+    import torch
+
+    from gpu_olap_engine_amd import _native as N
+    from gpu_olap_engine_amd.engine import Context
+    torch.cuda.set_device(0)
+    ctx = Context(profiling=True, max_gpu_memory=0)
+    info = ctx.device_info()
+    keys = ctx.generate(N.GEN_SM64_MOD_I32, n, modulus=groups, seed=7)
+    vals = ctx.generate(N.GEN_SM64_MOD_F64, n, modulus=1024, seed=8)
+    torch.cuda.synchronize()
+
+    def step():
+        return ctx.aggregate([(N.AGG_SUM, 0)], [vals], group_keys=keys, n_groups=groups)
+
+    out, dt = timed(step, args.steps, args.warmup, torch.cuda.synchronize, ctx)
+    ms = dt / args.steps * 1e3
+    stats = ctx.stats()
+    verify = {}
+    if not args.no_verify:   # exact: integer-valued doubles, every partial sum < 2^53; checked on the device
+        exp = torch.zeros(groups, dtype=torch.float64, device="cuda")
+        exp.index_add_(0, keys.to(torch.int64), vals)
+        assert torch.equal(out[0], exp), "group sums differ from torch.index_add_"
+        verify = {"groups_equal_index_add": True, "sum_of_sums": float(out[0].sum().item())}
+    alg = n * (4 + 8) + groups * 12
+    line = {"metric": f"group-by rows/sec, 1B-row GROUP BY int32 key SUM(float64), {groups} groups", "value": round(n / (ms * 1e-3), 1), "unit": "rows/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{label} GROUP BY int32 key SUM(float64), {n} rows, {groups} groups (dense keys), hash-aggregate with LDS pre-aggregation"},
+            "agg_alg_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "agg_roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "roofline": roofline_of(stats, n, 1, True), "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in stats.items()},
+            "verify": verify, "device": device_block(info)}
+    sample = args.cpu_sample if args.cpu_sample >= 0 else 200_000_000
+    if sample:
+        import oracle
+        s = min(sample, n)
+        k = oracle.gen_sm64_mod(7, 0, s, groups, dtype=np.int32).astype(np.int64)
+        v = oracle.gen_sm64_mod(8, 0, s, 1024).astype(np.float64)
+        t0 = time.perf_counter()
+        oracle.group_aggregate(k, v)
+        t1 = time.perf_counter()
+        line["cpu_baseline"] = {"value": s / (t1 - t0), "unit": "rows/s", "cores": 1, "kind": "port",
+                                "sample": f"{s} rows of the same generators, single-thread sequential f64 accumulation per group "
+                                          f"(executor.rs:313-327 extended by the group key); {t1 - t0:.2f} s"}
+    print(json.dumps(line), flush=True)
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C1: SELECT sum(v) FROM t WHERE k < c on a 1M-row batch
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_filter_sum(args, n):
+    import torch
+
+    from gpu_olap_engine_amd import _native as N
+    from gpu_olap_engine_amd.engine import Context
+    torch.cuda.set_device(0)
+    ctx = Context(profiling=True, max_gpu_memory=0)
+    info = ctx.device_info()
+    k = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=1000, seed=1)
+    v = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=1024, seed=2)
+    torch.cuda.synchronize()
+
+    def step():
+        return ctx.filter_sum(k, v, "<", 500)
+
+    out, dt = timed(step, args.steps, args.warmup, torch.cuda.synchronize, ctx)
+    ms = dt / args.steps * 1e3
+    stats = ctx.stats()
+    verify = {}
+    if not args.no_verify:
+        sel = k < 500
+        assert float(out[0].item()) == float(v[sel].sum().item()) and float(out[1].item()) == float(sel.sum().item())
+        verify = {"sum": float(out[0].item()), "kept_rows": float(out[1].item())}
+    alg = 16 * n
+    line = {"metric": "filter+sum rows/sec, SELECT sum(v) FROM t WHERE k<c", "value": round(n / (ms * 1e-3), 1), "unit": "rows/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"C1 SELECT sum(v) FROM t WHERE k<500, {n}-row batch (k, v int64), fused predicate + sum in one pass"},
+            "alg_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "roofline": roofline_of(stats, n, 1, True),
+            "kernels_ms_per_step": {kk: round(vv["total_ms"] / args.steps, 5) for kk, vv in stats.items()}, "verify": verify, "device": device_block(info)}
+    sample = args.cpu_sample if args.cpu_sample >= 0 else n
+    if sample:
+        import oracle
+        s = min(sample, n)
+        kk, vv = oracle.gen_sm64_mod(1, 0, s, 1000), oracle.gen_sm64_mod(2, 0, s, 1024)
+        reps = max(1, 200_000_000 // s)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.filter_sum(kk, vv, "<", 500)
+        t1 = time.perf_counter()
+        line["cpu_baseline"] = {"value": s * reps / (t1 - t0), "unit": "rows/s", "cores": 1, "kind": "port",
+                                "sample": f"{reps} x {s} rows, the reference's 4-pass CPU path (executor.rs:161-178 + :297-355) restated; {t1 - t0:.2f} s"}
+    print(json.dumps(line), flush=True)
+    ctx.close()
+
+
+def main():
+    args = parse_args()
+    if args.config == "C5":
+        bench_join(args, args.rows or 1_000_000_000, "C5")
+    elif args.config == "C3":
+        bench_join(args, args.rows or 100_000_000, "C3")
+    elif args.config == "C4":
+        bench_group_by(args, args.rows or 1_000_000_000, 1024, "C4")
+    elif args.config == "C4L":
+        bench_group_by(args, args.rows or 1_000_000_000, 1_048_576, "C4L")
+    else:
+        bench_filter_sum(args, args.rows or 1_000_000)
 
 
 if __name__ == "__main__":

@@ -19,10 +19,12 @@ NULL_ROW_ID = 0xFFFFFFFF
 CMP_EQ, CMP_NE, CMP_LT, CMP_LE, CMP_GT, CMP_GE, CMP_NEVER = range(7)
 AGG_SUM, AGG_COUNT, AGG_MIN, AGG_MAX, AGG_AVG = range(5)
 DT_INT64, DT_FLOAT64, DT_INT32 = 0, 1, 2
+KEYS_DENSE, KEYS_HASHED = 0, 1
 (WIDEN_I8, WIDEN_I16, WIDEN_I32, WIDEN_I64, WIDEN_U8, WIDEN_U16, WIDEN_U32, WIDEN_U64, WIDEN_F32, WIDEN_F64) = range(10)
 GEN_BUILD_KEYS, GEN_SM64_MOD_I64, GEN_SM64_MOD_I32, GEN_SM64_MOD_F64, GEN_SHIFT32_I64 = range(5)
 HOST_TO_DEVICE, DEVICE_TO_HOST = 0, 1
 MAX_KERNEL_STATS = 48
+PROVISION_NONE = 0xFFFFFFFF
 
 
 class GolapError(RuntimeError):
@@ -36,7 +38,8 @@ class EngineConfig(C.Structure):
     """golap_engine_config == EngineConfig, gpu-olap-core/src/lib.rs:20-31."""
     _fields_ = [("max_gpu_memory", C.c_uint64), ("num_streams", C.c_uint32), ("use_unified_memory", C.c_uint32),
                 ("batch_size", C.c_uint64), ("enable_cache", C.c_uint32), ("device_id", C.c_int32),
-                ("radix_bits", C.c_uint32), ("enable_profiling", C.c_uint32)]
+                ("radix_bits", C.c_uint32), ("enable_profiling", C.c_uint32), ("max_slabs_per_class", C.c_uint32),
+                ("provision_sigmas", C.c_uint32)]
 
 
 class DeviceInfo(C.Structure):
@@ -91,6 +94,40 @@ class JoinPartitionedPlan(C.Structure):
                 ("build_rows", C.c_uint64), ("probe_rows", C.c_uint64), ("narrow", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
+class P2POp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("is_send", C.c_int32), ("ptr", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(P2POp), C.c_uint32, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("exchange", EXCHANGE_FN)]
+
+
+COMM_ID_BYTES = 128
+
+
+class ShardedJoinParams(C.Structure):
+    _fields_ = [("build_key_ptr", C.c_uint64), ("probe_key_ptr", C.c_uint64), ("n_build_local", C.c_uint64), ("n_probe_local", C.c_uint64),
+                ("build_rid_base", C.c_uint32), ("probe_rid_base", C.c_uint32), ("n_build_total", C.c_uint64), ("n_probe_total", C.c_uint64),
+                ("build_rows_per_rank", C.POINTER(C.c_uint64)), ("probe_rows_per_rank", C.POINTER(C.c_uint64)),
+                ("out_pairs_ptr", C.c_uint64), ("out_count_ptr", C.c_uint64), ("max_pairs", C.c_uint64),
+                ("join_type", C.c_int32), ("force_exact", C.c_int32), ("max_msg_bytes", C.c_uint64)]
+
+
+class ShardedJoinInfo(C.Structure):
+    _fields_ = [("fast_path", C.c_uint32), ("fast_path_abandoned", C.c_uint32), ("extra_bits", C.c_uint32), ("n_groups", C.c_uint32),
+                ("local_bits", C.c_uint32), ("host_syncs", C.c_uint32), ("rows_received", C.c_uint64 * 2), ("bytes_sent", C.c_uint64 * 2)]
+
+
+class ShardedPlan(C.Structure):
+    _fields_ = [("eligible", C.c_uint32), ("extra_bits", C.c_uint32), ("n_buckets", C.c_uint32), ("buckets_per_rank", C.c_uint32),
+                ("local_bits", C.c_uint32), ("cap_rows", (C.c_uint64 * 64) * 2), ("msg_bytes", (C.c_uint64 * 64) * 2),
+                ("msg_pieces", (C.c_uint32 * 64) * 2)]
+
+
 class AggregateSpec(C.Structure):
     """aggregate_kernel.rs:38-44."""
     _fields_ = [("func", C.c_int32), ("value_col_index", C.c_uint64), ("output_col_index", C.c_uint64)]
@@ -100,7 +137,8 @@ class AggregateParams(C.Structure):
     """aggregate_kernel.rs:47-58 + extensions."""
     _fields_ = [("group_key_ptr", C.c_uint64), ("value_ptrs", C.POINTER(C.c_uint64)), ("n_value_cols", C.c_uint32),
                 ("n_rows", C.c_uint64), ("n_groups", C.c_uint32), ("out_ptr", C.c_uint64), ("key_dtype", C.c_int32),
-                ("value_dtypes", C.POINTER(C.c_int32)), ("out_count_ptr", C.c_uint64)]
+                ("value_dtypes", C.POINTER(C.c_int32)), ("out_count_ptr", C.c_uint64), ("key_mode", C.c_int32), ("reserved0", C.c_int32),
+                ("out_keys_ptr", C.c_uint64), ("out_n_groups_ptr", C.c_uint64)]
 
 
 class KernelStat(C.Structure):
@@ -127,6 +165,7 @@ SIGNATURES = {
     "golap_ctx_create": (C.c_int32, [_P(EngineConfig), _P(_VP)]),
     "golap_ctx_destroy": (None, [_VP]),
     "golap_last_error": (C.c_char_p, [_VP]),
+    "golap_debug_set": (C.c_int32, [_VP, C.c_char_p, C.c_char_p]),
     "golap_device_info_get": (C.c_int32, [_VP, _P(DeviceInfo)]),
     "golap_ctx_synchronize": (C.c_int32, [_VP, _VP]),
     "golap_slab_alloc": (C.c_int32, [_VP, C.c_uint64, _P(C.c_uint64), _P(C.c_uint32)]),
@@ -149,6 +188,16 @@ SIGNATURES = {
     "golap_join_partitioned_narrow_ok": (C.c_int32, [_P(JoinPartitionedPlan)]),
     "golap_join_partitioned_side": (C.c_int32, [_VP, C.c_int32, _P(PartitionedSide), _VP]),
     "golap_join_partitioned_finish": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_join_partitioned_abort": (C.c_int32, [_VP]),
+    "golap_comm_unique_id": (C.c_int32, [_P(C.c_uint8)]),
+    "golap_comm_create_rccl": (C.c_int32, [_VP, _P(C.c_uint8), C.c_int32, C.c_int32, _P(_VP)]),
+    "golap_comm_create_custom": (C.c_int32, [_VP, _P(Transport), C.c_int32, C.c_int32, _P(_VP)]),
+    "golap_comm_destroy": (None, [_VP]),
+    "golap_sharded_join": (C.c_int32, [_VP, _VP, _P(ShardedJoinParams), _VP]),
+    "golap_sharded_join_info_get": (C.c_int32, [_VP, _P(ShardedJoinInfo)]),
+    "golap_comm_selftest": (C.c_int32, [_VP, _VP, C.c_uint64, _P(C.c_uint64), _P(C.c_uint64)]),
+    "golap_shard_range": (None, [C.c_uint64, C.c_uint32, C.c_uint32, _P(C.c_uint64), _P(C.c_uint64)]),
+    "golap_sharded_plan_get": (C.c_int32, [C.c_uint32, C.c_uint64, C.c_uint64, _P(C.c_uint64), _P(C.c_uint64), C.c_uint64, _P(ShardedPlan)]),
     "golap_agg_identity_value": (C.c_int64, [C.c_int32]),
     "golap_aggregate": (C.c_int32, [_VP, _P(AggregateSpec), C.c_uint32, _P(AggregateParams), _VP]),
     "golap_widen_to_8byte": (C.c_int32, [_VP, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),

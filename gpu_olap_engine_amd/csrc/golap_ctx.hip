@@ -6,6 +6,8 @@
 namespace golap {
 
 static thread_local std::string g_thread_err;
+thread_local const Knobs* g_knobs = nullptr;
+thread_local const golap_engine_config* g_scope_cfg = nullptr;
 
 void set_thread_error(const char* msg) { g_thread_err = msg ? msg : ""; }
 
@@ -114,6 +116,17 @@ int32_t SlabAllocator::allocate(golap_ctx* ctx, uint64_t size, uint64_t* ptr, ui
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, c.size);              // :132-149 (really allocates; nothing is leaked)
+    if (e != hipSuccess) {   // the device is full: pooled slabs of every class go back to it before giving up
+        (void)hipGetLastError();
+        for (auto& oc : classes)
+            while (!oc.free_slabs.empty()) {
+                (void)hipFree((void*)oc.free_slabs.front());
+                oc.free_slabs.pop_front();
+                oc.allocated_count -= 1;
+                bytes_reserved -= oc.size;
+            }
+        e = hipMalloc(&p, c.size);
+    }
     if (e != hipSuccess) return fail(ctx, GOLAP_ERR_OOM, "hipMalloc(%llu) failed: %s", (unsigned long long)c.size, hipGetErrorString(e));
     c.allocated_count += 1;
     bytes_reserved += c.size;
@@ -126,7 +139,7 @@ int32_t SlabAllocator::release(golap_ctx* ctx, uint64_t ptr, uint32_t cls) {
     if (cls >= classes.size()) return fail(ctx, GOLAP_ERR_INVALID_ARG, "Invalid slab class index: %u", cls);   // :72-74
     std::lock_guard<std::mutex> lk(mu);
     SlabClass& c = classes[cls];
-    if (c.free_slabs.size() >= c.max_slabs) {          // :80-86: really free instead of only forgetting
+    if (c.free_slabs.size() >= std::min<uint32_t>(c.max_slabs, 16u)) {   // :80-86: really free instead of only forgetting (the pool keeps <= 16 per class)
         (void)hipFree((void*)ptr);
         c.allocated_count -= 1;
         bytes_reserved -= c.size;
@@ -248,6 +261,9 @@ int32_t zero_async(golap_ctx* ctx, hipStream_t st, void* ptr, uint64_t bytes) {
 // Workspace
 // ---------------------------------------------------------------------------
 int32_t ws_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st) {
+    if (ctx->ws_owned)
+        return fail(ctx, GOLAP_ERR_INVALID_ARG, "the context's workspace belongs to a join opened with golap_join_partitioned_begin: finish or abort it first");
+    ctx->err.clear();   // a new compute call starts: golap_last_error reports its failures, not an earlier call's
     bytes = round_up(bytes + 4096, 4096);
     if (ctx->ws.size < bytes) {
         if (ctx->ws.base) {
@@ -282,6 +298,39 @@ void ws_end(golap_ctx* ctx, hipStream_t st) {
     ctx->ws_stream = st;
 }
 
+int32_t aux_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st) {
+    bytes = round_up(bytes + 4096, 4096);
+    if (ctx->aux.size < bytes) {
+        if (ctx->aux.base) {
+            if (ctx->aux_done) (void)hipStreamSynchronize(ctx->aux_stream);   // the old slab may still be in use by queued kernels
+            GOLAP_TRY(ctx->slabs.release(ctx, ctx->aux.base, ctx->aux.cls));
+            ctx->aux = Workspace();
+        }
+        uint64_t p = 0;
+        uint32_t cls = 0;
+        GOLAP_TRY(ctx->slabs.allocate(ctx, bytes, &p, &cls));
+        ctx->aux.base = p;
+        ctx->aux.cls = cls;
+        ctx->aux.size = ctx->slabs.classes[cls].size;
+    }
+    if (ctx->aux_done && ctx->aux_stream != st) GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_done, 0));
+    ctx->aux.used = 0;
+    return GOLAP_OK;
+}
+
+uint64_t aux_take(golap_ctx* ctx, uint64_t bytes) {
+    const uint64_t o = round_up(ctx->aux.used, 256);
+    if (o + bytes > ctx->aux.size) return 0;
+    ctx->aux.used = o + bytes;
+    return ctx->aux.base + o;
+}
+
+void aux_end(golap_ctx* ctx, hipStream_t st) {
+    if (!ctx->aux_done) (void)hipEventCreateWithFlags(&ctx->aux_done, hipEventDisableTiming);
+    (void)hipEventRecord(ctx->aux_done, st);
+    ctx->aux_stream = st;
+}
+
 }  // namespace golap
 
 using namespace golap;
@@ -304,6 +353,8 @@ void golap_engine_config_default(golap_engine_config* cfg) {
     cfg->device_id = -1;
     cfg->radix_bits = 8;                               // join_kernels.cuh:22
     cfg->enable_profiling = 0;
+    cfg->max_slabs_per_class = 4096;
+    cfg->provision_sigmas = 0;
 }
 
 const char* golap_last_error(const golap_ctx* ctx) {
@@ -337,10 +388,18 @@ int32_t golap_ctx_create(const golap_engine_config* cfg, golap_ctx** out_ctx) {
     if (e != hipSuccess) { delete ctx; return fail(nullptr, GOLAP_ERR_HIP, "selecting device failed: %s", hipGetErrorString(e)); }
     e = hipGetDeviceProperties(&ctx->prop, ctx->device);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, GOLAP_ERR_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e)); }
-    ctx->slabs.init(c.max_gpu_memory, 8);
+    ctx->slabs.init(c.max_gpu_memory, c.max_slabs_per_class ? c.max_slabs_per_class : 4096);
     int32_t s = ctx->xfer.init(ctx, c.num_streams);
     if (s != GOLAP_OK) { golap_ctx_destroy(ctx); return s; }
     ctx->prof.enabled = c.enable_profiling != 0;
+    if (getenv("GOLAP_DEBUG_ENV")) {   // developer convenience: import GOLAP_* variables ONCE as knobs (scripts/, multi-process tests)
+        extern char** environ;
+        for (char** e = environ; e && *e; ++e)
+            if (!strncmp(*e, "GOLAP_", 6)) {
+                const char* eq = strchr(*e, '=');
+                if (eq) ctx->knobs.set(std::string(*e, eq - *e).c_str(), eq + 1);
+            }
+    }
     *out_ctx = ctx;
     return GOLAP_OK;
 }
@@ -352,9 +411,18 @@ void golap_ctx_destroy(golap_ctx* ctx) {
     ctx->prof.destroy();
     ctx->xfer.destroy();
     if (ctx->ws.base) (void)ctx->slabs.release(ctx, ctx->ws.base, ctx->ws.cls);
+    if (ctx->aux.base) (void)ctx->slabs.release(ctx, ctx->aux.base, ctx->aux.cls);
+    if (ctx->aux_done) (void)hipEventDestroy(ctx->aux_done);
     ctx->slabs.destroy();
     if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
     delete ctx;
+}
+
+int32_t golap_debug_set(golap_ctx* ctx, const char* name, const char* value) {
+    if (!ctx || !name) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->knobs.set(name, value);
+    return GOLAP_OK;
 }
 
 int32_t golap_device_info_get(golap_ctx* ctx, golap_device_info* out) {

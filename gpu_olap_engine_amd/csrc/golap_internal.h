@@ -97,6 +97,30 @@ struct Profiler {
     void destroy();
 };
 
+// Developer / test knobs (golap_debug_set): named strings kept in the context.  The library never reads the process
+// environment on a compute path; at context creation GOLAP_* variables are imported once, and only when GOLAP_DEBUG_ENV
+// is set.  Planning helpers that have no context argument find the calling context's knobs through a thread-local pointer
+// installed by KnobScope at every C-ABI entry point.
+struct Knobs {
+    std::vector<std::pair<std::string, std::string>> kv;
+    const char* get(const char* name) const {
+        for (const auto& e : kv)
+            if (e.first == name) return e.second.c_str();
+        return nullptr;
+    }
+    void set(const char* name, const char* value) {
+        for (size_t i = 0; i < kv.size(); ++i)
+            if (kv[i].first == name) {
+                if (value) kv[i].second = value; else kv.erase(kv.begin() + i);
+                return;
+            }
+        if (value) kv.push_back({name, value});
+    }
+};
+extern thread_local const Knobs* g_knobs;
+extern thread_local const golap_engine_config* g_scope_cfg;
+inline const char* knob(const char* name) { return g_knobs ? g_knobs->get(name) : nullptr; }
+
 // Workspace: one slab, bump-allocated per call, cached in the context.
 struct Workspace {
     uint64_t base = 0, size = 0, used = 0;
@@ -117,7 +141,13 @@ struct golap_ctx {
     golap::Workspace ws;
     hipEvent_t ws_done = nullptr;     // last use of the workspace (cross-stream ordering)
     hipStream_t ws_stream = nullptr;
+    golap::Workspace aux;             // second cached slab: scratch of an operator that itself calls another one (which re-begins `ws`)
+    hipEvent_t aux_done = nullptr;
+    hipStream_t aux_stream = nullptr;
     std::shared_ptr<void> pjs;        // golap::PartJoinState (golap_join.hip)
+    golap::Knobs knobs;               // golap_debug_set
+    bool ws_owned = false;            // between golap_join_partitioned_begin and _finish / _abort: ws_begin refuses other callers
+    std::vector<bool> attr_done;      // per kernel family: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applied on THIS context's device
 };
 
 namespace golap {
@@ -156,6 +186,22 @@ struct KernelTimer {
     }
 };
 
+struct KnobScope {
+    const Knobs* prev;
+    const golap_engine_config* prev_cfg;
+    explicit KnobScope(golap_ctx* c) : prev(g_knobs), prev_cfg(g_scope_cfg) { g_knobs = c ? &c->knobs : nullptr; g_scope_cfg = c ? &c->cfg : nullptr; }
+    ~KnobScope() { g_knobs = prev; g_scope_cfg = prev_cfg; }
+};
+
+// head-room of the provisioned (no-histogram) layouts: standard deviations + pad rows (golap_engine_config::provision_sigmas;
+// the per-pass test knobs GOLAP_RESERVE_SIGMAS / GOLAP_SLOT_SIGMAS override it)
+inline void provision_of(const char* knob_name, uint32_t& sigmas, uint32_t& pad) {
+    sigmas = 6;
+    pad = 48;
+    if (g_scope_cfg && g_scope_cfg->provision_sigmas) { sigmas = g_scope_cfg->provision_sigmas == GOLAP_PROVISION_NONE ? 0u : g_scope_cfg->provision_sigmas; pad = sigmas ? 48 : 0; }
+    if (const char* v = knob(knob_name)) { sigmas = (uint32_t)atoi(v); pad = sigmas ? 48 : 0; }
+}
+
 // NULL is the HIP null (legacy default) stream, exactly as in every HIP API -- it is also what
 // torch.cuda.current_stream().cuda_stream returns for torch's default stream.
 inline hipStream_t pick_stream(golap_ctx* ctx, void* stream) { (void)ctx; return (hipStream_t)stream; }
@@ -164,6 +210,9 @@ inline hipStream_t pick_stream(golap_ctx* ctx, void* stream) { (void)ctx; return
 int32_t ws_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st);
 uint64_t ws_take(golap_ctx* ctx, uint64_t bytes);   // 256-B aligned bump; returns 0 when exhausted
 void ws_end(golap_ctx* ctx, hipStream_t st);
+int32_t aux_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st);   // same three calls on the second slab (ctx->aux)
+uint64_t aux_take(golap_ctx* ctx, uint64_t bytes);
+void aux_end(golap_ctx* ctx, hipStream_t st);
 
 // in-place exclusive scan of n u32 values (n <= 16.7M); block_sums needs ceil(n/4096)+1 u32 (golap_join.hip)
 int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if = nullptr);

@@ -90,7 +90,11 @@ struct GroupSrc {
     const uint32_t* cursor;   // null: exact layout only
     uint32_t cap;
     const uint32_t* flag;     // set when a reserved range overflowed: the exact path has redone the pass
+    uint32_t nsub;            // reserved layout only, 0/1 = one range per group; n: group g is the n sub-ranges
+                              // [(g*n + s) * cap, + min(cursor[g*n + s], cap)) (one per XCD, see ReserveArgs::nsub)
 };
+__device__ __forceinline__ uint32_t group_pieces(const GroupSrc& gs) { return (gs.cursor && *gs.flag == 0 && gs.nsub > 1) ? gs.nsub : 1u; }
+__device__ __forceinline__ void group_piece(const GroupSrc& gs, uint32_t g, uint32_t s, uint32_t& start, uint32_t& len);
 
 __device__ __forceinline__ void group_extent(const GroupSrc& gs, uint32_t g, uint32_t& start, uint32_t& len) {
     if (gs.cursor && *gs.flag == 0) {
@@ -101,6 +105,13 @@ __device__ __forceinline__ void group_extent(const GroupSrc& gs, uint32_t g, uin
         start = gs.scanned[(size_t)g * gs.stride];
         len = gs.scanned[(size_t)(g + 1) * gs.stride] - start;
     }
+}
+
+__device__ __forceinline__ void group_piece(const GroupSrc& gs, uint32_t g, uint32_t s, uint32_t& start, uint32_t& len) {
+    if (group_pieces(gs) == 1) { group_extent(gs, g, start, len); return; }
+    const uint32_t i = g * gs.nsub + s, c = gs.cursor[i];
+    start = i * gs.cap;
+    len = c < gs.cap ? c : gs.cap;
 }
 
 // `run_if` (here and on the other exact-path kernels): when non-null the launch is a no-op unless *run_if != 0 --
@@ -414,7 +425,16 @@ struct ReserveArgs {
     uint32_t* overflow;      // set to 1 when a bucket outgrew its range
     uint32_t* wide;          // NARROW: set to 1 when a key does not fit 32 bits (and polled: the work-group stops at once)
     const uint32_t* run_if;  // when non-null the launch is a no-op unless *run_if != 0
+    uint32_t nsub;           // 0/1: one cursor per bucket.  n (= 8, the XCDs): bucket f owns n sub-ranges of `cap` rows with cursors
+                             // [f*n + s]; work-group b reserves in sub-range b % n.  Work-groups b and b + 8 share an XCD (observed
+                             // round-robin dispatch; speed only), so neighbouring runs -- which share the 128-byte line at their common
+                             // boundary -- are written through the SAME L2 and leave it as one full line instead of two partial ones
+                             // (each of those costs a read-modify-write at the memory side; measured in DESIGN.md 4.1).
 };
+__device__ __forceinline__ uint32_t reserve_slot(const ReserveArgs& rs, uint32_t f) {
+    const uint32_t n = rs.nsub > 1 ? rs.nsub : 1u;
+    return f * n + blockIdx.x % n;
+}
 
 // NARROW (optimistic 32-bit keys): the partitioned rows are written as ONE array of 8-byte (key32, row id) tuples instead
 // of an 8-byte key array + a 4-byte row-id array: 8 instead of 12 bytes per row through both partition passes and the
@@ -503,8 +523,8 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
             const uint32_t c0 = f0 < F ? s_cnt[f0] : 0u, c1 = f1 < F ? s_cnt[f1] : 0u;
             uint32_t r0 = 0, r1 = 0;
             if (RESERVE) {   // in flight during the scan below
-                if (c0) r0 = atomicAdd(&rs.cursor[f0], c0);
-                if (c1) r1 = atomicAdd(&rs.cursor[f1], c1);
+                if (c0) r0 = atomicAdd(&rs.cursor[reserve_slot(rs, f0)], c0);
+                if (c1) r1 = atomicAdd(&rs.cursor[reserve_slot(rs, f1)], c1);
             }
             const uint32_t inc = wave_inclusive_scan(c0 + c1);
             if (lane == 63) s_w[wv] = inc;
@@ -542,8 +562,8 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                 }
             }
             if (RESERVE && w0 == 0) {   // the reservations have had the scan and the staging above to come back
-                if (2 * tid < F) s_gpos[2 * tid] = 2 * tid * rs.cap + rsv0;
-                if (2 * tid + 1 < F) s_gpos[2 * tid + 1] = (2 * tid + 1) * rs.cap + rsv1;
+                if (2 * tid < F) s_gpos[2 * tid] = reserve_slot(rs, 2 * tid) * rs.cap + rsv0;
+                if (2 * tid + 1 < F) s_gpos[2 * tid + 1] = reserve_slot(rs, 2 * tid + 1) * rs.cap + rsv1;
                 if (rsv_over) atomicOr(rs.overflow, 1u);
             }
             lds_barrier();
@@ -556,12 +576,12 @@ __global__ __launch_bounds__(NT, WPE) void k_scatter_big(const long long* __rest
                         const uint2 row = s_rows[i];
                         const uint32_t b = bucket_of(hash_int32((int32_t)row.x), cfg);   // == hash_int64 of the zero-extended key
                         const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
-                        if (!RESERVE || gp < (b + 1u) * rs.cap) out_rows[gp] = row;
+                        if (!RESERVE || gp < (reserve_slot(rs, b) + 1u) * rs.cap) out_rows[gp] = row;
                     } else {
                         const long long k = s_keys[i];
                         const uint32_t b = bucket_of(hash_int64(k), cfg);
                         const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
-                        if (!RESERVE || gp < (b + 1u) * rs.cap) {   // rows past a bucket's range are dropped (overflow raised above)
+                        if (!RESERVE || gp < (reserve_slot(rs, b) + 1u) * rs.cap) {   // rows past a bucket's range are dropped (overflow raised above)
                             out_keys[gp] = k;
                             out_rids[gp] = s_rids[i];
                         }
@@ -611,8 +631,12 @@ __global__ __launch_bounds__(1024) void k_slots_setup(GroupSrc gs, uint32_t G, u
     const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
     uint32_t total = 0;
     if (g < G) {
-        uint32_t g_start, n_g;
-        group_extent(gs, g, g_start, n_g);
+        uint32_t n_g = 0;
+        for (uint32_t s = 0, np = group_pieces(gs); s < np; ++s) {
+            uint32_t st, l;
+            group_piece(gs, g, s, st, l);
+            n_g += l;
+        }
         const uint32_t avg = (n_g + F - 1) / F;
         const uint32_t cap = (avg + sigmas * isqrt_u32(avg) + pad + 15u) & ~15u;
         slot_cap[g] = cap;
@@ -884,6 +908,10 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
 static_assert(WC_CAP - 15 * WC_MAX_F >= 512, "a tile must always have room for new rows");
 static_assert(WC_CARRY_PT * WC_THREADS == 16 * WC_MAX_F, "carry slots per thread");
 static_assert((8 * WC_MAX_F) % WC_THREADS == 0, "carry slots per thread (8-row segments)");
+
+}  // namespace golap
+#include "golap_part_narrow.h"
+namespace golap {
 
 // ---------------------------------------------------------------------------
 // join of one sub-partition per work-group, table in LDS.
@@ -1344,7 +1372,7 @@ static uint32_t bits_needed(uint64_t n_build) {
 // pass structure for `extra` = bits beyond the first 8, given a max of `maxb` bits per pass
 static void split_bits(uint32_t total_bits, uint32_t max_per_pass, std::vector<uint32_t>& out) {
     out.clear();
-    const char* env = getenv("GOLAP_PASS_BITS");   // e.g. "8,5,5" -- experiment hook
+    const char* env = knob("GOLAP_PASS_BITS");   // e.g. "8,5,5" -- experiment hook
     if (env && *env) {
         uint32_t sum = 0;
         const char* p = env;
@@ -1387,12 +1415,13 @@ static uint32_t slots_for(uint32_t G, uint64_t n_rows) {
 
 // uniform chunks of the global first pass: <= 2048 work-groups; once the input is large enough, chunks of at least four
 // 24576-row tiles so that the 1024-thread big-tile scatter applies (launch_hist_scatter)
-static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) {
+// `tile`: chunks are whole tiles of the kernel that will read them (only a side's very last chunk then ends in a partial tile)
+static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out, uint32_t tile = PT_TILE) {
     const uint64_t n = std::max<uint64_t>(1, n_rows);
     uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n, PT_TILE)));
     const uint64_t big = n / (4 * 24576);
     if (big >= 256) c1 = std::min<uint64_t>(2048, big / 256 * 256);   // whole rounds of one 1024-thread work-group per CU (256 CUs)
-    const uint32_t chunk_rows = (uint32_t)round_up(ceil_div(n, c1), PT_TILE);
+    const uint32_t chunk_rows = (uint32_t)round_up(round_up(ceil_div(n, c1), PT_TILE), big >= 256 ? tile : PT_TILE);
     if (chunk_rows_out) *chunk_rows_out = chunk_rows;
     return (uint32_t)std::max<uint64_t>(1, ceil_div(n, chunk_rows));
 }
@@ -1445,7 +1474,7 @@ struct SideResult {
 
 // the last pass can skip its histogram when it is the second of two passes over contiguous groups
 static bool use_fast_last_pass(const JoinPlan& plan, bool has_segs) {
-    const char* env = getenv("GOLAP_NOHIST");   // "0" disables (A/B hook)
+    const char* env = knob("GOLAP_NOHIST");   // "0" disables (A/B hook)
     if (env && !strcmp(env, "0")) return false;
     if (!plan.allow_slots || has_segs || plan.passes.size() != 2) return false;
     const PassPlan& pp = plan.passes[1];
@@ -1463,16 +1492,29 @@ static uint32_t isqrt_host(uint64_t x) {
 
 // rows provisioned per first-pass bucket when the first pass reserves its output by atomics (k_scatter_big<.., RESERVE>)
 static uint64_t reserve_cap(uint64_t n_rows, uint32_t F) {
-    uint32_t sigmas = 6, pad = 48;
-    if (const char* env = getenv("GOLAP_RESERVE_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }   // test hook: 0 forces overflows
+    uint32_t sigmas, pad;
+    provision_of("GOLAP_RESERVE_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
     const uint64_t avg = ceil_div(std::max<uint64_t>(n_rows, 1), F);
     return round_up(avg + (uint64_t)sigmas * isqrt_host(avg) + pad, 16);
+}
+
+// Sub-ranges per first-pass bucket in the narrow pipeline (ReserveArgs::nsub): one per XCD.  GOLAP_NSUB: A/B hook.
+static uint32_t narrow_nsub() {
+    const char* e = knob("GOLAP_NSUB");
+    const uint32_t v = e ? (uint32_t)atoi(e) : 8u;
+    return v >= 1 && v <= 8 ? v : 8u;
+}
+// rows provisioned per (bucket, sub-range): the sub-range of work-groups b = s (mod nsub) receives at most ceil(chunks / nsub) chunks
+static uint64_t reserve_cap_sub(uint64_t n_rows, uint32_t F, uint32_t nsub, uint32_t n_chunks, uint32_t chunk_rows) {
+    if (nsub <= 1) return reserve_cap(n_rows, F);
+    const uint64_t n_s = std::min<uint64_t>(std::max<uint64_t>(n_rows, 1), ceil_div(n_chunks, nsub) * (uint64_t)chunk_rows);
+    return reserve_cap(n_s, F);
 }
 
 // No-histogram FIRST pass: single-source global pass of a two-pass plan whose second pass is the no-histogram one,
 // large enough for the 1024-thread big-tile kernel.
 static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool has_segs, bool has_rids) {
-    const char* env = getenv("GOLAP_RESERVE");   // "0" disables (A/B hook), "1" drops the size condition (test hook)
+    const char* env = knob("GOLAP_RESERVE");   // "0" disables (A/B hook), "1" drops the size condition (test hook)
     if (env && !strcmp(env, "0")) return false;
     if (!use_fast_last_pass(plan, has_segs) || has_rids) return false;
     const uint32_t F = plan.passes[0].cfg.F;
@@ -1483,10 +1525,14 @@ static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool h
     return reserve_cap(n_rows, F) * F < 0xFFFFFFF0ull;
 }
 
+static uint32_t part1_narrow_tile();
 // rows the first-pass output buffer must hold
 static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
     if (!use_reserve_first_pass(plan, n, has_segs, false)) return n;
-    return std::max<uint64_t>(n, reserve_cap(n, plan.passes[0].cfg.F) * plan.passes[0].cfg.F);
+    const uint32_t F = plan.passes[0].cfg.F, nsub = narrow_nsub();
+    uint32_t chunk_rows = 0;
+    const uint32_t nc = first_pass_chunks(n, &chunk_rows, part1_narrow_tile());
+    return std::max<uint64_t>(std::max<uint64_t>(n, reserve_cap(n, F) * F), reserve_cap_sub(n, F, nsub, nc, chunk_rows) * F * nsub);   // (narrow tuples: 8 B per row as well)
 }
 
 // rows the final buffers of one side must hold: slots are avg + 6 sqrt(avg) + 48, 16-row aligned (k_slots_setup)
@@ -1509,7 +1555,7 @@ static size_t scatter_wc_lds_bytes(uint32_t F, uint32_t cap = WC_CAP, uint32_t r
 // bucket streams stay inside one group's output window (passes >= 2: 21.3 -> 15.3 ms), and loses
 // on the global first pass whose 2 x F streams per work-group span the whole output (18.1 -> 21.5 ms).
 static bool use_wc_scatter(uint32_t F, bool local_pass) {
-    const char* env = getenv("GOLAP_SCATTER");   // "v1" / "wc": A/B hook
+    const char* env = knob("GOLAP_SCATTER");   // "v1" / "wc": A/B hook
     if (env && !strcmp(env, "v1")) return false;
     if (F > (uint32_t)WC_MAX_F) return false;
     if (env && !strcmp(env, "wc")) return true;
@@ -1520,7 +1566,7 @@ static size_t scatter_big_lds_bytes(uint32_t F, uint32_t win = BT_WIN, uint32_t 
 
 // big-tile scatter: global first pass with implicit row ids and a fan-out whose v1 runs would be < 1 line
 static bool use_big_scatter(uint32_t F, bool local_pass, bool has_rids) {
-    const char* env = getenv("GOLAP_SCATTER");
+    const char* env = knob("GOLAP_SCATTER");
     if (env && !strcmp(env, "v1")) return false;
     if (has_rids || local_pass) return false;
     if (env && !strcmp(env, "big")) return true;
@@ -1552,7 +1598,7 @@ static void launch_hist_scatter(bool hist, bool wc, uint32_t n_chunks, hipStream
     } else if (hist) {
         hipLaunchKernelGGL(k_hist<TAG>, dim3(n_chunks), dim3(PT_THREADS), 0, st, keys, c_off, c_len, hist_arr, cfg, run_if);
     } else if (!wc && use_big_scatter(cfg.F, false, rids != nullptr) && TAG == 1) {
-        const char* e = getenv("GOLAP_BIG_RPT");   // A/B hook: "<variant>"
+        const char* e = knob("GOLAP_BIG_RPT");   // A/B hook: "<variant>"
         // default: 1024 threads x 24 keys (24576-row tile, one work-group per CU) once there are enough chunks of several
         // tiles to give every CU a few; the 512-thread tile (two work-groups per CU) for mid-sized inputs
         const int v = e ? atoi(e) : (n_chunks >= 224 && n_rows / n_chunks >= 4 * 24576 ? 1224 : 24);
@@ -1680,8 +1726,8 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             uint32_t* flag = (uint32_t*)ws_take(ctx, 4);
             if (!slot_base || !slot_cap || !sub_start || !sub_len || !flag) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (slot arrays)");
             GOLAP_TRY(zero_async(ctx, st, (void*)(flag), 4));
-            uint32_t sigmas = 6, pad = 48;
-            if (const char* env = getenv("GOLAP_SLOT_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }   // test hook: 0 forces overflows
+            uint32_t sigmas, pad;
+            provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
             hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F, sigmas, pad, slot_base, slot_cap);
             FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, flag, nullptr};
             PassCfg cfg = pp.cfg;
@@ -1764,9 +1810,15 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     return GOLAP_OK;
 }
 
+// kernels that ask for more than 64 KiB of dynamic LDS need the attribute once per DEVICE: tracked per context (one context =
+// one device), under ctx->mu like every caller
+static bool attr_flag(golap_ctx* ctx, size_t which, bool set = false) {
+    if (ctx->attr_done.size() <= which) ctx->attr_done.resize(which + 1, false);
+    if (set) ctx->attr_done[which] = true;
+    return ctx->attr_done[which];
+}
 static int32_t ensure_scatter_lds(golap_ctx* ctx) {
-    static bool done = false;
-    if (done) return GOLAP_OK;
+    if (attr_flag(ctx, 0)) return GOLAP_OK;
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
     GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(PT_MAX_F)));
@@ -1789,12 +1841,22 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
         GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_scatter_wc<2, true, 16, true, WCN_RPT, WCN_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)scatter_wc_lds_bytes(WC_MAX_F, WCN_CAP, 8)));
         for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
+        {
+            const void* p1[] = {(const void*)k_part1_narrow<18, 18432, true, true>, (const void*)k_part1_narrow<18, 18432, true, false>,
+                                (const void*)k_part1_narrow<18, 18432, false, false>, (const void*)k_part1_narrow<16, 16384, true, true>,
+                                (const void*)k_part1_narrow<16, 16384, true, false>, (const void*)k_part1_narrow<16, 16384, false, false>,
+                                (const void*)k_part1_narrow<24, 12288, false, false>, (const void*)k_part1_narrow<18, 18432, true, false, 1>,
+                                (const void*)k_part1_narrow<18, 18432, true, false, 2>, (const void*)k_part1_narrow<18, 18432, true, false, 3>};
+            for (const void* f : p1) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part1_narrow_lds_bytes(PT_MAX_F, 18432)));
+            const void* p2[] = {(const void*)k_part2_ring<4, 32, true>, (const void*)k_part2_ring<4, 32, false>, (const void*)k_part2_ring<2, 32, false>, (const void*)k_part2_ring<4, 32, false, 2>};
+            for (const void* f : p2) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_ring_lds_bytes(P2R_MAX_F, 32)));
+        }
         const void* wcn[] = {(const void*)k_scatter_wc<1, false, 16, true>, (const void*)k_scatter_wc<2, false, 16, true>,
                              (const void*)k_scatter_wc<3, false, 16, true>};
         for (const void* f : wcn)
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F, WC_CAP, 8)));
     }
-    done = true;
+    attr_flag(ctx, 0, true);
     return GOLAP_OK;
 }
 
@@ -1811,7 +1873,7 @@ static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint
     bytes += n_tmp * (round_up(tmax * 8, 256) + round_up(tmax * 4, 256));
     bytes += 2 * (round_up((uint64_t)PT_MAX_F * 4, 256) + 512);   // first-pass reservation cursors + flags
     if (np == 2)                                                   // narrow pipeline: cursors, chunk descriptors, slot arrays (both sides)
-        bytes += 2 * (round_up((uint64_t)PT_MAX_F * 4, 256) + 2 * round_up(2048 * 4, 256) + 2 * round_up((uint64_t)(plan.passes[1].G + 1) * 4, 256) +
+        bytes += 2 * (round_up((uint64_t)PT_MAX_F * 8 * 4, 256) + 2 * round_up(2048 * 4, 256) + 2 * round_up((uint64_t)(plan.passes[1].G + 1) * 4, 256) +
                       2 * round_up((uint64_t)plan.passes[1].G * plan.passes[1].cfg.F * 4, 256)) + 4096;
     bytes += side_small_bytes(plan, n_build, n_src, has_segs) + side_small_bytes(plan, n_probe, n_src, has_segs);
     bytes += 2 * round_up((uint64_t)4096 * 4 * 2, 256);   // segment tables
@@ -1836,7 +1898,7 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     KernelTimer t(ctx, run_if ? "join_build_probe_lds_wide" : "join_build_probe_lds", st, run_if ? 0 : row_bytes * (n_build + n_probe));
     const uint32_t n_sub = (uint32_t)plan.n_sub;
     uint32_t stride_grid = 4096u;
-    if (const char* e = getenv("GOLAP_JOIN_STRIDE_GRID")) stride_grid = (uint32_t)std::max(1, atoi(e));   // debug hook
+    if (const char* e = knob("GOLAP_JOIN_STRIDE_GRID")) stride_grid = (uint32_t)std::max(1, atoi(e));   // debug hook
     const dim3 grid(run_if ? std::min<uint32_t>(n_sub, stride_grid) : n_sub), block(JN_THREADS);   // stand-by launch: small striding grid
     unsigned long long* oc = (unsigned long long*)out_count;
 #define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if
@@ -1862,15 +1924,67 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
 // Optimistic narrow pipeline for one side (see ReserveArgs): reserving first pass + no-histogram second pass over
 // (key32, row id) tuples.  Anything that does not fit -- a key outside [0, 2^32), a bucket or slot overflow -- raises
 // *wide and the 64-bit pipeline behind takes over; there is no stand-by path of its own.
+// A/B hooks for the round-2 narrow kernels (scripts/ab_env.py): GOLAP_P1N = 0 (k_scatter_big) | 24 | 18 | 16, GOLAP_P2R = 0 (k_scatter_wc) | 4 | 2
+static int p1n_variant() { const char* e = knob("GOLAP_P1N"); return e ? atoi(e) : 118; }
+static int p2r_variant() { const char* e = knob("GOLAP_P2R"); return e ? atoi(e) : 104; }
+
+// rows per tile of the first-pass kernel launch_part1_narrow will choose (chunks are cut in whole tiles of it)
+static uint32_t part1_narrow_tile() {
+    const int v1 = p1n_variant();
+    if (v1 == 16 || v1 == 116) return 16 * P1N_THREADS;
+    if (v1 == 24 || v1 == 124 || v1 == 0) return 24 * P1N_THREADS;
+    return 18 * P1N_THREADS;
+}
+
+// first pass of the narrow pipeline (also the exchange-time partition of the multi-GPU fast path)
+static void launch_part1_narrow(hipStream_t st, uint64_t in_keys, uint32_t rid_base, uint32_t nc, const uint32_t* c_off, const uint32_t* c_len,
+                                uint64_t tmp_rows, const PassCfg& cfg, const ReserveArgs& rsa) {
+    const int v1 = p1n_variant();
+    const bool al16 = (in_keys & 15) == 0;
+    const uint32_t F1 = cfg.F;
+#define GOLAP_P1N(RPT, WIN, VEC, ASM, ...)                                                                                                            \
+    hipLaunchKernelGGL((k_part1_narrow<RPT, WIN, VEC, ASM, ##__VA_ARGS__>), dim3(nc), dim3(P1N_THREADS), part1_narrow_lds_bytes(F1, WIN), st, (const long long*)in_keys, \
+                       rid_base, c_off, c_len, (uint2*)tmp_rows, cfg, rsa)
+    if (v1 == 901) GOLAP_P1N(18, 18432, true, false, 1);          // 9xx: timing-only diagnostic builds (scripts/ab_p12.py)
+    else if (v1 == 902) GOLAP_P1N(18, 18432, true, false, 2);
+    else if (v1 == 903) GOLAP_P1N(18, 18432, true, false, 3);
+    else if (v1 == 118 && al16) GOLAP_P1N(18, 18432, true, true);
+    else if (v1 == 116 && al16) GOLAP_P1N(16, 16384, true, true);
+    else if (v1 == 24 || v1 == 124) GOLAP_P1N(24, 12288, false, false);
+    else if ((v1 == 18 || v1 == 118) && al16) GOLAP_P1N(18, 18432, true, false);
+    else if (v1 == 18 || v1 == 118) GOLAP_P1N(18, 18432, false, false);
+    else if ((v1 == 16 || v1 == 116) && al16) GOLAP_P1N(16, 16384, true, false);
+    else if (v1 == 16 || v1 == 116) GOLAP_P1N(16, 16384, false, false);
+    else
+        hipLaunchKernelGGL((k_scatter_big<1, 24, 1024, 12288, 4, false, 3, true, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F1, 12288, 1024), st,
+                           (const long long*)in_keys, rid_base, c_off, c_len, (const uint32_t*)nullptr, (long long*)tmp_rows, (uint32_t*)nullptr, cfg, rsa);
+#undef GOLAP_P1N
+}
+
+// last pass of the narrow pipeline: per-bucket LDS rings (k_part2_ring); F <= P2R_MAX_F
+static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint64_t out_rows, const PassCfg& cfg, const FixedArgs& fx, const SegSrc& seg) {
+    const int v2 = p2r_variant();
+#define GOLAP_P2R(RPT, ASM, ...)                                                                                                          \
+    hipLaunchKernelGGL((k_part2_ring<RPT, 32, ASM, ##__VA_ARGS__>), dim3(G), dim3(P2R_THREADS), part2_ring_lds_bytes(cfg.F, 32), st, (const uint2*)in_rows, \
+                       (uint2*)out_rows, cfg, fx, seg)
+    if (v2 == 902) GOLAP_P2R(4, false, 2);
+    else if (v2 == 4) GOLAP_P2R(4, false);
+    else if (v2 == 2) GOLAP_P2R(2, false);
+    else GOLAP_P2R(4, true);
+#undef GOLAP_P2R
+}
+
 static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, uint64_t in_keys, uint32_t rid_base, uint64_t n_rows,
                                uint64_t tmp_rows, uint64_t final_rows_ptr, uint32_t* wide, const uint32_t* zero_word, SideResult& res) {
     const PassPlan& p1 = plan.passes[0];
     const PassPlan& p2 = plan.passes[1];
     const uint32_t F1 = p1.cfg.F, G = p2.G, F2 = p2.cfg.F;
-    const uint32_t cap1 = (uint32_t)reserve_cap(n_rows, F1);
     uint32_t chunk_rows = 0;
-    const uint32_t nc = first_pass_chunks(n_rows, &chunk_rows);
-    uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F1 * 4);
+    const uint32_t nc = first_pass_chunks(n_rows, &chunk_rows, part1_narrow_tile());
+    const uint32_t nsub = (p2r_variant() == 0 || F2 > (uint32_t)P2R_MAX_F) ? 1u : narrow_nsub();   // (the write-combining second pass reads one extent per group)
+    const uint32_t cap1 = (uint32_t)reserve_cap_sub(n_rows, F1, nsub, nc, chunk_rows);
+    if ((uint64_t)cap1 * F1 * nsub >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "narrow pipeline: first-pass positions exceed u32");
+    uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F1 * nsub * 4);
     uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
     uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
     uint32_t* slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(G + 1) * 4);
@@ -1879,29 +1993,31 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     uint32_t* sub_len = (uint32_t*)ws_take(ctx, (uint64_t)G * F2 * 4);
     if (!cursor || !c_off || !c_len || !slot_base || !slot_cap || !sub_start || !sub_len)
         return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (narrow pipeline arrays)");
-    GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F1 * 4));
+    GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F1 * nsub * 4));
     hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_rows, chunk_rows, nc, c_off, c_len);
     {
         PassCfg cfg = p1.cfg;
         cfg.S = nc;
         KernelTimer t(ctx, "radix_scatter_p1", st, 16 * n_rows);
-        hipLaunchKernelGGL((k_scatter_big<1, 24, 1024, 12288, 4, false, 3, true, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F1, 12288, 1024), st,
-                           (const long long*)in_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,
-                           (long long*)tmp_rows, (uint32_t*)nullptr, cfg, ReserveArgs{cursor, cap1, wide, wide, nullptr});
+        const ReserveArgs rsa{cursor, cap1, wide, wide, nullptr, nsub};
+        launch_part1_narrow(st, in_keys, rid_base, nc, c_off, c_len, tmp_rows, cfg, rsa);
     }
     GOLAP_HIP_TRY(ctx, hipGetLastError());
-    GroupSrc groups{nullptr, 0, cursor, cap1, zero_word};
-    uint32_t sigmas = 6, pad = 48;
-    if (const char* env = getenv("GOLAP_SLOT_SIGMAS")) { sigmas = (uint32_t)atoi(env); pad = sigmas ? 48 : 0; }
+    GroupSrc groups{nullptr, 0, cursor, cap1, zero_word, nsub};
+    uint32_t sigmas, pad;
+    provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
     hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F2, sigmas, pad, slot_base, slot_cap);
     {
         FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, wide, wide};
         PassCfg cfg = p2.cfg;
         cfg.S = 1;
         KernelTimer t(ctx, "radix_scatter_p2", st, 16 * n_rows);
-        hipLaunchKernelGGL((k_scatter_wc<2, true, 16, true, WCN_RPT, WCN_CAP>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F2, WCN_CAP, 8), st, (const long long*)tmp_rows,
-                           (const uint32_t*)nullptr, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           (long long*)final_rows_ptr, (uint32_t*)nullptr, cfg, fx, (const uint32_t*)nullptr);
+        if (p2r_variant() != 0 && F2 <= (uint32_t)P2R_MAX_F)
+            launch_part2_ring(st, G, tmp_rows, final_rows_ptr, cfg, fx, SegSrc{nullptr, nullptr, 0});
+        else
+            hipLaunchKernelGGL((k_scatter_wc<2, true, 16, true, WCN_RPT, WCN_CAP>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F2, WCN_CAP, 8), st, (const long long*)tmp_rows,
+                               (const uint32_t*)nullptr, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                               (long long*)final_rows_ptr, (uint32_t*)nullptr, cfg, fx, (const uint32_t*)nullptr);
     }
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     res = SideResult();
@@ -1918,13 +2034,13 @@ static bool partition_narrow_ok(uint32_t F, bool has_rids) { return use_big_scat
 static bool local_narrow_ok(const JoinPlan& plan) {
     for (const PassPlan& pp : plan.passes)
         if (pp.cfg.F < 32 || pp.cfg.F > (uint32_t)WC_MAX_F) return false;
-    const char* env = getenv("GOLAP_SCATTER");
+    const char* env = knob("GOLAP_SCATTER");
     return !(env && !strcmp(env, "v1"));
 }
 
 // Narrow keys are tried when both sides take the reserving + no-histogram flow (large two-pass joins).
 static bool use_narrow_keys(const JoinPlan& plan, uint64_t n_build, uint64_t n_probe) {
-    const char* env = getenv("GOLAP_NARROW");   // "0" disables (A/B hook)
+    const char* env = knob("GOLAP_NARROW");   // "0" disables (A/B hook)
     if (env && !strcmp(env, "0")) return false;
     return use_reserve_first_pass(plan, n_build, false, false) && use_reserve_first_pass(plan, n_probe, false, false);
 }
@@ -2051,6 +2167,7 @@ int32_t golap_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_joi
     if (strategy != GOLAP_JOIN_RADIX_HASH && strategy != GOLAP_JOIN_BROADCAST_HASH)
         return fail(ctx, GOLAP_ERR_INVALID_ARG, "unknown join strategy %d", (int)strategy);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     GOLAP_TRY(zero_async(ctx, st, (void*)((void*)p->out_count_ptr), 8));
@@ -2096,8 +2213,16 @@ int32_t golap_join_plan_get(golap_ctx* ctx, uint64_t n_build, uint32_t n_owners,
 
 // radix_partition_kernel as a stand-alone step: the reference's 256 partitions (join_kernels.cuh:22-23, :69),
 // optionally refined by `extra_bits` more hash bits so the receiving rank needs one local pass less.
+static int32_t radix_partition_impl(golap_ctx* ctx, const golap_partition_params* p, hipStream_t st);
 int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* p, void* stream) {
     if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return radix_partition_impl(ctx, p, pick_stream(ctx, stream));
+}
+// (call with ctx->mu held)
+static int32_t radix_partition_impl(golap_ctx* ctx, const golap_partition_params* p, hipStream_t st) {
     if (!p->out_offsets_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_offsets_ptr is null");
     if (p->n_rows && (!p->key_ptr || !p->out_key_ptr || (!p->out_row_id_ptr && !p->narrow))) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
     if (p->narrow && (p->row_id_ptr || !p->wide_flag_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "narrow partition needs implicit row ids and a wide_flag_ptr");
@@ -2105,9 +2230,6 @@ int32_t golap_radix_partition(golap_ctx* ctx, const golap_partition_params* p, v
         return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_owners must be a power of two <= 256");
     if (p->extra_bits > 2) return fail(ctx, GOLAP_ERR_INVALID_ARG, "extra_bits must be 0..2");
     if (p->n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32: at most 2^32-16 rows");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = pick_stream(ctx, stream);
     GOLAP_TRY(ensure_scatter_lds(ctx));
     const uint32_t F = 256u << p->extra_bits;
     JoinPlan plan;
@@ -2173,7 +2295,7 @@ static void make_local_plan(const golap_join_partitioned_plan* p, JoinPlan& plan
         if (avg + 4.5 * std::sqrt(avg) <= (double)JN_CAP) break;
     }
     if (need == 0) need = 1;   // always run at least one local pass: it also merges the source segments
-    if (const char* env = getenv("GOLAP_LOCAL_BITS")) {   // experiment hook: total local bits
+    if (const char* env = knob("GOLAP_LOCAL_BITS")) {   // experiment hook: total local bits
         uint32_t v = (uint32_t)strtoul(env, nullptr, 10);
         if (v >= 1 && v <= 20) need = v;
     }
@@ -2205,6 +2327,7 @@ static int32_t part_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, 
     if (p->pre_bits < 8 || p->pre_bits > 12) return fail(ctx, GOLAP_ERR_INVALID_ARG, "pre_bits must be in 8..12");
     if (p->build_rows >= 0xFFFFFFF0ull || p->probe_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "too many rows for u32 offsets");
     PartJoinState& S = pjs_of(ctx);
+    if (S.active) return fail(ctx, GOLAP_ERR_INVALID_ARG, "golap_join_partitioned_begin: a partitioned join is already open on this context (finish or abort it)");
     S = PartJoinState();
     S.n_groups = p->n_groups;
     S.n_sources = p->n_sources;
@@ -2232,7 +2355,13 @@ static int32_t part_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, 
         S.buf[0].tmp_rids[i] = S.buf[1].tmp_rids[i] = tr;
     }
     S.active = true;
+    ctx->ws_owned = true;   // until part_finish / part_abort: ws_begin refuses every other caller (their bump allocation would overwrite this join's rows)
     return GOLAP_OK;
+}
+
+static void part_abort(golap_ctx* ctx) {
+    pjs_of(ctx).active = false;
+    ctx->ws_owned = false;
 }
 
 static int32_t part_side(golap_ctx* ctx, int32_t which, const golap_partitioned_side* side, hipStream_t st) {
@@ -2261,13 +2390,28 @@ static int32_t part_side(golap_ctx* ctx, int32_t which, const golap_partitioned_
     return GOLAP_OK;
 }
 
-static int32_t part_finish(golap_ctx* ctx, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, hipStream_t st) {
+static int32_t part_finish(golap_ctx* ctx, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, hipStream_t st, int32_t join_type = 0) {
     PartJoinState& S = pjs_of(ctx);
     if (!S.active || !S.done[0] || !S.done[1]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "golap_join_partitioned_finish needs begin + both sides");
     GOLAP_TRY(zero_async(ctx, st, (void*)((void*)out_count), 8));
     S.active = false;
-    if (S.rows[0] == 0 || S.rows[1] == 0) return GOLAP_OK;
-    GOLAP_TRY(launch_lds_join(ctx, st, S.plan, S.res[0], S.res[1], S.rows[0], S.rows[1], out_pairs, out_count, max_pairs, 0, S.narrow));
+    ctx->ws_owned = false;
+    if ((S.rows[0] == 0 && !(join_type & 2)) || (S.rows[1] == 0 && !(join_type & 1)) || (S.rows[0] == 0 && S.rows[1] == 0)) { ws_end(ctx, st); return GOLAP_OK; }
+    if (S.rows[0] == 0 || S.rows[1] == 0) {
+        // an outer join keeps the rows of the non-empty side: the empty side has no partitioned form (run_side was skipped), so
+        // describe it as sub-partitions without rows
+        SideResult& e = S.res[S.rows[0] == 0 ? 0 : 1];
+        const uint64_t n_off = S.plan.n_sub + 1;
+        uint32_t* zeros = (uint32_t*)ws_take(ctx, n_off * 4);
+        if (!zeros) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
+        GOLAP_TRY(zero_async(ctx, st, zeros, n_off * 4));
+        e = SideResult();
+        e.off = zeros;
+        e.stride = 1;
+        e.keys = (const long long*)S.buf[0].final_keys;
+        e.rids = (const uint32_t*)S.buf[0].final_rids;
+    }
+    GOLAP_TRY(launch_lds_join(ctx, st, S.plan, S.res[0], S.res[1], S.rows[0], S.rows[1], out_pairs, out_count, max_pairs, join_type, S.narrow));
     ws_end(ctx, st);
     return GOLAP_OK;
 }
@@ -2278,7 +2422,7 @@ extern "C" {
 
 int32_t golap_join_partitioned_narrow_ok(const golap_join_partitioned_plan* p) {
     if (!p || p->n_groups == 0 || p->pre_bits < 8 || p->pre_bits > 12) return 0;
-    const char* env = getenv("GOLAP_NARROW");
+    const char* env = knob("GOLAP_NARROW");
     if (env && !strcmp(env, "0")) return 0;
     JoinPlan plan;
     make_local_plan(p, plan);
@@ -2288,6 +2432,7 @@ int32_t golap_join_partitioned_narrow_ok(const golap_join_partitioned_plan* p) {
 int32_t golap_join_partitioned_begin(golap_ctx* ctx, const golap_join_partitioned_plan* p, void* stream) {
     if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return part_begin(ctx, p, pick_stream(ctx, stream));
 }
@@ -2295,6 +2440,7 @@ int32_t golap_join_partitioned_begin(golap_ctx* ctx, const golap_join_partitione
 int32_t golap_join_partitioned_side(golap_ctx* ctx, int32_t which, const golap_partitioned_side* side, void* stream) {
     if (!ctx || !side) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return part_side(ctx, which, side, pick_stream(ctx, stream));
 }
@@ -2304,6 +2450,7 @@ int32_t golap_join_partitioned_finish(golap_ctx* ctx, uint64_t out_pairs_ptr, ui
     if (!out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
     if (max_pairs && !out_pairs_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_pairs_ptr is null but max_pairs > 0");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return part_finish(ctx, out_pairs_ptr, out_count_ptr, max_pairs, pick_stream(ctx, stream));
 }
@@ -2313,6 +2460,7 @@ int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_para
     if (!ctx || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     golap_join_partitioned_plan pl;
@@ -2324,9 +2472,20 @@ int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_para
     pl.build_rows = p->build.n_rows;
     pl.probe_rows = p->probe.n_rows;
     GOLAP_TRY(part_begin(ctx, &pl, st));
-    GOLAP_TRY(part_side(ctx, 0, &p->build, st));
-    GOLAP_TRY(part_side(ctx, 1, &p->probe, st));
-    return part_finish(ctx, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, st);
+    int32_t rc = part_side(ctx, 0, &p->build, st);
+    if (rc == GOLAP_OK) rc = part_side(ctx, 1, &p->probe, st);
+    if (rc == GOLAP_OK) rc = part_finish(ctx, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, st);
+    if (rc != GOLAP_OK) part_abort(ctx);
+    return rc;
+}
+
+int32_t golap_join_partitioned_abort(golap_ctx* ctx) {
+    if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    part_abort(ctx);
+    return GOLAP_OK;
 }
 
 }  // extern "C"
+
+#include "golap_shard.inc.h"

@@ -704,6 +704,12 @@ __global__ __launch_bounds__(OP_THREADS) void k_verify_pairs(const uint2* __rest
     }
 }
 
+static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st);
+static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st);
+__global__ void k_fill_i64(long long* __restrict__ a, unsigned long long n, long long v) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) a[i] = v;
+}
+
 static uint32_t stream_grid(golap_ctx* ctx, uint64_t n, uint32_t per_block) {
     uint64_t want = ceil_div(std::max<uint64_t>(1, n), per_block);
     uint64_t cap = (uint64_t)ctx->prop.multiProcessorCount * 8;   // guideline 11: cap at ~2048 blocks, grid-stride the rest
@@ -722,6 +728,7 @@ int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, 
     if (pred->op < 0 || pred->op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", pred->op);
     if (p->n_rows == 0) return GOLAP_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     KernelTimer t(ctx, "filter_mask", st, 9 * p->n_rows);
@@ -748,6 +755,7 @@ int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred,
     if (pred->op < 0 || pred->op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", pred->op);
     if (n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32: at most 2^32-16 rows per batch");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     if (n_rows == 0) { GOLAP_TRY(zero_async(ctx, st, (void*)((void*)out_count_ptr), 8)); return GOLAP_OK; }
@@ -781,6 +789,7 @@ int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_p
     if (n_indices_max == 0) return GOLAP_OK;
     if (!column_ptr || !indices_ptr || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     KernelTimer t(ctx, "take_8byte", st, 20 * n_indices_max);
@@ -797,6 +806,7 @@ int32_t golap_filter_sum(golap_ctx* ctx, const golap_filter_predicate* pred, uin
     if (n_rows && (!key_column_ptr || !value_column_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
     if (pred->op < 0 || pred->op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", pred->op);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     const uint32_t grid = stream_grid(ctx, n_rows, OP_THREADS * 8);
@@ -833,15 +843,27 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
         if (specs[i].output_col_index >= n_specs) return fail(ctx, GOLAP_ERR_INVALID_ARG, "spec %u: output_col_index out of range", i);
     }
     if (p->n_rows && !p->value_ptrs) return fail(ctx, GOLAP_ERR_INVALID_ARG, "value_ptrs is null");
+    if (p->key_mode != GOLAP_KEYS_DENSE && p->key_mode != GOLAP_KEYS_HASHED) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad key_mode %d", p->key_mode);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
+    if (p->key_mode == GOLAP_KEYS_HASHED) return aggregate_hashed(ctx, specs, n_specs, p, st);
+    return aggregate_dense(ctx, specs, n_specs, p, st);
+}
+
+}  // extern "C"
+
+namespace golap {
+
+// the dense path: slot = key % n_groups (join_kernels.cuh:230); call with ctx->mu held
+static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st) {
     const uint32_t G = p->n_groups;
     const bool grouped = p->group_key_ptr != 0;
     // LDS path when the 28-byte-per-group table fits comfortably (2 work-groups per CU)
     const bool lds_path = grouped && (uint64_t)G * 28 <= 64 * 1024;
     // beyond one LDS table: partition by slot range, then LDS-aggregate (big inputs only; GOLAP_AGG_PART=0 -> global atomics)
-    const char* part_env = getenv("GOLAP_AGG_PART");
+    const char* part_env = knob("GOLAP_AGG_PART");
     const bool part_path = grouped && !lds_path && G <= (uint32_t)AG_GB * AG_MAX_B && p->n_rows >= (1ull << 22) && p->n_rows < 0xFFFFFFF0ull &&
                            !(part_env && !strcmp(part_env, "0"));
     const uint32_t pB = part_path ? (uint32_t)ceil_div(G, AG_GB) : 0;
@@ -856,7 +878,7 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     uint64_t rows_per_block = 0;
     if (lds_path) {
         uint32_t per_cu = 2;
-        if (const char* e = getenv("GOLAP_AGG_WGS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));   // A/B hook
+        if (const char* e = knob("GOLAP_AGG_WGS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));   // A/B hook
         lds_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * per_cu, ceil_div(std::max<uint64_t>(1, p->n_rows), 4096)));
         rows_per_block = ceil_div(std::max<uint64_t>(1, p->n_rows), lds_grid);
     }
@@ -881,25 +903,25 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
         p_bsums = (uint32_t*)ws_take(ctx, ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4);
         p_slab = (double*)ws_take(ctx, (uint64_t)pB * pW * 4 * AG_GB * 8);
         if (!p_slot || !p_val || !p_hist || !p_bsums || !p_slab) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted (partition buffers)");
-        static bool attr2 = false;
-        if (!attr2) {
+        if (ctx->attr_done.size() < 3) ctx->attr_done.resize(3, false);   // per context = per device (golap_internal.h)
+        if (!ctx->attr_done[1]) {
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB * 28 + 16));
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB * 28 + 16));
             const void* big[] = {(const void*)k_agg_scatter_big<int, true>, (const void*)k_agg_scatter_big<int, false>,
                                  (const void*)k_agg_scatter_big<long long, true>, (const void*)k_agg_scatter_big<long long, false>};
             for (const void* f : big) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AGB_LDS));
-            attr2 = true;
+            ctx->attr_done[1] = true;
         }
     }
     if (lds_path) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        if (ctx->attr_done.size() < 3) ctx->attr_done.resize(3, false);
+        if (!ctx->attr_done[2]) {
             const void* fns[] = {(const void*)k_group_lds<int, true, true>,        (const void*)k_group_lds<int, true, false>,
                                  (const void*)k_group_lds<int, false, true>,       (const void*)k_group_lds<int, false, false>,
                                  (const void*)k_group_lds<long long, true, true>,  (const void*)k_group_lds<long long, true, false>,
                                  (const void*)k_group_lds<long long, false, true>, (const void*)k_group_lds<long long, false, false>};
             for (const void* f : fns) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            attr_done = true;
+            ctx->attr_done[2] = true;
         }
     }
     // one pass per distinct value column; every spec on that column is finalised from the same stats
@@ -1013,11 +1035,177 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     return GOLAP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// GOLAP_KEYS_HASHED: GROUP BY over arbitrary int64 / int32 keys.
+// aggregate_kernel.rs:76-77 plans "a global-memory hash table with open addressing"; the kernel the reference ships
+// (join_kernels.cuh:216-240) has none -- it adds into aggregates[key % num_groups] and silently merges congruent keys.
+// Here a key -> slot table in device memory gives every distinct key a dense slot, and the dense machinery above runs on
+// the slots:
+//   k_hk_insert   every row's key into an open-addressing table (linear probing, 64-bit CAS on the key word only; no row
+//                 waits for another -- slots get their ids in a later kernel, so there is no spin inside a wave).  A
+//                 direct-mapped per-work-group LDS cache of "keys already in the table" keeps repeated keys (the common
+//                 case: few groups) away from global memory;
+//   flat scan     occupied entries -> exclusive prefix = slot ids in TABLE order (reproducible: independent of arrival order);
+//   k_hk_keys     the key of every slot (out_keys), the number of slots (out_n_groups);
+//   k_hk_lookup   key -> slot id per row (read-only probing, LDS cache of (key, id)), written as a u32 column;
+//   aggregate_dense on the u32 column (every slot id < n_groups, so its `% n_groups` is the identity).
+// The empty-entry marker is INT64_MIN; a real key INT64_MIN gets the slot after the table's (a flag records its presence).
+// ---------------------------------------------------------------------------
+constexpr long long HK_EMPTY = (long long)0x8000000000000000ull;
+constexpr int HK_CACHE = 2048;   // direct-mapped LDS cache entries per work-group
+
+__device__ __forceinline__ uint32_t hk_hash(long long key, uint32_t mask) {
+    unsigned long long z = (unsigned long long)key * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 32;
+    return (uint32_t)z & mask;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(OP_THREADS) void k_hk_insert(const KeyT* __restrict__ keys, unsigned long long n, long long* __restrict__ table, uint32_t mask,
+                                                          uint32_t* __restrict__ flags /*[0] INT64_MIN seen, [1] table full*/) {
+    __shared__ long long s_seen[HK_CACHE];
+    for (uint32_t i = threadIdx.x; i < HK_CACHE; i += OP_THREADS) s_seen[i] = HK_EMPTY;
+    __syncthreads();
+    for (unsigned long long i = (unsigned long long)blockIdx.x * OP_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * OP_THREADS) {
+        const long long key = (long long)keys[i];
+        if (key == HK_EMPTY) { flags[0] = 1u; continue; }   // (same value from every writer)
+        const uint32_t h = hk_hash(key, mask);
+        const uint32_t c = h & (HK_CACHE - 1);
+        if (s_seen[c] == key) continue;                      // this work-group already made sure the key is in the table
+        uint32_t s = h, probes = 0;
+        for (;;) {
+            const long long cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == key) break;
+            if (cur == HK_EMPTY) {
+                long long expected = HK_EMPTY;
+                if (__hip_atomic_compare_exchange_strong(&table[s], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || expected == key) break;
+            }
+            s = (s + 1) & mask;
+            if (++probes > mask) { flags[1] = 1u; break; }   // every entry holds another key: n_groups was far too small
+        }
+        s_seen[c] = key;   // (an aligned 8-byte LDS store: readers see the old or the new key, never a mix)
+    }
+}
+
+__global__ __launch_bounds__(OP_THREADS) void k_hk_mark(const long long* __restrict__ table, uint32_t cap, uint32_t* __restrict__ mark /*[cap + 1]*/) {
+    for (uint32_t s = blockIdx.x * OP_THREADS + threadIdx.x; s <= cap; s += gridDim.x * OP_THREADS) mark[s] = (s < cap && table[s] != HK_EMPTY) ? 1u : 0u;
+}
+
+// after the scan: ids[s] = slot of table entry s, ids[cap] = number of occupied entries
+__global__ __launch_bounds__(OP_THREADS) void k_hk_keys(const long long* __restrict__ table, const uint32_t* __restrict__ ids, uint32_t cap, uint32_t n_groups,
+                                                        const uint32_t* __restrict__ flags, long long* __restrict__ out_keys, uint32_t* __restrict__ out_n) {
+    const uint32_t used = ids[cap];
+    for (uint32_t s = blockIdx.x * OP_THREADS + threadIdx.x; s < cap; s += gridDim.x * OP_THREADS) {
+        const long long k = table[s];
+        if (k != HK_EMPTY && ids[s] < n_groups && out_keys) out_keys[ids[s]] = k;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t total = used + (flags[0] ? 1u : 0u);
+        if (flags[0] && used < n_groups && out_keys) out_keys[used] = HK_EMPTY;   // the key INT64_MIN owns the slot behind the table's
+        if (out_n) *out_n = flags[1] ? 0xFFFFFFFFu : total;
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict__ keys, unsigned long long n, const long long* __restrict__ table,
+                                                          const uint32_t* __restrict__ ids, uint32_t mask, uint32_t cap, uint32_t n_groups,
+                                                          uint32_t* __restrict__ slot_out) {
+    __shared__ volatile long long s_key[HK_CACHE];   // (volatile: the reader's two looks at the key must be two loads)
+    __shared__ volatile uint32_t s_id[HK_CACHE];
+    for (uint32_t i = threadIdx.x; i < HK_CACHE; i += OP_THREADS) s_key[i] = HK_EMPTY;
+    __syncthreads();
+    const uint32_t used = ids[cap];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * OP_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * OP_THREADS) {
+        const long long key = (long long)keys[i];
+        uint32_t id;
+        if (key == HK_EMPTY) {
+            id = used;
+        } else {
+            const uint32_t h = hk_hash(key, mask);
+            const uint32_t c = h & (HK_CACHE - 1);
+            // the cache entry is (key, id) written as two words: take the id only if the key matches before AND after reading it
+            const long long ck = s_key[c];
+            const uint32_t cid = s_id[c];
+            if (ck == key && s_key[c] == key) {
+                id = cid;
+            } else {
+                uint32_t s = h, probes = 0;
+                while (table[s] != key && probes <= mask) { s = (s + 1) & mask; ++probes; }   // (the key is there unless the table overflowed)
+                id = ids[s];
+                s_key[c] = HK_EMPTY;   // invalidate, publish the id, publish the key: a reader never pairs a key with another key's id
+                __threadfence_block();
+                s_id[c] = id;
+                __threadfence_block();
+                s_key[c] = key;
+            }
+        }
+        slot_out[i] = id < n_groups ? id : id % n_groups;   // (ids beyond the bound only occur when the bound was too small: results are void, stay in range)
+    }
+}
+
+static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st) {
+    if (!p->group_key_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "GOLAP_KEYS_HASHED needs a group key column");
+    if (p->n_groups > (1u << 23)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^23 groups (key table of 2^24 entries)");
+    if (p->n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^32-16 rows");
+    uint32_t cap = 1024;
+    while (cap < 2 * p->n_groups) cap <<= 1;   // load factor <= 0.5 while the bound holds
+    const uint32_t mask = cap - 1;
+    const uint64_t n = p->n_rows;
+    GOLAP_TRY(aux_begin(ctx, round_up((uint64_t)cap * 8, 256) + 2 * round_up(((uint64_t)cap + 1) * 4, 256) + round_up(std::max<uint64_t>(n, 1) * 4, 256) + 8192, st));
+    long long* table = (long long*)aux_take(ctx, (uint64_t)cap * 8);
+    uint32_t* ids = (uint32_t*)aux_take(ctx, ((uint64_t)cap + 1) * 4);
+    uint32_t* bsums = (uint32_t*)aux_take(ctx, ceil_div((uint64_t)cap + 1, FLAT_SCAN_BLOCK) * 4 + 4);
+    uint32_t* slots = (uint32_t*)aux_take(ctx, std::max<uint64_t>(n, 1) * 4);
+    uint32_t* flags = (uint32_t*)aux_take(ctx, 8);
+    if (!table || !ids || !bsums || !slots || !flags) return fail(ctx, GOLAP_ERR_OOM, "aggregate scratch exhausted (key table)");
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    const uint32_t tgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, ceil_div((uint64_t)cap + 1, OP_THREADS)));
+    const uint32_t rgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, ceil_div(std::max<uint64_t>(n, 1), OP_THREADS * 8)));
+    const uint64_t key_bytes = p->key_dtype == GOLAP_DT_INT32 ? 4 : 8;
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync(flags, 0, 8, st));
+    {   // every entry = HK_EMPTY (0x80 in the top byte only: a kernel, not a byte memset)
+        KernelTimer t(ctx, "hash_keys_insert", st, key_bytes * n);
+        hipLaunchKernelGGL(k_fill_i64, dim3(tgrid), dim3(OP_THREADS), 0, st, table, (unsigned long long)cap, HK_EMPTY);
+        if (n) {
+            if (p->key_dtype == GOLAP_DT_INT32)
+                hipLaunchKernelGGL(k_hk_insert<int>, dim3(rgrid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, (unsigned long long)n, table, mask, flags);
+            else
+                hipLaunchKernelGGL(k_hk_insert<long long>, dim3(rgrid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, (unsigned long long)n, table, mask, flags);
+        }
+    }
+    hipLaunchKernelGGL(k_hk_mark, dim3(tgrid), dim3(OP_THREADS), 0, st, (const long long*)table, cap, ids);
+    GOLAP_TRY(flat_scan(ctx, st, ids, cap + 1, bsums));
+    hipLaunchKernelGGL(k_hk_keys, dim3(tgrid), dim3(OP_THREADS), 0, st, (const long long*)table, (const uint32_t*)ids, cap, p->n_groups, (const uint32_t*)flags,
+                       (long long*)p->out_keys_ptr, (uint32_t*)p->out_n_groups_ptr);
+    if (n) {
+        KernelTimer t(ctx, "hash_keys_lookup", st, (key_bytes + 4) * n);
+        if (p->key_dtype == GOLAP_DT_INT32)
+            hipLaunchKernelGGL(k_hk_lookup<int>, dim3(rgrid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, (unsigned long long)n, (const long long*)table,
+                               (const uint32_t*)ids, mask, cap, p->n_groups, slots);
+        else
+            hipLaunchKernelGGL(k_hk_lookup<long long>, dim3(rgrid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, (unsigned long long)n,
+                               (const long long*)table, (const uint32_t*)ids, mask, cap, p->n_groups, slots);
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    golap_aggregate_params q = *p;
+    q.group_key_ptr = (uint64_t)slots;
+    q.key_dtype = GOLAP_DT_INT32;
+    q.key_mode = GOLAP_KEYS_DENSE;
+    const int32_t rc = aggregate_dense(ctx, specs, n_specs, &q, st);
+    aux_end(ctx, st);
+    return rc;
+}
+
+}  // namespace golap
+
+extern "C" {
+
 int32_t golap_widen_to_8byte(golap_ctx* ctx, uint64_t in_ptr, int32_t in_dtype, uint64_t validity_ptr, uint64_t n_rows, uint64_t out_ptr, void* stream) {
     if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
     if (n_rows == 0) return GOLAP_OK;
     if (!in_ptr || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     const dim3 g(stream_grid(ctx, n_rows, OP_THREADS * 4)), b(OP_THREADS);
@@ -1048,6 +1236,7 @@ int32_t golap_generate(golap_ctx* ctx, int32_t kind, uint64_t seed, uint64_t fir
     if (kind < GOLAP_GEN_BUILD_KEYS || kind > GOLAP_GEN_SHIFT32_I64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad generator kind %d", kind);
     if (kind != GOLAP_GEN_SHIFT32_I64 && modulus == 0) return fail(ctx, GOLAP_ERR_INVALID_ARG, "modulus must be > 0");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     hipLaunchKernelGGL(k_generate, dim3(stream_grid(ctx, count, OP_THREADS * 4)), dim3(OP_THREADS), 0, st, kind, (unsigned long long)seed,
@@ -1061,6 +1250,7 @@ int32_t golap_verify_pairs(golap_ctx* ctx, uint64_t pairs_ptr, uint64_t n_pairs,
     if (!ctx || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (n_pairs && (!pairs_ptr || !build_key_ptr || !probe_key_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     GOLAP_TRY(zero_async(ctx, st, (void*)((void*)out_ptr), 32));

@@ -1,0 +1,478 @@
+// golap_part_narrow.h -- the two partition passes of the optimistic narrow-key pipeline, rewritten
+// in round 2 around the SQ counter profile of their predecessors (profiles/r02_sq0: ~60 vector + 8-13 LDS
+// instructions per row, 7 barrier-separated phases per tile, one 1024-thread work-group per CU so nothing overlaps):
+//
+//   k_part1_narrow  global first pass, int64 keys in -> (key32, row id) tuples out, bucket ranges reserved by per-tile
+//                   atomics (ReserveArgs).  Same register-resident big tile as k_scatter_big, but
+//                     * the LDS window row carries (key32, bucket | tile position) instead of (key32, row id): the
+//                       write-out loop reads the bucket back instead of hashing the key a second time, and one
+//                       `delta[bucket]` lookup replaces the s_gpos / s_start pair; the row id is rebuilt from the
+//                       tile position (row ids are implicit in the first pass, join_kernels.cuh:75);
+//                     * the next tile's keys are requested as soon as the last window has been staged (the key
+//                       registers are dead from then on), so HBM reads overlap the write-out instead of starting
+//                       after it; 16-byte loads when the column is 16-byte aligned;
+//                     * s_cnt is re-zeroed by the thread that consumed it: one barrier less per tile.
+//   k_part2_ring    local last pass over one group per work-group, tuples in -> tuples out into slot-provisioned
+//                   sub-partitions (FixedArgs).  No tile sort and no carry copy: every bucket owns a RING of R rows in
+//                   LDS; a row takes the next ring position of its bucket with one returning LDS atomic and is stored
+//                   there directly; after each tile every bucket with a complete 16-row line (one 128-byte HBM line)
+//                   writes it out, whole, by one 16-lane group.  Two barriers per tile instead of seven, ~4 LDS
+//                   operations per row instead of ~13.  A row that finds its ring full (bucket received more than R
+//                   minus its fill in one tile: 0.02 % of (tile, bucket) pairs at 8 rows per bucket and tile) keeps its
+//                   reserved position and is placed after the flush (extra rounds until nothing is pending).
+//
+// ASM forms: vmcnt counts a wave's loads AND stores in issue order, and hipcc, which cannot count stores issued under
+// data-dependent control flow, waits vmcnt(0) at the first use of a prefetched key -- i.e. for every store of the
+// write-out just issued (p1) or even for the prefetch issued behind it (p2).  The ASM forms hide these loads and stores
+// from hipcc (cdna_hip_programming.md 5.7 item 1, form (ii)) and issue every store at wave-uniform control flow
+// (predicated through EXEC inside the statement), so the number of stores younger than a load is a compile-time
+// constant and the wait is a counted vmcnt(N): N is never larger than the true number of younger operations, extra
+// stores (retry rounds) only make the wait stricter.
+// Both keep the device-side contracts of the kernels they replace: rs.wide / fx.overflow raise the same device words,
+// the layouts (bucket ranges of `cap` rows; sub_start / sub_len per sub-partition) are identical, so the 64-bit
+// pipeline standing by behind them and the LDS join are unchanged.
+#pragma once
+
+namespace golap {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ld16_hidden(u32x4& v, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ld8_hidden(u32x2& v, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
+// 8-byte store of the lanes with ok != 0; the instruction itself is always issued (one vmcnt event per call)
+__device__ __forceinline__ void st8_hidden_if(void* p, u32x2 v, uint32_t ok) {
+    unsigned long long saved;
+    asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_store_dwordx2 %1, %2, off\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(p), "v"(v), "v"(ok)
+                 : "memory", "vcc", "scc");
+}
+// returning global atomic add of the active lanes (inactive lanes keep `ret`)
+__device__ __forceinline__ void atomic_add_rtn_hidden(uint32_t& ret, uint32_t* p, uint32_t v) {
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(ret) : "v"(p), "v"(v) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+__device__ __forceinline__ void pin(u32x4& v) { asm volatile("" : "+v"(v)); }   // no consumer of v is scheduled above this point
+__device__ __forceinline__ void pin(u32x2& v) { asm volatile("" : "+v"(v)); }
+// L2-served read of a word other work-groups may set (sc1 bypasses this CU's L1), hidden like the loads above.  (A scalar
+// `s_load_dword ... glc` poll by every wave was tried instead: 4096 uncached reads of ONE address per tile round serialise
+// at its memory channel -- the first pass ran 6 x slower.)
+__device__ __forceinline__ void ld4_hidden_sc1(uint32_t& v, const uint32_t* p) { asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory"); }
+
+constexpr int P1N_THREADS = 1024;
+constexpr int P1N_WAVES = P1N_THREADS / 64;
+
+static inline size_t part1_narrow_lds_bytes(uint32_t F, uint32_t win) { return (size_t)win * 8 + (size_t)F * 12 + (P1N_WAVES + 2) * 4 + 16; }
+
+// VEC2: 16-byte loads (needs a 16-byte aligned column); ASM: hidden loads/stores + counted waits (implies VEC2).
+// DIAG != 0: timing-only diagnostic builds for scripts/ab_p12.py (WRONG results, never launched by the product path):
+//   1 = write-out goes to the tile's own input positions (linear, no scatter), 2 = no stores at all, 3 = no loads (keys made up).
+template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG = 0>
+__global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* __restrict__ in_keys, uint32_t rid_base,
+                                                              const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
+                                                              uint2* __restrict__ out_rows, PassCfg cfg, ReserveArgs rs) {
+    constexpr int NT = P1N_THREADS, NW = P1N_WAVES;
+    constexpr int TILE = NT * RPT;
+    constexpr int ROUNDS = (TILE + WIN - 1) / WIN;
+    constexpr int STORES = WIN / NT;   // store instructions per wave behind the next tile's loads: those of the last window (ASM: all issued at uniform control flow)
+    static_assert(TILE <= 32768, "tile position is packed into 15 bits");
+    static_assert(!VEC2 || RPT % 2 == 0, "16-byte loads take two keys");
+    static_assert(!ASM || VEC2, "the hidden loads are the 16-byte ones");
+    static_assert(WIN % NT == 0 && STORES <= 60, "window rows per thread; vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    uint2* s_rows = reinterpret_cast<uint2*>(s_raw);                       // [WIN] (key32, bucket << 15 | tile position)
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_raw + (size_t)WIN * 8);   // [F] rows of the bucket in this tile
+    uint32_t* s_start = s_cnt + cfg.F;                                     // [F] tile-local slot of the bucket's first row
+    uint32_t* s_delta = s_start + cfg.F;                                   // [F] global position - tile-local slot
+    uint32_t* s_w = s_delta + cfg.F;                                       // [NW] wave totals, [NW] abandon flag
+
+    if (rs.run_if && *rs.run_if == 0) return;
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t len = chunk_len[chunk];
+    if (len == 0) return;
+    const uint32_t off = chunk_off[chunk];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t F = cfg.F;   // <= NT: one bucket per thread in the scan
+    if (tid < F) s_cnt[tid] = 0;
+
+    // keys of the tile: kv[h] = (lo, hi) of key 2h, (lo, hi) of key 2h + 1
+    u32x4 kv[(RPT + 1) / 2];
+    // tile position of register r: consecutive lanes read consecutive 8-byte (16-byte) words
+    auto tile_pos = [&](int r) -> uint32_t { return VEC2 ? 2u * ((uint32_t)(r >> 1) * NT + tid) + (uint32_t)(r & 1) : (uint32_t)r * NT + tid; };
+    auto load_tile = [&](uint32_t t0) {
+        const long long* __restrict__ src = in_keys + off + t0;
+        const uint32_t tn = len - t0 < (uint32_t)TILE ? len - t0 : (uint32_t)TILE;
+        if (DIAG == 3) {
+#pragma unroll
+            for (int h = 0; h < RPT / 2; ++h) kv[h] = u32x4{(off + t0 + tile_pos(2 * h)) * 2654435761u, 0u, (off + t0 + tile_pos(2 * h + 1)) * 2654435761u, 0u};
+        } else if (VEC2 && tn == (uint32_t)TILE) {   // work-group-uniform: whole tile, unconditional 16-byte loads
+#pragma unroll
+            for (int h = 0; h < RPT / 2; ++h) {
+                if (ASM) ld16_hidden(kv[h], src + tile_pos(2 * h));
+                else kv[h] = *reinterpret_cast<const u32x4*>(src + tile_pos(2 * h));
+            }
+        } else if (ASM) {   // partial tile (the last one of a chunk): hidden 8-byte loads, waited for at once
+            u32x2 t[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const uint32_t i = tile_pos(r);
+                ld8_hidden(t[r], src + (i < tn ? i : tn - 1));
+            }
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) pin(t[r]);
+#pragma unroll
+            for (int h = 0; h < RPT / 2; ++h) kv[h] = u32x4{t[2 * h].x, t[2 * h].y, t[2 * h + 1].x, t[2 * h + 1].y};
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {   // clamped, unconditional (a conditional load costs a branch + vmcnt(0))
+                const uint32_t i = tile_pos(r);
+                const u32x2 k = *reinterpret_cast<const u32x2*>(src + (i < tn ? i : tn - 1));
+                if (r & 1) { kv[r >> 1].z = k.x; kv[r >> 1].w = k.y; } else { kv[r >> 1].x = k.x; kv[r >> 1].y = k.y; }
+            }
+        }
+    };
+    uint32_t polled = 0;
+    if (ASM && wv == 0) ld4_hidden_sc1(polled, rs.wide);
+    load_tile(0);
+    for (uint32_t t0 = 0; t0 < len; t0 += TILE) {
+        const uint32_t tn = len - t0 < (uint32_t)TILE ? len - t0 : (uint32_t)TILE;
+        const uint32_t rbase = off + t0;
+        // has the narrow attempt been abandoned?  (one thread asks, everybody learns it behind the next barrier)
+        if (!ASM && tid == 0) s_w[NW] = __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t0 == 0) lds_barrier();   // s_cnt zeroed (later tiles: re-zeroed two barriers ago by the scan below)
+        if (ASM) {
+            // the keys (and, in wave 0, the abandon word in front of them) were requested before the STORES stores of the
+            // previous write-out: everything older than those stores has landed once at most STORES operations are
+            // outstanding (first tile: nothing is younger)
+            if (t0 == 0) wait_vmcnt<0>(); else wait_vmcnt<STORES>();
+#pragma unroll
+            for (int h = 0; h < RPT / 2; ++h) pin(kv[h]);
+            if (wv == 0) {
+                asm volatile("" : "+v"(polled));
+                if (tid == 0) s_w[NW] = polled;
+            }
+        }
+        uint32_t k32[RPT], br[RPT];
+        uint32_t hi = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            k32[r] = (r & 1) ? kv[r >> 1].z : kv[r >> 1].x;
+            hi |= (r & 1) ? kv[r >> 1].w : kv[r >> 1].y;   // clamped duplicates are real keys too
+            br[r] = 0xFFFFFFFFu;
+            if (tile_pos(r) < tn) {
+                const uint32_t b = bucket_of(hash_int32((int32_t)k32[r]), cfg);   // == hash_int64 of the zero-extended key
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);                    // b < 1024, rank < 32768
+            }
+        }
+        if (hi) atomicOr(rs.wide, 1u);
+        lds_barrier();
+        if (s_w[NW]) return;   // work-group-uniform: some key somewhere does not fit 32 bits, the 64-bit pipeline takes over
+        // exclusive scan of the bucket counts; the bucket's run in the output is reserved meanwhile (one returning
+        // global atomic per (tile, bucket), consumed after the first window has been staged)
+        uint32_t c = 0, rsv = 0, start;
+        if (tid < F) {
+            c = s_cnt[tid];
+            s_cnt[tid] = 0;   // for the next tile
+            if (c) {
+                if (ASM) atomic_add_rtn_hidden(rsv, rs.cursor + reserve_slot(rs, tid), c);   // (a returning atomic hipcc tracks costs a vmcnt(0) at every reuse of its register)
+                else rsv = atomicAdd(&rs.cursor[reserve_slot(rs, tid)], c);
+            }
+        }
+        {
+            const uint32_t inc = wave_inclusive_scan(c);
+            if (lane == 63) s_w[wv] = inc;
+            lds_barrier();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            start = base + inc - c;
+            if (tid < F) s_start[tid] = start;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+            if (br[r] != 0xFFFFFFFFu) br[r] = (br[r] & 0xFFFF0000u) | (s_start[br[r] >> 16] + (br[r] & 0xFFFFu));   // bucket | tile-local slot
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const uint32_t w0 = (uint32_t)rd * WIN;
+            if (w0 < tn) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const uint32_t pos = (br[r] & 0xFFFFu) - w0;   // rows of other windows fall outside
+                    if (br[r] != 0xFFFFFFFFu && pos < (uint32_t)WIN) s_rows[pos] = make_uint2(k32[r], ((br[r] >> 16) << 15) | tile_pos(r));
+                }
+            }
+            if (ASM && rd == 0) {   // nothing hidden is younger than the reservation here (the next tile's loads follow below)
+                wait_vmcnt<0>();
+                asm volatile("" : "+v"(rsv));
+            }
+            if (rd == 0 && tid < F) {   // the reservations have had the scan and the staging above to come back
+                s_delta[tid] = reserve_slot(rs, tid) * rs.cap + rsv - start;
+                if (rsv + c > rs.cap) atomicOr(rs.overflow, 1u);   // rsv + c cannot wrap: both < 2^31
+            }
+            if (rd == ROUNDS - 1 && t0 + TILE < len) {   // key registers are dead: the next tile streams in during the write-out
+                if (ASM && wv == 0) ld4_hidden_sc1(polled, rs.wide);   // (one tile stale when it is read: abandoning is an optimisation)
+                load_tile(t0 + TILE);
+            }
+            lds_barrier();
+            const uint32_t wn = w0 < tn ? (tn - w0 < (uint32_t)WIN ? tn - w0 : (uint32_t)WIN) : 0u;
+            if (ASM) {
+#pragma unroll 2
+                for (int j = 0; j < WIN / NT; ++j) {   // every store instruction is issued, whatever the data (see the file header)
+                    const uint32_t i = (uint32_t)j * NT + tid;
+                    const uint2 row = s_rows[i];
+                    const uint32_t b = (row.y >> 15) & (F - 1u);   // (masked: rows beyond wn hold stale words)
+                    const uint32_t gp = s_delta[b] + w0 + i;
+                    const uint32_t ok = (i < wn && gp < (reserve_slot(rs, b) + 1u) * rs.cap) ? 1u : 0u;
+                    st8_hidden_if(out_rows + gp, u32x2{row.x, rid_base + rbase + (row.y & 0x7FFFu)}, ok);
+                }
+            } else if (wn) {
+#pragma unroll 4
+                for (int j = 0; j < WIN / NT; ++j) {
+                    const uint32_t i = (uint32_t)j * NT + tid;
+                    if (i < wn) {
+                        const uint2 row = s_rows[i];
+                        const uint32_t b = row.y >> 15;
+                        const uint32_t gp = DIAG == 1 ? rbase + w0 + i : s_delta[b] + w0 + i;
+                        if (DIAG != 2 && (DIAG == 1 || gp < (reserve_slot(rs, b) + 1u) * rs.cap))   // rows past a bucket's range are dropped (overflow raised above)
+                            out_rows[gp] = make_uint2(row.x, rid_base + rbase + (row.y & 0x7FFFu));   // join_kernels.cuh:75
+                    }
+                }
+            }
+            if (rd + 1 < ROUNDS) lds_barrier();   // the window is restaged; (after the last round the next LDS writes that could
+                                                  // collide -- s_start, s_delta, s_rows -- all sit behind later barriers)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// last pass over (key32, row id) tuples: per-bucket rings in LDS (see the file header)
+// ---------------------------------------------------------------------------
+constexpr int P2R_THREADS = 1024;
+constexpr int P2R_LINE = 16;     // rows per 128-byte line
+constexpr int P2R_MAX_F = 512;
+
+static inline size_t part2_ring_lds_bytes(uint32_t F, uint32_t R) { return (size_t)F * R * 8 + (size_t)F * 8 + 64 + 3 * 64 * 4; }
+
+// Rows of a group: one extent of the previous pass's output (fx.groups), or -- after a partition exchange -- one segment
+// per source rank (SegSrc: row offsets relative to in_rows, [group][source]); the rings do not care where rows come from.
+struct SegSrc {
+    const uint32_t* off;
+    const uint32_t* len;
+    uint32_t n_src;     // 0: use fx.groups
+};
+constexpr int P2R_MAX_SRC = 64;
+
+template <int RPT, int R, bool ASM, int DIAG = 0>   // DIAG 2: timing-only build without the flush stores (wrong results; scripts/ab_p12.py)
+__global__ __launch_bounds__(P2R_THREADS) void k_part2_ring(const uint2* __restrict__ in_rows, uint2* __restrict__ out_rows, PassCfg cfg, FixedArgs fx,
+                                                            SegSrc seg) {
+    constexpr int NT = P2R_THREADS, TILE = NT * RPT, LINE = P2R_LINE;
+    constexpr int FLUSH_ITERS = P2R_MAX_F / (NT / LINE);   // buckets per 16-lane group (ASM: always this many store instructions per flush)
+    static_assert(RPT % 2 == 0 && (R & (R - 1)) == 0 && R >= 2 * LINE, "ring geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const uint32_t F = cfg.F;
+    uint2* s_ring = reinterpret_cast<uint2*>(s_raw);                          // [F][R]
+    uint32_t* s_wr = reinterpret_cast<uint32_t*>(s_raw + (size_t)F * R * 8);  // [F] rows that have taken a position so far
+    uint32_t* s_rd = s_wr + F;                                                // [F] rows written out so far (multiple of LINE)
+    uint32_t* s_flag = s_rd + F;                                              // [2] "rows are pending" (alternating)
+    uint32_t* s_poff = s_flag + 2;                                            // [n_pieces] first row of the piece
+    uint32_t* s_plen = s_poff + P2R_MAX_SRC;                                  // [n_pieces] rows of the piece
+    uint32_t* s_pend = s_plen + P2R_MAX_SRC;                                  // [n_pieces] tiles up to and including the piece
+
+    if (fx.skip_if && *fx.skip_if != 0) return;
+    const uint32_t g = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n_pieces = seg.n_src ? seg.n_src : group_pieces(fx.groups);
+    if (tid == 0) {   // the group's pieces and their tile counts (a handful of entries: one thread)
+        uint32_t tiles = 0;
+        for (uint32_t s = 0; s < n_pieces; ++s) {
+            uint32_t o, l;
+            if (seg.n_src) { o = seg.off[(size_t)g * seg.n_src + s]; l = seg.len[(size_t)g * seg.n_src + s]; }
+            else group_piece(fx.groups, g, s, o, l);
+            tiles += (l + TILE - 1) / TILE;
+            s_poff[s] = o; s_plen[s] = l; s_pend[s] = tiles;
+        }
+    }
+    if (tid < F) { s_wr[tid] = 0; s_rd[tid] = 0; }
+    if (tid < 2) s_flag[tid] = 0;
+    lds_barrier();
+    const uint32_t n_tiles = s_pend[n_pieces - 1];
+    // (readfirstlane: work-group-uniform values in scalar registers, and -- because it consumes the loads here -- hipcc's wait for
+    // them sits in front of the tile loop; left to their first use inside the loop it becomes a vmcnt(0) per tile, which would
+    // also drain the hidden prefetch)
+    const uint32_t slot0 = __builtin_amdgcn_readfirstlane(fx.slot_base[g]), cap = __builtin_amdgcn_readfirstlane(fx.slot_cap[g]);
+    if (n_tiles == 0) {
+        if (tid < F) { fx.sub_start[(size_t)g * F + tid] = slot0 + tid * cap; fx.sub_len[(size_t)g * F + tid] = 0; }
+        return;
+    }
+    // tile k of the group -> first row (relative to in_rows) and number of rows; k < n_tiles.  Tiles are visited in order, so
+    // each of the two streams (loads run two tiles ahead of the processing) keeps a cursor over the pieces: the piece table
+    // is only read when a stream steps into the next piece (a scan per call cost ~20 % of a tile with 8 pieces).
+    struct PieceCursor { uint32_t s, before, end, off, len; };
+    auto cursor_init = [&]() -> PieceCursor { return PieceCursor{0u, 0u, s_pend[0], s_poff[0], s_plen[0]}; };
+    auto locate = [&](PieceCursor& c, uint32_t k, uint32_t& row0, uint32_t& tn) {
+        while (k >= c.end) {   // work-group-uniform; pieces without rows are skipped (their end == before)
+            c.before = c.end;
+            ++c.s;
+            c.end = s_pend[c.s];
+            c.off = s_poff[c.s];
+            c.len = s_plen[c.s];
+        }
+        const uint32_t t0 = (k - c.before) * (uint32_t)TILE;
+        row0 = c.off + t0;
+        tn = c.len - t0 < (uint32_t)TILE ? c.len - t0 : (uint32_t)TILE;
+    };
+    PieceCursor cur_load = cursor_init(), cur_proc = cursor_init();
+    // rows 2q, 2q+1 of a tile travel in one 16-byte load of thread q % NT
+    // A tile arrives as RPT/2 16-byte words (v) or, when it is the short last tile of a piece (or starts on an odd row), as RPT
+    // 8-byte words (t, `split`): both hidden, both waited for by the same counted wait -- a piece boundary does not drain the pipeline.
+    auto load_tile = [&](u32x4 (&v)[RPT / 2], u32x2 (&t)[RPT], bool& split, uint32_t k) {
+        split = false;
+        if (k >= n_tiles) return;
+        uint32_t row0, tn;
+        locate(cur_load, k, row0, tn);
+        const uint2* __restrict__ src = in_rows + row0;
+        if (tn == (uint32_t)TILE && (row0 & 1u) == 0) {   // work-group-uniform
+#pragma unroll
+            for (int h = 0; h < RPT / 2; ++h) {
+                const uint2* p = src + 2u * ((uint32_t)h * NT + tid);
+                if (ASM) ld16_hidden(v[h], p);
+                else v[h] = *reinterpret_cast<const u32x4*>(p);
+            }
+        } else if (ASM) {   // (a load hipcc tracks would make it wait vmcnt(0) at every use of these registers, on the fast path too)
+            split = true;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const uint32_t i = 2u * ((uint32_t)(r >> 1) * NT + tid) + (uint32_t)(r & 1);
+                ld8_hidden(t[r], src + (i < tn ? i : tn - 1));
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < RPT / 2; ++h) {
+                const uint32_t i = 2u * ((uint32_t)h * NT + tid);
+                const uint2 a = src[i < tn ? i : tn - 1], b = src[i + 1 < tn ? i + 1 : tn - 1];
+                v[h] = u32x4{a.x, a.y, b.x, b.y};
+            }
+        }
+    };
+    // bank rotation of a bucket's ring: neighbouring buckets (flushed by one 32-lane group) start on opposite halves
+    auto ring_at = [&](uint32_t b, uint32_t p) -> uint32_t { return b * R + ((p + ((b & 1u) << 4)) & (uint32_t)(R - 1)); };
+    uint32_t it = 0;
+    // complete lines of every bucket leave the rings; `fin`: also the unfinished last line
+    auto flush = [&](bool fin) {
+        const uint32_t q = tid >> 4, l = tid & 15;
+        if (ASM && !fin) {
+#pragma unroll 2
+            for (int j = 0; j < FLUSH_ITERS; ++j) {   // fixed trip count, one (predicated) store instruction per iteration at uniform control flow
+                const uint32_t b = q + (uint32_t)j * (NT / LINE);
+                const bool live = b < F;
+                const uint32_t bc = live ? b : 0u;
+                const uint32_t wr = s_wr[bc], rd = s_rd[bc];
+                uint32_t end = wr < cap ? wr : cap;
+                if (end > rd + R) end = rd + R;
+                end = rd + ((end - rd) & ~(uint32_t)(LINE - 1));
+                uint2* __restrict__ dst = out_rows + slot0 + bc * cap;
+                const uint2 row = s_ring[ring_at(bc, rd + l)];
+                st8_hidden_if(dst + rd + l, u32x2{row.x, row.y}, (live && end != rd) ? 1u : 0u);
+                if (__ballot(live && end - rd > (uint32_t)LINE) != 0ull) {   // rare: a second complete line (extra stores only make the counted wait stricter)
+                    const uint2 row2 = s_ring[ring_at(bc, rd + LINE + l)];
+                    st8_hidden_if(dst + rd + LINE + l, u32x2{row2.x, row2.y}, (live && end - rd > (uint32_t)LINE) ? 1u : 0u);
+                }
+                if (l == 0 && live && end != rd) s_rd[bc] = end;
+            }
+            return;
+        }
+        for (uint32_t b = q; b < F; b += NT / LINE) {
+            const uint32_t wr = s_wr[b], rd = s_rd[b];
+            uint32_t end = wr < cap ? wr : cap;                 // rows past the slot were dropped
+            if (end > rd + R) end = rd + R;                     // positions beyond the ring are still pending
+            if (!fin) end = rd + ((end - rd) & ~(uint32_t)(LINE - 1));
+            uint2* __restrict__ dst = out_rows + slot0 + b * cap;
+            if (DIAG != 2)
+                for (uint32_t p = rd + l; p < end; p += LINE) dst[p] = s_ring[ring_at(b, p)];   // 16 lanes x 8 B = one 128-byte line
+            if (l == 0 && end != rd) s_rd[b] = end;
+        }
+    };
+    auto place = [&](uint32_t key, uint32_t rid, uint32_t b, uint32_t pos) -> bool {   // true when the row stays pending
+        if (pos >= cap) return false;                         // slot overflow: dropped, flag raised at the end
+        if (pos - s_rd[b] >= (uint32_t)R) return true;
+        s_ring[ring_at(b, pos)] = make_uint2(key, rid);
+        return false;
+    };
+    uint32_t tile_no = 0;
+    auto process = [&](u32x4 (&v)[RPT / 2], u32x2 (&t)[RPT], bool& split, uint32_t k) {
+        uint32_t row0_unused, tn;
+        locate(cur_proc, k, row0_unused, tn);
+        if (ASM) {
+            // this tile's rows were requested two tiles ago, before two flushes of FLUSH_ITERS stores each (whatever was
+            // loaded in between only adds to the younger operations); the first two tiles follow the prologue's full wait
+            if (tile_no >= 2) wait_vmcnt<2 * FLUSH_ITERS>(); else wait_vmcnt<0>();
+#pragma unroll
+            for (int h = 0; h < RPT / 2; ++h) pin(v[h]);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) pin(t[r]);
+        }
+        ++tile_no;
+        const bool was_split = split;
+        uint32_t key[RPT], rid[RPT], bk[RPT], pos[RPT];
+        uint32_t pend = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            key[r] = was_split ? t[r].x : ((r & 1) ? v[r >> 1].z : v[r >> 1].x);
+            rid[r] = was_split ? t[r].y : ((r & 1) ? v[r >> 1].w : v[r >> 1].y);
+            const uint32_t i = 2u * ((uint32_t)(r >> 1) * NT + tid) + (uint32_t)(r & 1);
+            bk[r] = 0xFFFFFFFFu;
+            if (i < tn) {
+                bk[r] = bucket_of(hash_int32((int32_t)key[r]), cfg);
+                pos[r] = atomicAdd(&s_wr[bk[r]], 1u);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+            if (bk[r] != 0xFFFFFFFFu && place(key[r], rid[r], bk[r], pos[r])) pend |= 1u << r;
+        if (__ballot(pend != 0) != 0ull && lane == 0) s_flag[it & 1] = 1;
+        bool first = true;
+        for (;;) {
+            lds_barrier();                       // ring rows + pending flag visible
+            if (first) load_tile(v, t, split, k + 2);   // this tile's registers are free: the tile after next streams in behind two flushes
+            first = false;
+            flush(false);
+            const bool more = s_flag[it & 1] != 0;
+            if (tid == 0) s_flag[(it + 1) & 1] = 0;
+            ++it;
+            lds_barrier();                       // rings drained (s_rd advanced), the other flag cleared
+            if (!more) break;                    // work-group-uniform
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                if ((pend >> r) & 1u)
+                    if (!place(key[r], rid[r], bk[r], pos[r])) pend &= ~(1u << r);
+            if (__ballot(pend != 0) != 0ull && lane == 0) s_flag[it & 1] = 1;
+        }
+    };
+    u32x4 va[RPT / 2], vb[RPT / 2];
+    u32x2 ta[RPT], tb[RPT];
+    bool split_a = false, split_b = false;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) { ta[r] = u32x2{0u, 0u}; tb[r] = u32x2{0u, 0u}; }
+#pragma unroll
+    for (int h = 0; h < RPT / 2; ++h) { va[h] = u32x4{0u, 0u, 0u, 0u}; vb[h] = u32x4{0u, 0u, 0u, 0u}; }
+    load_tile(va, ta, split_a, 0);
+    load_tile(vb, tb, split_b, 1);
+    for (uint32_t k = 0; k < n_tiles; k += 2) {
+        process(va, ta, split_a, k);
+        if (k + 1 < n_tiles) process(vb, tb, split_b, k + 1);
+    }
+    if (ASM) wait_vmcnt<0>();
+    flush(true);   // (the barrier at the end of the last process() ordered every ring write before this)
+    if (tid < F) {
+        const uint32_t cnt = s_wr[tid];
+        fx.sub_start[(size_t)g * F + tid] = slot0 + tid * cap;
+        fx.sub_len[(size_t)g * F + tid] = cnt < cap ? cnt : cap;
+        if (cnt > cap) atomicOr(fx.overflow, 1u);
+    }
+}
+
+}  // namespace golap

@@ -1,0 +1,732 @@
+// golap_shard.inc.h -- multi-GPU sharded radix hash join; included at the end of golap_join.hip (it uses
+// that file's planning helpers and kernels).  One process per GPU; the only data-path collective is the partition
+// exchange (grouped ncclSend/ncclRecv over xGMI, all links of a GPU busy at once), plus tiny all-gathers.
+//
+// Fast path (every key in [0, 2^32), large inputs), per rank, all on the caller's stream + the communicator's stream:
+//   partition(build) -> [all-gather bucket counts, exchange(build)] || partition(probe) -> [all-gather, exchange(probe)]
+//   || ring pass(build) -> ring pass(probe) -> LDS join -> status all-gather -> ONE host read of the status words.
+//   * the exchange-time partition is the single-GPU first pass itself (k_part1_narrow: no histogram, bucket ranges
+//     reserved by atomics, 8-byte (key32, row id) tuples), laid out owner-major;
+//   * because every bucket owns a range of `cap` rows whose size depends only on the source rank's row count, both
+//     ends of a message know its size without any size exchange: the slice of rank r's buffer that holds the buckets
+//     owned by rank d is sent whole (slack included: +0.4 % at 125M rows per rank); the row counts inside
+//     (the reservation cursors) are all-gathered device-to-device and only ever read by kernels;
+//   * the receiving side's last pass is the single-GPU last pass (k_part2_ring) fed by one segment per source.
+// Exact path (anything else): histogram partition (64-bit rows), bucket sizes all-gathered and read back by the host,
+// variable-size exchange, segment-fed local passes (run_side) -- the round-1 Python orchestration, now in C++.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace golap {
+
+// ---------------------------------------------------------------------------
+// RCCL, bound at run time (no link-time dependency: the library loads on hosts without RCCL; torch ships its own copy
+// and an already loaded one is reused)
+// ---------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi* rccl_api(golap_ctx* ctx) {
+    static std::mutex mu;
+    static RcclApi api;
+    static bool tried = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // a copy some other library (torch) has already loaded
+    for (size_t i = 0; !h && i < sizeof(names) / sizeof(names[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fail(ctx, GOLAP_ERR_UNSUPPORTED, "librccl not found (%s)", dlerror()); return nullptr; }
+#define GOLAP_SYM(field, name)                                                                      \
+    *(void**)&api.field = dlsym(h, name);                                                           \
+    if (!api.field) { fail(ctx, GOLAP_ERR_UNSUPPORTED, "librccl lacks %s", name); return nullptr; }
+    GOLAP_SYM(GetUniqueId, "ncclGetUniqueId");
+    GOLAP_SYM(CommInitRank, "ncclCommInitRank");
+    GOLAP_SYM(CommDestroy, "ncclCommDestroy");
+    GOLAP_SYM(AllGather, "ncclAllGather");
+    GOLAP_SYM(Send, "ncclSend");
+    GOLAP_SYM(Recv, "ncclRecv");
+    GOLAP_SYM(GroupStart, "ncclGroupStart");
+    GOLAP_SYM(GroupEnd, "ncclGroupEnd");
+    GOLAP_SYM(GetErrorString, "ncclGetErrorString");
+#undef GOLAP_SYM
+    api.handle = h;
+    return &api;
+}
+
+}  // namespace golap
+
+struct golap_comm {
+    golap_ctx* ctx = nullptr;
+    int32_t world = 1, rank = 0;
+    bool builtin = false;
+    golap_transport tr{};
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr;          // the exchange runs here, beside the caller's compute stream
+    hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_xchg[2] = {nullptr, nullptr}, ev_misc = nullptr;
+    uint32_t* h_status = nullptr;          // pinned: status words / size matrices read back by the host
+    uint64_t h_status_bytes = 0;
+    golap_sharded_join_info info{};
+};
+
+namespace golap {
+
+#define GOLAP_NCCL_TRY(ctx, api, expr)                                                                                     \
+    do {                                                                                                                   \
+        ncclResult_t _r = (expr);                                                                                          \
+        if (_r != ncclSuccess) return fail((ctx), GOLAP_ERR_HIP, "%s failed: %s", #expr, (api)->GetErrorString(_r));        \
+    } while (0)
+
+static int32_t rccl_all_gather(void* user, uint64_t send_ptr, uint64_t recv_ptr, uint64_t bytes, void* stream) {
+    golap_comm* cm = (golap_comm*)user;
+    RcclApi* api = rccl_api(cm->ctx);
+    if (!api) return GOLAP_ERR_UNSUPPORTED;
+    GOLAP_NCCL_TRY(cm->ctx, api, api->AllGather((const void*)send_ptr, (void*)recv_ptr, (size_t)bytes, ncclUint8, cm->nccl, (hipStream_t)stream));
+    return GOLAP_OK;
+}
+
+static int32_t rccl_exchange(void* user, const golap_p2p_op* ops, uint32_t n_ops, void* stream) {
+    golap_comm* cm = (golap_comm*)user;
+    RcclApi* api = rccl_api(cm->ctx);
+    if (!api) return GOLAP_ERR_UNSUPPORTED;
+    if (n_ops == 0) return GOLAP_OK;
+    GOLAP_NCCL_TRY(cm->ctx, api, api->GroupStart());
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        const golap_p2p_op& o = ops[i];
+        // byte counts as size_t of ncclUint8; callers keep every message <= max_msg_bytes (see split_message)
+        ncclResult_t r = o.is_send ? api->Send((const void*)o.ptr, (size_t)o.bytes, ncclUint8, o.peer, cm->nccl, (hipStream_t)stream)
+                                   : api->Recv((void*)o.ptr, (size_t)o.bytes, ncclUint8, o.peer, cm->nccl, (hipStream_t)stream);
+        if (r != ncclSuccess) {
+            (void)api->GroupEnd();
+            return fail(cm->ctx, GOLAP_ERR_HIP, "ncclSend/ncclRecv failed: %s", api->GetErrorString(r));
+        }
+    }
+    GOLAP_NCCL_TRY(cm->ctx, api, api->GroupEnd());
+    return GOLAP_OK;
+}
+
+// A message of `bytes` bytes between two ranks travels as ceil(bytes / max_msg) pieces; both ends derive the same list.
+// (One 8 GB ncclSend/ncclRecv pair was observed to deliver wrong data on this stack -- round 1, scripts/dbg_sharded.py
+// CHECK_BIG -- and tests/test_sharded_gpu.py::test_rccl_message_size_boundary pins where that starts; bounded pieces
+// also let a transport pipeline them.)
+static void split_message(int32_t peer, bool is_send, uint64_t ptr, uint64_t bytes, uint64_t max_msg, std::vector<golap_p2p_op>& ops) {
+    for (uint64_t o = 0; o < bytes; o += max_msg) {
+        golap_p2p_op op;
+        op.peer = peer;
+        op.is_send = is_send ? 1 : 0;
+        op.ptr = ptr + o;
+        op.bytes = std::min(max_msg, bytes - o);
+        ops.push_back(op);
+    }
+}
+
+static void rows_per_rank(uint64_t n_total, uint32_t world, const uint64_t* given, std::vector<uint64_t>& out) {
+    out.resize(world);
+    for (uint32_t r = 0; r < world; ++r) {
+        if (given) out[r] = given[r];
+        else {
+            uint64_t lo, hi;
+            golap_shard_range(n_total, r, world, &lo, &hi);
+            out[r] = hi - lo;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fast-path plan (host only; every rank computes the same numbers)
+// ---------------------------------------------------------------------------
+struct ShardPlan {
+    bool eligible = false;
+    uint32_t world = 1, e1 = 0, F1 = 256, per = 256, local_bits = 0, F2 = 1;
+    std::vector<uint64_t> rows[2], cap[2];     // [side][rank]
+    JoinPlan local;                            // the one local pass
+};
+
+static uint32_t exchange_extra_bits(uint64_t n_build_total) {
+    JoinPlan p;
+    make_plan(std::max<uint64_t>(1, n_build_total), 0, true, p);
+    const int32_t over = (int32_t)p.total_bits - 8 - 9;   // hash bits one local pass (<= 9) cannot resolve
+    return (uint32_t)std::max(0, std::min(2, over));
+}
+
+static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_probe_total, const uint64_t* b_rows, const uint64_t* p_rows,
+                            ShardPlan& sp) {
+    sp = ShardPlan();
+    sp.world = world;
+    rows_per_rank(n_build_total, world, b_rows, sp.rows[0]);
+    rows_per_rank(n_probe_total, world, p_rows, sp.rows[1]);
+    sp.e1 = exchange_extra_bits(n_build_total);
+    sp.F1 = 256u << sp.e1;
+    sp.per = sp.F1 / world;
+    golap_join_partitioned_plan pl;
+    memset(&pl, 0, sizeof pl);
+    pl.n_groups = sp.per;
+    pl.n_sources = world;
+    pl.pre_bits = 8 + sp.e1;
+    pl.total_build_rows_hint = std::max<uint64_t>(1, n_build_total / world);
+    make_local_plan(&pl, sp.local);
+    sp.local_bits = sp.local.total_bits - pl.pre_bits;
+    sp.F2 = sp.local.passes.empty() ? 1 : sp.local.passes[0].cfg.F;
+    for (int side = 0; side < 2; ++side) {
+        sp.cap[side].resize(world);
+        for (uint32_t r = 0; r < world; ++r) sp.cap[side][r] = reserve_cap(sp.rows[side][r], sp.F1);
+    }
+    // the fast path is the two-pass tuple pipeline: one local pass with a ring-sized fan-out, every rank's first pass large
+    // enough for the big-tile kernel, positions within u32
+    bool ok = world <= (uint32_t)P2R_MAX_SRC && sp.local.passes.size() == 1 && sp.F2 >= 32 && sp.F2 <= (uint32_t)P2R_MAX_F && sp.per <= 1024;
+    for (int side = 0; side < 2 && ok; ++side)
+        for (uint32_t r = 0; r < world && ok; ++r) {
+            uint32_t chunk_rows = 0;
+            const uint32_t chunks = first_pass_chunks(sp.rows[side][r], &chunk_rows, part1_narrow_tile());
+            if (chunks < 224 || sp.rows[side][r] / chunks < 4 * 24576) ok = false;
+            if (sp.cap[side][r] * sp.F1 >= 0xFFFFFFF0ull) ok = false;
+        }
+    const char* env = knob("GOLAP_SHARD_FAST");   // test hook: "1" drops the size condition, "0" disables the fast path
+    if (env && !strcmp(env, "1"))
+        ok = world <= (uint32_t)P2R_MAX_SRC && sp.local.passes.size() == 1 && sp.F2 >= 32 && sp.F2 <= (uint32_t)P2R_MAX_F && sp.per <= 1024;
+    if (env && !strcmp(env, "0")) ok = false;
+    if (const char* e2 = knob("GOLAP_NARROW")) if (!strcmp(e2, "0")) ok = false;
+    sp.eligible = ok;
+}
+
+// ---------------------------------------------------------------------------
+// device helpers of the fast path
+// ---------------------------------------------------------------------------
+struct ShardSrcTable {
+    uint32_t cap[P2R_MAX_SRC];    // rows provisioned per bucket by source r
+    uint32_t base[P2R_MAX_SRC];   // row offset (relative to the tuple base pointer) of source r's group 0
+};
+
+// Segment table of the ring pass + the slot sizes of k_slots_setup, from the all-gathered reservation cursors:
+//   hdr[r * hdr_stride + b] = rows source r put into bucket b (b owner-major: my buckets are [me * per, (me + 1) * per)),
+//   hdr[r * hdr_stride + F1] = source r's "narrow attempt failed" word.
+__global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restrict__ hdr, uint32_t hdr_stride, uint32_t F1, uint32_t world, uint32_t me,
+                                                        uint32_t per, ShardSrcTable src, uint32_t F2, uint32_t sigmas, uint32_t pad,
+                                                        uint32_t* __restrict__ seg_off, uint32_t* __restrict__ seg_len, uint32_t* __restrict__ slot_base,
+                                                        uint32_t* __restrict__ slot_cap, uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_w[16];
+    const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
+    uint32_t total = 0;
+    if (g < per) {
+        uint32_t n_g = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint32_t c = hdr[(size_t)r * hdr_stride + me * per + g];
+            const uint32_t len = c < src.cap[r] ? c : src.cap[r];   // (an overflowing bucket raised source r's word; the result is discarded)
+            seg_off[g * world + r] = src.base[r] + g * src.cap[r];
+            seg_len[g * world + r] = len;
+            n_g += len;
+        }
+        const uint32_t avg = (n_g + F2 - 1) / F2;
+        const uint32_t cap = (avg + sigmas * isqrt_u32(avg) + pad + 15u) & ~15u;
+        slot_cap[g] = cap;
+        total = cap * F2;
+    }
+    if (g < world && hdr[(size_t)g * hdr_stride + F1]) atomicOr(status, 1u);   // some rank met a wide key / an overflowing bucket
+    const uint32_t inc = wave_inclusive_scan(total);
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < wv; ++i) base += s_w[i];
+    if (g < per) slot_base[g] = base + inc - total;
+    if (g == per - 1) slot_base[per] = base + inc;
+}
+
+static int32_t comm_all_gather(golap_comm* cm, uint64_t send, uint64_t recv, uint64_t bytes, hipStream_t s) {
+    int32_t st = cm->tr.all_gather(cm->tr.user, send, recv, bytes, (void*)s);
+    if (st != GOLAP_OK && cm->ctx->err.empty()) return fail(cm->ctx, st, "transport all_gather failed (%d)", st);
+    return st;
+}
+static int32_t comm_exchange(golap_comm* cm, const std::vector<golap_p2p_op>& ops, hipStream_t s) {
+    int32_t st = cm->tr.exchange(cm->tr.user, ops.data(), (uint32_t)ops.size(), (void*)s);
+    if (st != GOLAP_OK && cm->ctx->err.empty()) return fail(cm->ctx, st, "transport exchange failed (%d)", st);
+    return st;
+}
+
+static int32_t ensure_host_words(golap_comm* cm, uint64_t bytes) {
+    if (cm->h_status_bytes >= bytes) return GOLAP_OK;
+    if (cm->h_status) (void)hipHostFree(cm->h_status);
+    cm->h_status = nullptr;
+    cm->h_status_bytes = 0;
+    GOLAP_HIP_TRY(cm->ctx, hipHostMalloc((void**)&cm->h_status, bytes, hipHostMallocDefault));
+    cm->h_status_bytes = bytes;
+    return GOLAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fast path
+// ---------------------------------------------------------------------------
+static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, bool* failed) {
+    const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2;
+    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : (1ull << 30);
+    const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
+    const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
+    const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};
+    for (int side = 0; side < 2; ++side)
+        if (n_local[side] != sp.rows[side][me]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "local row count differs from the sharding every rank assumes");
+    GOLAP_TRY(ensure_scatter_lds(ctx));
+    // ---- workspace: per side [send: F1 x cap_me | recv: per x cap_r for r != me | final (slot-provisioned)] + small arrays ----
+    uint64_t send_rows[2], recv_rows[2], final_rows_[2], recv_off_rows[2][P2R_MAX_SRC];
+    for (int side = 0; side < 2; ++side) {
+        send_rows[side] = (uint64_t)F1 * sp.cap[side][me];
+        uint64_t ro = send_rows[side], n_g_max = 0;
+        for (uint32_t r = 0; r < P; ++r) {
+            n_g_max += sp.cap[side][r];
+            if (r == me) { recv_off_rows[side][r] = (uint64_t)me * per * sp.cap[side][me]; continue; }   // own buckets are read in place
+            recv_off_rows[side][r] = ro;
+            ro += (uint64_t)per * sp.cap[side][r];
+        }
+        recv_rows[side] = ro - send_rows[side];
+        const uint64_t avg = ceil_div(n_g_max, F2);
+        final_rows_[side] = (uint64_t)per * F2 * round_up(avg + 6ull * isqrt_host(avg) + 48 + 15, 16);
+        if (send_rows[side] + recv_rows[side] >= 0xFFFFFFF0ull || final_rows_[side] >= 0xFFFFFFF0ull)
+            return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: positions exceed u32");
+    }
+    const uint32_t hdr_stride = F1 + 4;
+    uint64_t small = 0;
+    small += 2 * (round_up((uint64_t)hdr_stride * 4, 256) + round_up((uint64_t)P * hdr_stride * 4, 256));          // cursors + gathered
+    small += 2 * (2 * round_up((uint64_t)per * P * 4, 256) + 2 * round_up((uint64_t)(per + 1) * 4, 256) + 2 * round_up((uint64_t)per * F2 * 4, 256));
+    small += 2 * 2 * round_up(2048 * 4, 256) + 4096 + round_up((uint64_t)P * 4, 256);
+    uint64_t need = small + (1 << 20);
+    for (int side = 0; side < 2; ++side) need += round_up((send_rows[side] + recv_rows[side]) * 8, 256) + round_up(final_rows_[side] * 8, 256);
+    if (p->join_type & 2) need += round_up(ceil_div(final_rows_[1], 32) * 4 + 8, 256);
+    GOLAP_TRY(ws_begin(ctx, need, st));
+    uint64_t tuples[2], finals[2];
+    for (int side = 0; side < 2; ++side) {
+        tuples[side] = ws_take(ctx, (send_rows[side] + recv_rows[side]) * 8);
+        finals[side] = ws_take(ctx, final_rows_[side] * 8);
+        if (!tuples[side] || !finals[side]) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
+    }
+    uint32_t* words = (uint32_t*)ws_take(ctx, 16);            // [0] local status (any rank's failure ORed in), [1] constant 0
+    uint32_t* status_all = (uint32_t*)ws_take(ctx, (uint64_t)P * 4);
+    if (!words || !status_all) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
+    GOLAP_TRY(zero_async(ctx, st, words, 16));
+    uint32_t* probe_hit = nullptr;
+    if (p->join_type & 2) {
+        const uint64_t nw = ceil_div(final_rows_[1], 32) + 1;
+        probe_hit = (uint32_t*)ws_take(ctx, nw * 4);
+        if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted (probe bitmap)");
+        GOLAP_TRY(zero_async(ctx, st, probe_hit, nw * 4));
+    }
+    SideResult res[2];
+    uint32_t *hdr[2], *hdr_all[2];
+    // ---- partition both sides (compute stream); each side's gather + exchange follows on the communicator's stream ----
+    for (int side = 0; side < 2; ++side) {
+        hdr[side] = (uint32_t*)ws_take(ctx, (uint64_t)hdr_stride * 4);          // [F1] reservation cursors, [F1] this rank's failure word
+        hdr_all[side] = (uint32_t*)ws_take(ctx, (uint64_t)P * hdr_stride * 4);
+        uint32_t chunk_rows = 0;
+        const uint32_t nc = first_pass_chunks(n_local[side], &chunk_rows, part1_narrow_tile());
+        uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
+        uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
+        if (!hdr[side] || !hdr_all[side] || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
+        GOLAP_TRY(zero_async(ctx, st, hdr[side], (uint64_t)hdr_stride * 4));
+        hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_local[side], chunk_rows, nc, c_off, c_len);
+        PassCfg cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.F = F1;
+        cfg.S = nc;
+        cfg.mode = 1;
+        cfg.e1 = sp.e1;
+        cfg.owners_log2 = ilog2(P);
+        {
+            KernelTimer t(ctx, side ? "partition_scatter_probe" : "partition_scatter_build", st, 16 * n_local[side]);
+            launch_part1_narrow(st, keys_in[side], rid_base[side], nc, c_off, c_len, tuples[side], cfg,
+                                ReserveArgs{hdr[side], (uint32_t)sp.cap[side][me], hdr[side] + F1, hdr[side] + F1, nullptr});
+        }
+        GOLAP_HIP_TRY(ctx, hipGetLastError());
+        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side], st));
+        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side], 0));
+        GOLAP_TRY(comm_all_gather(cm, (uint64_t)hdr[side], (uint64_t)hdr_all[side], (uint64_t)hdr_stride * 4, cm->stream));
+        std::vector<golap_p2p_op> ops;
+        for (uint32_t r = 0; r < P; ++r) {
+            if (r == me) continue;
+            const uint64_t sbytes = (uint64_t)per * sp.cap[side][me] * 8, rbytes = (uint64_t)per * sp.cap[side][r] * 8;
+            split_message((int32_t)r, true, tuples[side] + (uint64_t)r * per * sp.cap[side][me] * 8, sbytes, max_msg, ops);
+            split_message((int32_t)r, false, tuples[side] + recv_off_rows[side][r] * 8, rbytes, max_msg, ops);
+            cm->info.bytes_sent[side] += sbytes;
+        }
+        GOLAP_TRY(comm_exchange(cm, ops, cm->stream));
+        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[side], cm->stream));
+        cm->info.rows_received[side] = recv_rows[side] + (uint64_t)per * sp.cap[side][me];
+    }
+    // ---- ring pass per side, as soon as that side's rows are in ----
+    for (int side = 0; side < 2; ++side) {
+        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_xchg[side], 0));
+        uint32_t* seg_off = (uint32_t*)ws_take(ctx, (uint64_t)per * P * 4);
+        uint32_t* seg_len = (uint32_t*)ws_take(ctx, (uint64_t)per * P * 4);
+        uint32_t* slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(per + 1) * 4);
+        uint32_t* slot_cap = (uint32_t*)ws_take(ctx, (uint64_t)per * 4);
+        uint32_t* sub_start = (uint32_t*)ws_take(ctx, (uint64_t)per * F2 * 4);
+        uint32_t* sub_len = (uint32_t*)ws_take(ctx, (uint64_t)per * F2 * 4);
+        if (!seg_off || !seg_len || !slot_base || !slot_cap || !sub_start || !sub_len) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
+        ShardSrcTable tab;
+        memset(&tab, 0, sizeof tab);
+        for (uint32_t r = 0; r < P; ++r) {
+            tab.cap[r] = (uint32_t)sp.cap[side][r];
+            tab.base[r] = (uint32_t)recv_off_rows[side][r];
+        }
+        uint32_t sigmas, pad;
+        provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
+        hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)hdr_all[side], hdr_stride, F1, P, me, per, tab, F2, sigmas, pad,
+                           seg_off, seg_len, slot_base, slot_cap, words);
+        FixedArgs fx{GroupSrc{}, slot_base, slot_cap, sub_start, sub_len, words, nullptr};
+        PassCfg cfg = sp.local.passes[0].cfg;
+        cfg.S = 1;
+        {
+            KernelTimer t(ctx, side ? "local_scatter_probe" : "local_scatter_build", st, 16 * cm->info.rows_received[side]);
+            launch_part2_ring(st, per, tuples[side], finals[side], cfg, fx, SegSrc{seg_off, seg_len, P});
+        }
+        GOLAP_HIP_TRY(ctx, hipGetLastError());
+        res[side] = SideResult();
+        res[side].keys = (const long long*)finals[side];
+        res[side].alt_start = sub_start;
+        res[side].alt_len = sub_len;
+        res[side].flag = words + 1;
+        res[side].positions = final_rows_[side];
+    }
+    JoinPlan jp = sp.local;
+    jp.n_sub = (uint64_t)per * F2;
+    GOLAP_TRY(launch_lds_join(ctx, st, jp, res[0], res[1], cm->info.rows_received[0], cm->info.rows_received[1], p->out_pairs_ptr, p->out_count_ptr,
+                              p->max_pairs, p->join_type, true, nullptr, words, probe_hit));
+    // ---- did the narrow attempt hold on EVERY rank?  (all ranks must take the same path: the words are gathered) ----
+    GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_misc, st));
+    GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_misc, 0));
+    GOLAP_TRY(comm_all_gather(cm, (uint64_t)words, (uint64_t)status_all, 4, cm->stream));
+    GOLAP_TRY(ensure_host_words(cm, (uint64_t)P * 4));
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync(cm->h_status, status_all, (size_t)P * 4, hipMemcpyDeviceToHost, cm->stream));
+    GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_misc, cm->stream));
+    ws_end(ctx, st);
+    GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_misc, 0));   // the caller's stream also orders behind the communicator's
+    GOLAP_HIP_TRY(ctx, hipEventSynchronize(cm->ev_misc));         // THE host synchronisation of the fast path
+    cm->info.host_syncs += 1;
+    uint32_t any = 0;
+    for (uint32_t r = 0; r < P; ++r) any |= cm->h_status[r];
+    *failed = any != 0;
+    return GOLAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// exact path: histogram partition (64-bit rows), sizes read back, variable-size exchange, segment-fed local passes
+// ---------------------------------------------------------------------------
+struct SlabHold {   // slabs that must outlive the workspace (the workspace is re-begun by the partition and by the local passes)
+    golap_ctx* ctx;
+    std::vector<std::pair<uint64_t, uint32_t>> slabs;
+    explicit SlabHold(golap_ctx* c) : ctx(c) {}
+    uint64_t take(uint64_t bytes) {
+        uint64_t p = 0;
+        uint32_t cls = 0;
+        if (ctx->slabs.allocate(ctx, std::max<uint64_t>(bytes, 256), &p, &cls) != GOLAP_OK) return 0;
+        slabs.push_back({p, cls});
+        return p;
+    }
+    ~SlabHold() {
+        for (auto& s : slabs) (void)ctx->slabs.release(ctx, s.first, s.second);
+    }
+};
+
+static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st) {
+    const uint32_t P = sp.world, me = (uint32_t)cm->rank, e1 = sp.e1, F1 = sp.F1, per = sp.per;
+    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : (1ull << 30);
+    const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
+    const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
+    const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};
+    SlabHold hold(ctx);
+    uint64_t recv_keys[2] = {0, 0}, recv_rids[2] = {0, 0}, n_recv[2] = {0, 0};
+    std::vector<uint64_t> seg_off[2], seg_len[2];
+    const uint64_t off_words = (uint64_t)F1 + 1;
+    GOLAP_TRY(ensure_host_words(cm, 2 * (uint64_t)P * off_words * 4));
+    for (int side = 0; side < 2; ++side) {
+        // partition this rank's rows (exact layout: contiguous buckets, owner-major)
+        const uint64_t pk = hold.take(std::max<uint64_t>(1, n_local[side]) * 8), pr = hold.take(std::max<uint64_t>(1, n_local[side]) * 4);
+        const uint64_t offs = hold.take(off_words * 4), offs_all = hold.take((uint64_t)P * off_words * 4);
+        if (!pk || !pr || !offs || !offs_all) return GOLAP_ERR_OOM;
+        golap_partition_params pp;
+        memset(&pp, 0, sizeof pp);
+        pp.key_ptr = keys_in[side];
+        pp.n_rows = n_local[side];
+        pp.rid_base = rid_base[side];
+        pp.n_owners = P;
+        pp.extra_bits = e1;
+        pp.out_key_ptr = pk;
+        pp.out_row_id_ptr = pr;
+        pp.out_offsets_ptr = offs;
+        GOLAP_TRY(radix_partition_impl(ctx, &pp, st));
+        // bucket sizes of every rank: device all-gather, then the one read-back this side needs
+        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side], st));
+        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side], 0));
+        GOLAP_TRY(comm_all_gather(cm, offs, offs_all, off_words * 4, cm->stream));
+        uint32_t* h = cm->h_status + (uint64_t)side * P * off_words;
+        GOLAP_HIP_TRY(ctx, hipMemcpyAsync(h, (const void*)offs_all, (size_t)P * off_words * 4, hipMemcpyDeviceToHost, cm->stream));
+        GOLAP_HIP_TRY(ctx, hipStreamSynchronize(cm->stream));
+        cm->info.host_syncs += 1;
+        // what I receive: from every source r its buckets [me * per, (me + 1) * per)
+        std::vector<uint64_t> from(P), base(P);
+        for (uint32_t r = 0; r < P; ++r) {
+            const uint32_t* o = h + (uint64_t)r * off_words;
+            from[r] = (uint64_t)o[(me + 1) * per] - o[me * per];
+            base[r] = n_recv[side];
+            n_recv[side] += from[r];
+        }
+        recv_keys[side] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 8);
+        recv_rids[side] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 4);
+        if (!recv_keys[side] || !recv_rids[side]) return GOLAP_ERR_OOM;
+        seg_off[side].assign((size_t)per * P, 0);
+        seg_len[side].assign((size_t)per * P, 0);
+        for (uint32_t r = 0; r < P; ++r) {
+            const uint32_t* o = h + (uint64_t)r * off_words;
+            for (uint32_t g = 0; g < per; ++g) {
+                seg_off[side][(size_t)g * P + r] = base[r] + ((uint64_t)o[me * per + g] - o[me * per]);
+                seg_len[side][(size_t)g * P + r] = (uint64_t)o[me * per + g + 1] - o[me * per + g];
+            }
+        }
+        const uint32_t* mine = h + (uint64_t)me * off_words;
+        std::vector<golap_p2p_op> ops;
+        for (uint32_t r = 0; r < P; ++r) {
+            const uint64_t s0 = mine[r * per], s1 = mine[(r + 1) * per];   // my rows bound for r: one contiguous slice, nothing is packed
+            if (r == me) {
+                if (s1 > s0) {   // own partitions never touch the transport
+                    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)(recv_keys[side] + base[r] * 8), (const void*)(pk + s0 * 8), (s1 - s0) * 8, hipMemcpyDeviceToDevice, cm->stream));
+                    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)(recv_rids[side] + base[r] * 4), (const void*)(pr + s0 * 4), (s1 - s0) * 4, hipMemcpyDeviceToDevice, cm->stream));
+                }
+                continue;
+            }
+            split_message((int32_t)r, true, pk + s0 * 8, (s1 - s0) * 8, max_msg, ops);
+            split_message((int32_t)r, false, recv_keys[side] + base[r] * 8, from[r] * 8, max_msg, ops);
+            split_message((int32_t)r, true, pr + s0 * 4, (s1 - s0) * 4, max_msg, ops);
+            split_message((int32_t)r, false, recv_rids[side] + base[r] * 4, from[r] * 4, max_msg, ops);
+            cm->info.bytes_sent[side] += (s1 - s0) * 12;
+        }
+        GOLAP_TRY(comm_exchange(cm, ops, cm->stream));   // in flight while the other side is partitioned
+        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[side], cm->stream));
+        cm->info.rows_received[side] = n_recv[side];
+    }
+    golap_join_partitioned_plan pl;
+    memset(&pl, 0, sizeof pl);
+    pl.n_groups = per;
+    pl.n_sources = P;
+    pl.pre_bits = 8 + e1;
+    pl.total_build_rows_hint = std::max<uint64_t>(1, p->n_build_total / P);
+    pl.build_rows = n_recv[0];
+    pl.probe_rows = n_recv[1];
+    GOLAP_TRY(part_begin(ctx, &pl, st));
+    int32_t rc = GOLAP_OK;
+    for (int side = 0; side < 2 && rc == GOLAP_OK; ++side) {
+        if (hipStreamWaitEvent(st, cm->ev_xchg[side], 0) != hipSuccess) { rc = fail(ctx, GOLAP_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        golap_partitioned_side sd;
+        sd.key_ptr = recv_keys[side];
+        sd.row_id_ptr = recv_rids[side];
+        sd.n_rows = n_recv[side];
+        sd.seg_off = seg_off[side].data();
+        sd.seg_len = seg_len[side].data();
+        rc = part_side(ctx, side, &sd, st);
+    }
+    if (rc == GOLAP_OK) rc = part_finish(ctx, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, st, p->join_type);
+    if (rc != GOLAP_OK) { part_abort(ctx); (void)hipStreamSynchronize(cm->stream); return rc; }
+    // the slabs above go back to the pool at scope exit: every kernel that reads them must have finished
+    GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
+    cm->info.host_syncs += 1;
+    return GOLAP_OK;
+}
+
+}  // namespace golap
+
+extern "C" {
+
+void golap_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
+    if (world == 0) world = 1;
+    const uint64_t per = n_total / world;
+    if (lo) *lo = (uint64_t)rank * per;
+    if (hi) *hi = rank + 1 == world ? n_total : ((uint64_t)rank + 1) * per;
+}
+
+int32_t golap_comm_unique_id(uint8_t out_id[GOLAP_COMM_ID_BYTES]) {
+    if (!out_id) return fail(nullptr, GOLAP_ERR_INVALID_ARG, "null argument");
+    RcclApi* api = rccl_api(nullptr);
+    if (!api) return GOLAP_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    GOLAP_NCCL_TRY(nullptr, api, api->GetUniqueId(&id));
+    static_assert(sizeof(id) == GOLAP_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(out_id, &id, sizeof id);
+    return GOLAP_OK;
+}
+
+static int32_t comm_common(golap_ctx* ctx, int32_t world, int32_t rank, golap_comm** out, golap_comm** made) {
+    if (!ctx || !out) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (world < 1 || world > P2R_MAX_SRC || (world & (world - 1)) || 256 % world) return fail(ctx, GOLAP_ERR_INVALID_ARG, "world size must be a power of two <= 64");
+    if (rank < 0 || rank >= world) return fail(ctx, GOLAP_ERR_INVALID_ARG, "rank %d out of range", rank);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    golap_comm* cm = new golap_comm();
+    cm->ctx = ctx;
+    cm->world = world;
+    cm->rank = rank;
+    hipError_t e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&cm->ev_part[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_xchg[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_misc, hipEventDisableTiming);
+    if (e != hipSuccess) { golap_comm_destroy(cm); return fail(ctx, GOLAP_ERR_HIP, "communicator setup failed: %s", hipGetErrorString(e)); }
+    *made = cm;
+    return GOLAP_OK;
+}
+
+int32_t golap_comm_create_rccl(golap_ctx* ctx, const uint8_t id[GOLAP_COMM_ID_BYTES], int32_t world, int32_t rank, golap_comm** out) {
+    if (!id) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    RcclApi* api = rccl_api(ctx);
+    if (!api) return GOLAP_ERR_UNSUPPORTED;
+    golap_comm* cm = nullptr;
+    GOLAP_TRY(comm_common(ctx, world, rank, out, &cm));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = api->CommInitRank(&cm->nccl, world, uid, rank);
+    if (r != ncclSuccess) { golap_comm_destroy(cm); return fail(ctx, GOLAP_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(r)); }
+    cm->builtin = true;
+    cm->tr.user = cm;
+    cm->tr.all_gather = rccl_all_gather;
+    cm->tr.exchange = rccl_exchange;
+    *out = cm;
+    return GOLAP_OK;
+}
+
+int32_t golap_comm_create_custom(golap_ctx* ctx, const golap_transport* transport, int32_t world, int32_t rank, golap_comm** out) {
+    if (!transport || !transport->all_gather || !transport->exchange) return fail(ctx, GOLAP_ERR_INVALID_ARG, "transport callbacks missing");
+    golap_comm* cm = nullptr;
+    GOLAP_TRY(comm_common(ctx, world, rank, out, &cm));
+    cm->tr = *transport;
+    *out = cm;
+    return GOLAP_OK;
+}
+
+void golap_comm_destroy(golap_comm* cm) {
+    if (!cm) return;
+    if (cm->ctx) (void)hipSetDevice(cm->ctx->device);
+    if (cm->stream) (void)hipStreamSynchronize(cm->stream);
+    if (cm->nccl) {
+        RcclApi* api = rccl_api(cm->ctx);
+        if (api) (void)api->CommDestroy(cm->nccl);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (cm->ev_part[i]) (void)hipEventDestroy(cm->ev_part[i]);
+        if (cm->ev_xchg[i]) (void)hipEventDestroy(cm->ev_xchg[i]);
+    }
+    if (cm->ev_misc) (void)hipEventDestroy(cm->ev_misc);
+    if (cm->h_status) (void)hipHostFree(cm->h_status);
+    if (cm->stream) (void)hipStreamDestroy(cm->stream);
+    delete cm;
+}
+
+int32_t golap_sharded_plan_get(uint32_t world, uint64_t n_build_total, uint64_t n_probe_total, const uint64_t* build_rows_per_rank,
+                               const uint64_t* probe_rows_per_rank, uint64_t max_msg_bytes, golap_sharded_plan* out) {
+    if (!out) return fail(nullptr, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (world < 1 || world > (uint32_t)P2R_MAX_SRC || (world & (world - 1))) return fail(nullptr, GOLAP_ERR_INVALID_ARG, "world size must be a power of two <= 64");
+    ShardPlan sp;
+    make_shard_plan(world, n_build_total, n_probe_total, build_rows_per_rank, probe_rows_per_rank, sp);
+    memset(out, 0, sizeof *out);
+    out->eligible = sp.eligible ? 1 : 0;
+    out->extra_bits = sp.e1;
+    out->n_buckets = sp.F1;
+    out->buckets_per_rank = sp.per;
+    out->local_bits = sp.local_bits;
+    const uint64_t mm = max_msg_bytes ? max_msg_bytes : (1ull << 30);
+    for (int side = 0; side < 2; ++side)
+        for (uint32_t r = 0; r < world; ++r) {
+            out->cap_rows[side][r] = sp.cap[side][r];
+            out->msg_bytes[side][r] = (uint64_t)sp.per * sp.cap[side][r] * 8;
+            out->msg_pieces[side][r] = (uint32_t)ceil_div(out->msg_bytes[side][r], mm);
+        }
+    return GOLAP_OK;
+}
+
+// Diagnostic: one UNSPLIT message of `bytes` bytes from this rank to itself through the transport (ncclSend + ncclRecv in one
+// group), checked word by word on the device.  Pins where large single messages stop being delivered correctly on a stack
+// (tests/test_sharded_gpu.py::test_rccl_message_size_boundary); the join itself never sends more than max_msg_bytes at once.
+__global__ void k_selftest_fill(uint32_t* __restrict__ a, unsigned long long n) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        a[i] = (uint32_t)(i * 2654435761ull) ^ (uint32_t)(i >> 32);
+}
+__global__ void k_selftest_check(const uint32_t* __restrict__ a, unsigned long long n, unsigned long long* __restrict__ bad, unsigned long long* __restrict__ first_bad) {
+    unsigned long long local = 0, first = ~0ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        if (a[i] != ((uint32_t)(i * 2654435761ull) ^ (uint32_t)(i >> 32))) { ++local; if (i < first) first = i; }
+    if (local) { atomicAdd(bad, local); atomicMin(first_bad, first); }
+}
+
+int32_t golap_comm_selftest(golap_ctx* ctx, golap_comm* cm, uint64_t bytes, uint64_t* out_bad_words, uint64_t* out_first_bad_word) {
+    if (!ctx || !cm || !out_bad_words) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (bytes == 0 || (bytes & 3)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bytes must be a positive multiple of 4");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SlabHold hold(ctx);
+    const uint64_t src = hold.take(bytes), dst = hold.take(bytes), res = hold.take(256);
+    if (!src || !dst || !res) return GOLAP_ERR_OOM;
+    const unsigned long long n = bytes / 4;
+    hipStream_t s = cm->stream;
+    hipLaunchKernelGGL(k_selftest_fill, dim3(2048), dim3(256), 0, s, (uint32_t*)src, n);
+    GOLAP_TRY(zero_async(ctx, s, (void*)dst, bytes));
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)res, 0, 8, s));
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync((void*)(res + 8), 0xFF, 8, s));
+    std::vector<golap_p2p_op> ops(2);
+    ops[0].peer = cm->rank; ops[0].is_send = 1; ops[0].ptr = src; ops[0].bytes = bytes;
+    ops[1].peer = cm->rank; ops[1].is_send = 0; ops[1].ptr = dst; ops[1].bytes = bytes;
+    GOLAP_TRY(comm_exchange(cm, ops, s));
+    hipLaunchKernelGGL(k_selftest_check, dim3(2048), dim3(256), 0, s, (const uint32_t*)dst, n, (unsigned long long*)res, (unsigned long long*)(res + 8));
+    uint64_t h[2] = {0, 0};
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync(h, (const void*)res, 16, hipMemcpyDeviceToHost, s));
+    GOLAP_HIP_TRY(ctx, hipStreamSynchronize(s));
+    *out_bad_words = h[0];
+    if (out_first_bad_word) *out_first_bad_word = h[1];
+    return GOLAP_OK;
+}
+
+int32_t golap_sharded_join_info_get(golap_comm* cm, golap_sharded_join_info* out) {
+    if (!cm || !out) return fail(cm ? cm->ctx : nullptr, GOLAP_ERR_INVALID_ARG, "null argument");
+    *out = cm->info;
+    return GOLAP_OK;
+}
+
+int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, void* stream) {
+    if (!ctx || !cm || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (cm->ctx != ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "communicator belongs to another context");
+    if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+    if (p->max_pairs && !p->out_pairs_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_pairs_ptr is null but max_pairs > 0");
+    if ((p->n_build_local && !p->build_key_ptr) || (p->n_probe_local && !p->probe_key_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null key column");
+    if (p->join_type < 0 || p->join_type > 3) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad join_type %d", p->join_type);
+    if (p->n_build_total >= 0xFFFFFFF0ull || p->n_probe_total >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "global row ids are u32");
+    if ((uint64_t)p->build_rid_base + p->n_build_local > 0xFFFFFFFFull || (uint64_t)p->probe_rid_base + p->n_probe_local > 0xFFFFFFFFull)
+        return fail(ctx, GOLAP_ERR_UNSUPPORTED, "rid_base + rows exceeds the u32 row-id range");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    memset(&cm->info, 0, sizeof cm->info);
+    ShardPlan sp;
+    make_shard_plan((uint32_t)cm->world, p->n_build_total, p->n_probe_total, p->build_rows_per_rank, p->probe_rows_per_rank, sp);
+    cm->info.extra_bits = sp.e1;
+    cm->info.n_groups = sp.per;
+    cm->info.local_bits = sp.local_bits;
+    GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
+    if (sp.eligible && !p->force_exact) {
+        bool failed = false;
+        GOLAP_TRY(sharded_join_fast(ctx, cm, p, sp, st, &failed));
+        if (!failed) { cm->info.fast_path = 1; return GOLAP_OK; }
+        cm->info.fast_path_abandoned = 1;
+        cm->info.bytes_sent[0] = cm->info.bytes_sent[1] = 0;
+        GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
+    }
+    return sharded_join_exact(ctx, cm, p, sp, st);
+}
+
+}  // extern "C"

@@ -1,5 +1,13 @@
 """One-process-per-GPU sharded radix hash join.
 
+PRODUCT PATH: `NativeShardedJoin` -- a thin wrapper over the C ABI's golap_sharded_join (csrc/golap_shard.inc.h): partition,
+exchange (RCCL over xGMI, called from C++), local passes and join are all driven by the library; Python only hands over
+tensors and, once, the communicator's unique id.  `StagedTransport` plugs torch.distributed (gloo) into the same C++ code
+through the transport callbacks, so that several ranks can rehearse the real kernels on ONE GPU (tests).
+
+`ShardedJoin` below is the round-1 orchestration of the exact path in Python, kept as the CPU-testable model of the
+protocol (tests/test_distributed_cpu.py drives it under gloo with an oracle-backed stand-in for the device steps).
+
 Rows of both tables start range-sharded; every rank radix-partitions its local rows into the
 reference's 256 partitions (join_kernels.cuh:69), laid out owner-major so that the rows bound
 for each peer are one contiguous range; partition p is owned by rank p % P.  The only data-path
@@ -295,3 +303,108 @@ class ShardedAggregate:
             else:                                                            # AVG = sum / count, 0.0 for an empty group (executor.rs:339-345)
                 out.append(torch.where(sc[1] > 0, sc[0] / sc[1].clamp(min=1.0), torch.zeros_like(sc[0])))
         return torch.stack(out)
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# product path: golap_sharded_join through the C ABI
+# ---------------------------------------------------------------------------------------------------------------------
+class StagedTransport:
+    """golap_transport callbacks over torch.distributed with host staging (rehearsal / non-RCCL fabrics): device buffers
+    are copied to host memory with the library's TransferQueue, moved with the process group (gloo), and copied back."""
+
+    def __init__(self, ctx, group=None):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _native as N
+        self.ctx, self.group = ctx, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        lib = ctx._lib
+
+        def d2h(ptr, nbytes):
+            h = np.empty(max(nbytes, 1), dtype=np.uint8)
+            ctx._ck(lib.golap_xfer_enqueue(ctx._h, N.DEVICE_TO_HOST, ptr, h.ctypes.data, nbytes, 0))
+            return h
+
+        def h2d(h, ptr, nbytes):
+            ctx._ck(lib.golap_xfer_enqueue(ctx._h, N.HOST_TO_DEVICE, h.ctypes.data, ptr, nbytes, 0))
+
+        def all_gather(user, send_ptr, recv_ptr, nbytes, stream):
+            try:
+                ctx._ck(lib.golap_ctx_synchronize(ctx._h, C.c_void_p(stream)))
+                h = d2h(send_ptr, nbytes)
+                ctx.xfer_synchronize()
+                mine = torch.from_numpy(h[:nbytes].copy())
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                allb = torch.cat(parts).numpy()
+                h2d(allb, recv_ptr, nbytes * self.world)
+                ctx.xfer_synchronize()
+                return 0
+            except Exception as e:   # an exception must not unwind through the C frames
+                print(f"StagedTransport.all_gather failed: {e!r}", flush=True)
+                return N.ERR_HIP
+
+        def exchange(user, ops, n_ops, stream):
+            try:
+                ctx._ck(lib.golap_ctx_synchronize(ctx._h, C.c_void_p(stream)))
+                sends, recvs, works = [], [], []
+                for i in range(n_ops):
+                    o = ops[i]
+                    if o.is_send:
+                        sends.append((o.peer, d2h(o.ptr, o.bytes), o.bytes))
+                    else:
+                        recvs.append((o.peer, torch.empty(max(o.bytes, 1), dtype=torch.uint8), o.ptr, o.bytes))
+                ctx.xfer_synchronize()
+                for peer, h, nb in sends:
+                    g = peer if self.group is None else dist.get_global_rank(self.group, peer)
+                    works.append(dist.isend(torch.from_numpy(h[:nb]), g, group=self.group))
+                for peer, t, ptr, nb in recvs:
+                    g = peer if self.group is None else dist.get_global_rank(self.group, peer)
+                    works.append(dist.irecv(t[:nb], g, group=self.group))
+                for w in works:
+                    w.wait()
+                for peer, t, ptr, nb in recvs:
+                    h2d(t.numpy(), ptr, nb)
+                ctx.xfer_synchronize()
+                return 0
+            except Exception as e:
+                print(f"StagedTransport.exchange failed: {e!r}", flush=True)
+                return N.ERR_HIP
+
+        self.all_gather, self.exchange = all_gather, exchange
+
+
+class NativeShardedJoin:
+    """The multi-GPU join as the library runs it (golap_sharded_join).  transport: "rccl" (built-in, ncclSend/ncclRecv from
+    C++; the 128-byte unique id is broadcast once through torch.distributed) or "staged" (StagedTransport)."""
+
+    def __init__(self, ctx, group=None, transport="rccl", max_msg_bytes=0):
+        from .engine import comm_unique_id
+        self.ctx, self.group = ctx, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.max_msg_bytes = max_msg_bytes
+        if transport == "rccl":
+            box = [comm_unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                src = 0 if group is None else dist.get_global_rank(group, 0)
+                dist.broadcast_object_list(box, src=src, group=group)
+            self.comm = ctx.comm_create_rccl(box[0], self.world, self.rank)
+        elif transport == "staged":
+            self._tr = StagedTransport(ctx, group)
+            self.comm = ctx.comm_create_custom(self._tr.all_gather, self._tr.exchange, self.world, self.rank)
+        else:
+            raise ValueError("transport must be 'rccl' or 'staged'")
+
+    def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, n_probe_total=None, out_pairs=None,
+             max_pairs=None, join_type=0, force_exact=False):
+        """-> (pairs int32[.,2] with GLOBAL u32 row ids, count int64[1] device, info dict)."""
+        pairs, cnt = self.comm.sharded_join(build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, n_probe_total,
+                                            out_pairs=out_pairs, max_pairs=max_pairs, join_type=join_type, force_exact=force_exact,
+                                            max_msg_bytes=self.max_msg_bytes)
+        return pairs, cnt, self.comm.info()
+
+    def close(self):
+        self.comm.close()

@@ -62,7 +62,7 @@ def default_config():
 class Context:
     """One golap_ctx on the current torch device (one process per GPU)."""
 
-    def __init__(self, config=None, profiling=False, max_gpu_memory=None):
+    def __init__(self, config=None, profiling=False, max_gpu_memory=None, provision_sigmas=None, max_slabs_per_class=None):
         self._lib = N.load()
         if not torch.cuda.is_available():
             raise GolapError(N.ERR_NO_DEVICE, "no HIP device visible to torch; this package has no CPU fallback")
@@ -72,6 +72,10 @@ class Context:
             cfg.enable_profiling = 1
         if max_gpu_memory is not None:
             cfg.max_gpu_memory = max_gpu_memory
+        if provision_sigmas is not None:
+            cfg.provision_sigmas = provision_sigmas
+        if max_slabs_per_class is not None:
+            cfg.max_slabs_per_class = max_slabs_per_class
         self.config = cfg
         h = C.c_void_p()
         st = self._lib.golap_ctx_create(C.byref(cfg), C.byref(h))
@@ -98,6 +102,25 @@ class Context:
 
     def _ck(self, status):
         N.check(self._h, status)
+
+    # ---- developer / test knobs ------------------------------------------------
+    def debug_set(self, name, value):
+        """golap_debug_set: experiment variants / forced device paths (value None removes the knob)."""
+        self._ck(self._lib.golap_debug_set(self._h, name.encode(), None if value is None else str(value).encode()))
+
+    def knobs(self, **kv):
+        """context manager: set knobs for the duration of a block"""
+        ctx = self
+
+        class _K:
+            def __enter__(self_inner):
+                for k, v in kv.items():
+                    ctx.debug_set(k, v)
+
+            def __exit__(self_inner, *a):
+                for k in kv:
+                    ctx.debug_set(k, None)
+        return _K()
 
     # ---- info / stats ------------------------------------------------------
     def device_info(self):
@@ -266,19 +289,41 @@ class Context:
         side = self._side(keys, rids, seg_off, seg_len, rows)
         self._ck(self._lib.golap_join_partitioned_side(self._h, which, C.byref(side), _stream()))
 
+    def join_partitioned_abort(self):
+        self._ck(self._lib.golap_join_partitioned_abort(self._h))
+
     def join_partitioned_finish(self, out_pairs, out_count=None):
         if out_count is None:
             out_count = torch.zeros(1, dtype=torch.int64, device=out_pairs.device)
         self._ck(self._lib.golap_join_partitioned_finish(self._h, _ptr(out_pairs), _ptr(out_count), out_pairs.numel() // 2, _stream()))
         return out_pairs, out_count
 
+    # ---- multi-GPU sharded join (golap_comm / golap_sharded_join) -----------------------
+    def comm_create_rccl(self, comm_id, world, rank):
+        """Built-in RCCL communicator; comm_id = the 128 bytes of comm_unique_id() made on one rank and handed to all."""
+        buf = (C.c_uint8 * N.COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        h = C.c_void_p()
+        self._ck(self._lib.golap_comm_create_rccl(self._h, buf, world, rank, C.byref(h)))
+        return Comm(self, h, world, rank)
+
+    def comm_create_custom(self, all_gather, exchange, world, rank):
+        """Communicator over host-supplied transport callbacks (N.ALL_GATHER_FN / N.EXCHANGE_FN signatures)."""
+        tr = N.Transport(None, N.ALL_GATHER_FN(all_gather), N.EXCHANGE_FN(exchange))
+        h = C.c_void_p()
+        self._ck(self._lib.golap_comm_create_custom(self._h, C.byref(tr), world, rank, C.byref(h)))
+        c = Comm(self, h, world, rank)
+        c._keep = tr      # the C side copied the struct; the callback objects must stay alive
+        return c
+
     # ---- GpuAggregate -----------------------------------------------------------
-    def aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False):
+    def aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False, hashed=False):
         """AggregateKernel::aggregate.
 
         specs  : list of (func, value_col_index) -- output plane i belongs to specs[i]
         values : list of int64/float64 device tensors
         -> f64[n_specs, n_groups] (and u64 counts as int64[n_groups] when want_counts)
+        hashed : GOLAP_KEYS_HASHED -- any keys; n_groups bounds the number of distinct keys;
+                 -> (out, [counts,] slot_keys int64[n_groups], n_distinct int32[1] device)
         """
         dev = values[0].device
         n_rows = values[0].numel()
@@ -301,8 +346,13 @@ class Context:
                 raise TypeError("group keys must be int32 or int64")
             if group_keys.numel() != n_rows:
                 raise ValueError("group key column differs in length")
-        prm = N.AggregateParams(_ptr(group_keys), vptrs, nv, n_rows, n_groups, _ptr(out), kd, vdt, _ptr(counts))
+        okeys = torch.zeros(n_groups, dtype=torch.int64, device=dev) if hashed else None
+        ong = torch.zeros(1, dtype=torch.int32, device=dev) if hashed else None
+        prm = N.AggregateParams(_ptr(group_keys), vptrs, nv, n_rows, n_groups, _ptr(out), kd, vdt, _ptr(counts),
+                                N.KEYS_HASHED if hashed else N.KEYS_DENSE, 0, _ptr(okeys), _ptr(ong))
         self._ck(self._lib.golap_aggregate(self._h, sp, len(specs), C.byref(prm), _stream()))
+        if hashed:
+            return (out, counts, okeys, ong) if want_counts else (out, okeys, ong)
         return (out, counts) if want_counts else out
 
     # ---- arrow-interop widening ----------------------------------------------------
@@ -334,3 +384,80 @@ class Context:
 
     def synchronize(self):
         self._ck(self._lib.golap_ctx_synchronize(self._h, _stream()))
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0 calls it, the host hands the 128 bytes to every rank)."""
+    buf = (C.c_uint8 * N.COMM_ID_BYTES)()
+    N.check(None, N.load().golap_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def shard_range(n_total, rank, world):
+    """golap_shard_range: rank g holds rows [g*N/P, (g+1)*N/P) (last rank takes the remainder)."""
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    N.load().golap_shard_range(n_total, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def sharded_plan(world, n_build_total, n_probe_total=None, max_msg_bytes=0):
+    """golap_sharded_plan_get (host only): the fast path's provisioned bucket ranges and message sizes."""
+    pl = N.ShardedPlan()
+    N.check(None, N.load().golap_sharded_plan_get(world, n_build_total, n_build_total if n_probe_total is None else n_probe_total,
+                                                  None, None, max_msg_bytes, C.byref(pl)))
+    return {"eligible": bool(pl.eligible), "extra_bits": pl.extra_bits, "n_buckets": pl.n_buckets, "buckets_per_rank": pl.buckets_per_rank,
+            "local_bits": pl.local_bits,
+            "cap_rows": [[pl.cap_rows[s][r] for r in range(world)] for s in range(2)],
+            "msg_bytes": [[pl.msg_bytes[s][r] for r in range(world)] for s in range(2)],
+            "msg_pieces": [[pl.msg_pieces[s][r] for r in range(world)] for s in range(2)]}
+
+
+class Comm:
+    """golap_comm: a context bound to a communicator (one process per GPU)."""
+
+    def __init__(self, ctx, handle, world, rank):
+        self.ctx, self._h, self.world, self.rank = ctx, handle, world, rank
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.golap_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sharded_join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, n_probe_total=None, out_pairs=None,
+                     max_pairs=None, out_count=None, join_type=0, force_exact=False, max_msg_bytes=0):
+        """golap_sharded_join (collective).  -> (pairs int32[max_pairs,2] with GLOBAL u32 row ids, count int64[1] device)."""
+        _chk_tensor(build_keys, torch.int64, "build_keys")
+        _chk_tensor(probe_keys, torch.int64, "probe_keys")
+        if n_probe_total is None:
+            n_probe_total = n_build_total
+        if out_pairs is None:
+            max_pairs = max(1, probe_keys.numel() * 2 if max_pairs is None else max_pairs)
+            out_pairs = torch.empty((max_pairs, 2), dtype=torch.int32, device=build_keys.device)
+        elif max_pairs is None:
+            max_pairs = out_pairs.numel() // 2
+        if out_count is None:
+            out_count = torch.zeros(1, dtype=torch.int64, device=build_keys.device)
+        prm = N.ShardedJoinParams(_ptr(build_keys), _ptr(probe_keys), build_keys.numel(), probe_keys.numel(), build_rid_base, probe_rid_base,
+                                  n_build_total, n_probe_total, None, None, _ptr(out_pairs), _ptr(out_count), max_pairs, join_type,
+                                  1 if force_exact else 0, max_msg_bytes)
+        self.ctx._ck(self.ctx._lib.golap_sharded_join(self.ctx._h, self._h, C.byref(prm), _stream()))
+        return out_pairs, out_count
+
+    def selftest(self, nbytes):
+        """golap_comm_selftest -> (wrong 4-byte words, index of the first one or None)."""
+        bad, first = C.c_uint64(0), C.c_uint64(0)
+        self.ctx._ck(self.ctx._lib.golap_comm_selftest(self.ctx._h, self._h, nbytes, C.byref(bad), C.byref(first)))
+        return bad.value, (first.value if bad.value else None)
+
+    def info(self):
+        i = N.ShardedJoinInfo()
+        self.ctx._ck(self.ctx._lib.golap_sharded_join_info_get(self._h, C.byref(i)))
+        return {"fast_path": bool(i.fast_path), "fast_path_abandoned": bool(i.fast_path_abandoned), "extra_bits": i.extra_bits,
+                "n_groups": i.n_groups, "local_bits": i.local_bits, "host_syncs": i.host_syncs,
+                "rows_received": list(i.rows_received), "bytes_sent": list(i.bytes_sent)}

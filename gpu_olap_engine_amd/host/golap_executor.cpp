@@ -590,10 +590,57 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
         double mmv[2];
         H_TRY(d2h(dmm.ptr, mmv, 16));
         H_TRY(xsync());
-        if (mmv[0] < 0 || mmv[1] > 9e15) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group keys must be non-negative and dense");
+        // dense keys (non-negative, range not much wider than the row count) index the group table directly (slot = key % G,
+        // join_kernels.cuh:230); anything else -- negative, sparse, hash-like keys -- goes through the key -> slot hash table
+        // (GOLAP_KEYS_HASHED, aggregate_kernel.rs:76-77)
+        const bool dense_keys = mmv[0] >= 0 && mmv[1] <= 9e15 && (mmv[1] - mmv[0]) < (double)(64ull << 20) && (mmv[1] - mmv[0]) <= 4.0 * (double)n + 1024.0;
+        if (!dense_keys) {
+            const uint64_t bound = std::min<uint64_t>(n, 1ull << 23);   // distinct keys <= rows
+            DevBuf dout, dcnt, dkeys, dn;
+            H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * bound * 8));
+            H_TRY(dcnt.alloc(ctx, bound * 8));
+            H_TRY(dkeys.alloc(ctx, bound * 8));
+            H_TRY(dn.alloc(ctx, 8));
+            memset(&ap, 0, sizeof ap);
+            ap.group_key_ptr = dk.ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)bound;
+            ap.out_ptr = dout.ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt.ptr;
+            ap.key_mode = GOLAP_KEYS_HASHED; ap.out_keys_ptr = dkeys.ptr; ap.out_n_groups_ptr = dn.ptr;
+            if (na == 0) {
+                golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
+                ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd;
+                H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
+            } else {
+                H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
+            }
+            H_TRY(ksync());
+            uint32_t nd = 0;
+            H_TRY(d2h(dn.ptr, &nd, 4));
+            H_TRY(xsync());
+            if (nd > bound) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^23 distinct group keys");
+            std::vector<int64_t> gk(nd);
+            std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * bound);
+            if (nd) H_TRY(d2h(dkeys.ptr, gk.data(), (uint64_t)nd * 8));
+            H_TRY(d2h(dout.ptr, res.data(), res.size() * 8));
+            H_TRY(xsync());
+            std::vector<uint32_t> order(nd);
+            for (uint32_t i = 0; i < nd; ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return gk[a] < gk[b]; });   // rows sorted by key
+            for (uint32_t slot : order) {
+                kc.data.insert(kc.data.end(), (const uint8_t*)&gk[slot], (const uint8_t*)&gk[slot] + 8);
+                for (uint32_t i = 0; i < na; ++i) {
+                    const double v = res[(size_t)i * bound + slot];
+                    acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&v, (const uint8_t*)&v + 8);
+                }
+                ob.num_rows++;
+            }
+            kc.rows = ob.num_rows;
+            ob.cols.push_back(std::move(kc));
+            for (auto& c : acs) { c.rows = ob.num_rows; ob.cols.push_back(std::move(c)); }
+            out.push_back(std::move(ob));
+            return GOLAP_OK;
+        }
         const int64_t kmin = (int64_t)mmv[0], kmax = (int64_t)mmv[1];
         const uint64_t G = (uint64_t)(kmax - kmin) + 1;
-        if (G > (64ull << 20)) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: key range too wide for the dense group table");
         DevBuf dout, dcnt;
         H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * G * 8));
         H_TRY(dcnt.alloc(ctx, G * 8));

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GOLAP_ABI_VERSION 1
+#define GOLAP_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -56,7 +56,11 @@ typedef struct golap_engine_config {
     int32_t  device_id;          /* HIP ordinal; -1 = current device            */
     uint32_t radix_bits;         /* join_kernels.cuh:22  RADIX_BITS = 8         */
     uint32_t enable_profiling;   /* 1 = record per-kernel hipEvents (golap_stats) */
+    uint32_t max_slabs_per_class;/* slab_allocator.rs:25-28 (constructor argument); default 4096: in practice only max_gpu_memory bounds the pool */
+    uint32_t provision_sigmas;   /* standard deviations of head-room in the provisioned (no-histogram) layouts; 0 = default 6.
+                                    Tests set 1 / GOLAP_PROVISION_NONE to force the overflow fall-backs; results never depend on it. */
 } golap_engine_config;
+#define GOLAP_PROVISION_NONE 0xFFFFFFFFu   /* provision_sigmas: no head-room at all */
 
 void    golap_engine_config_default(golap_engine_config* cfg);
 int32_t golap_ctx_create(const golap_engine_config* cfg, golap_ctx** out_ctx);
@@ -64,6 +68,11 @@ void    golap_ctx_destroy(golap_ctx* ctx);
 /* ctx may be NULL: returns the calling thread's last error. */
 const char* golap_last_error(const golap_ctx* ctx);
 uint32_t golap_abi_version(void);
+
+/* Developer / test knobs: named strings that select experiment variants or force rarely taken device paths (the names are
+ * listed in scripts/README.md; results never depend on them).  value NULL removes a knob.  The library does not read the
+ * process environment on any compute path; GOLAP_* variables are imported once at golap_ctx_create when GOLAP_DEBUG_ENV is set. */
+int32_t golap_debug_set(golap_ctx* ctx, const char* name, const char* value);
 
 typedef struct golap_device_info {
     char     name[128];
@@ -243,7 +252,11 @@ int32_t golap_join_partitioned(golap_ctx* ctx, const golap_join_partitioned_para
 
 /* The same join in three steps, so that the partition exchange of one side can overlap the device work of
  * the other: begin (plan + workspace), side (local sub-partitioning of the build (0) or probe (1) rows, may be
- * called as soon as that side's rows have arrived), finish (LDS build/probe, pair output). */
+ * called as soon as that side's rows have arrived), finish (LDS build/probe, pair output).
+ * Between begin and finish the context's scratch workspace belongs to this join: every other compute call on the
+ * same context (golap_join, golap_radix_partition, golap_aggregate, golap_filter_*) fails with GOLAP_ERR_INVALID_ARG
+ * instead of overwriting the partitioned rows -- partition both sides BEFORE begin, or use a second context.
+ * golap_join_partitioned_abort releases the workspace without joining. */
 typedef struct golap_join_partitioned_plan {
     uint32_t n_groups;     /* (256 / n_owners) << extra_bits */
     uint32_t n_sources;
@@ -258,6 +271,81 @@ int32_t golap_join_partitioned_narrow_ok(const golap_join_partitioned_plan* plan
 int32_t golap_join_partitioned_begin(golap_ctx* ctx, const golap_join_partitioned_plan* plan, void* stream);
 int32_t golap_join_partitioned_side(golap_ctx* ctx, int32_t which, const golap_partitioned_side* side, void* stream);
 int32_t golap_join_partitioned_finish(golap_ctx* ctx, uint64_t out_pairs_ptr, uint64_t out_count_ptr, uint64_t max_pairs, void* stream);
+int32_t golap_join_partitioned_abort(golap_ctx* ctx);
+
+/* ---- multi-GPU: one process per GPU, partition exchange over xGMI ----------------------------
+ * The reference has no distributed layer (README.md:414); north_star asks for the 256 radix partitions sharded over the
+ * GPUs of one node with an RCCL all-to-all.  Rows of both tables start range-sharded with GLOBAL u32 row ids; every rank
+ * radix-partitions its rows (join_kernels.cuh:69, partition p -> rank p % P, owner-major so each peer's rows are one
+ * slice), the slices are exchanged, every rank joins its own partitions; output pairs stay sharded.
+ *
+ * golap_comm binds a context to a communicator: the built-in RCCL one (librccl is dlopen'ed; the host distributes the
+ * 128-byte unique id any way it likes) or host-supplied transport callbacks (other fabrics; the tests' gloo rehearsal).
+ * golap_sharded_join is collective: every rank of the communicator calls it with the same totals.  Fast path (large
+ * joins whose keys all lie in [0, 2^32)): no histogram and no size exchange -- every bucket owns a fixed, provisioned
+ * range, messages have sizes both ends can compute, the per-bucket row counts travel device-to-device (all-gather) and
+ * only reach the kernels; ONE host synchronisation per join (the status word at the end).  Anything else (a key outside
+ * [0, 2^32), a skewed bucket, small inputs) takes the exact path: histogram partition, size all-gather read back by the
+ * host, variable-size exchange, segment-fed local passes.  All ranks take the same path (the status word is gathered). */
+typedef struct golap_comm golap_comm;
+typedef struct golap_p2p_op {
+    int32_t  peer;       /* rank in the communicator */
+    int32_t  is_send;    /* 1 = send, 0 = receive */
+    uint64_t ptr;        /* device address */
+    uint64_t bytes;
+} golap_p2p_op;
+typedef struct golap_transport {
+    void* user;
+    /* every rank contributes bytes_per_rank from send_ptr; recv_ptr receives world * bytes_per_rank, rank-major (device memory) */
+    int32_t (*all_gather)(void* user, uint64_t send_ptr, uint64_t recv_ptr, uint64_t bytes_per_rank, void* stream);
+    /* one group of point-to-point transfers; between two ranks sends and receives match in list order */
+    int32_t (*exchange)(void* user, const golap_p2p_op* ops, uint32_t n_ops, void* stream);
+} golap_transport;
+#define GOLAP_COMM_ID_BYTES 128
+int32_t golap_comm_unique_id(uint8_t out_id[GOLAP_COMM_ID_BYTES]);                     /* ncclGetUniqueId (rank 0, then broadcast by the host) */
+int32_t golap_comm_create_rccl(golap_ctx* ctx, const uint8_t id[GOLAP_COMM_ID_BYTES], int32_t world, int32_t rank, golap_comm** out);
+int32_t golap_comm_create_custom(golap_ctx* ctx, const golap_transport* transport, int32_t world, int32_t rank, golap_comm** out);
+void    golap_comm_destroy(golap_comm* comm);
+
+typedef struct golap_sharded_join_params {
+    uint64_t build_key_ptr, probe_key_ptr;       /* device int64: this rank's rows */
+    uint64_t n_build_local, n_probe_local;
+    uint32_t build_rid_base, probe_rid_base;     /* global row id of local row 0 */
+    uint64_t n_build_total, n_probe_total;       /* over all ranks */
+    const uint64_t* build_rows_per_rank;         /* host [world] or NULL = range sharding (golap_shard_range) */
+    const uint64_t* probe_rows_per_rank;
+    uint64_t out_pairs_ptr, out_count_ptr, max_pairs;   /* as golap_join_params; pairs carry global row ids */
+    int32_t  join_type;                          /* as golap_join_params */
+    int32_t  force_exact;                        /* != 0: skip the fast path */
+    uint64_t max_msg_bytes;                      /* 0 = 1 GiB: larger messages are split (both ends compute the same pieces) */
+} golap_sharded_join_params;
+typedef struct golap_sharded_join_info {          /* what the last golap_sharded_join on this communicator did */
+    uint32_t fast_path;          /* 1: the no-histogram tuple path produced the result */
+    uint32_t fast_path_abandoned;/* 1: it was tried and its status word sent every rank to the exact path */
+    uint32_t extra_bits, n_groups, local_bits;
+    uint32_t host_syncs;         /* host synchronisations inside the call */
+    uint64_t rows_received[2];   /* build, probe (exact path; fast path: provisioned rows) */
+    uint64_t bytes_sent[2];
+} golap_sharded_join_info;
+int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* comm, const golap_sharded_join_params* params, void* stream);
+int32_t golap_sharded_join_info_get(golap_comm* comm, golap_sharded_join_info* out);
+/* Diagnostic: ONE unsplit message of `bytes` bytes from this rank to itself through the transport, verified on the device:
+ * *out_bad_words = 4-byte words that arrived wrong (first one in *out_first_bad_word).  golap_sharded_join never sends more
+ * than max_msg_bytes in one message; this pins where larger ones stop working on a given RCCL build. */
+int32_t golap_comm_selftest(golap_ctx* ctx, golap_comm* comm, uint64_t bytes, uint64_t* out_bad_words, uint64_t* out_first_bad_word);
+/* rank g of `world` holds rows [lo, hi) of n_total (last rank takes the remainder) */
+void    golap_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi);
+/* Host-only description of the fast path's messages (every rank computes the same numbers; no device needed):
+ * rows provisioned per bucket by each source rank and the pieces of every (source, destination) message. */
+typedef struct golap_sharded_plan {
+    uint32_t eligible;           /* 1: the fast path applies to these sizes */
+    uint32_t extra_bits, n_buckets, buckets_per_rank, local_bits;
+    uint64_t cap_rows[2][64];    /* [side][source rank] rows provisioned per bucket */
+    uint64_t msg_bytes[2][64];   /* [side][source rank] bytes every peer receives from that rank */
+    uint32_t msg_pieces[2][64];  /* pieces that message is split into (max_msg_bytes) */
+} golap_sharded_plan;
+int32_t golap_sharded_plan_get(uint32_t world, uint64_t n_build_total, uint64_t n_probe_total, const uint64_t* build_rows_per_rank,
+                               const uint64_t* probe_rows_per_rank, uint64_t max_msg_bytes, golap_sharded_plan* out);
 
 /* ---- GpuAggregate --------------------------------------------------------
  * AggFunc + identity_value aggregate_kernel.rs:17-34, AggregateSpec :38-44,
@@ -286,7 +374,17 @@ typedef struct golap_aggregate_params {             /* aggregate_kernel.rs:47-58
     int32_t  key_dtype;          /* GOLAP_DT_INT64 | GOLAP_DT_INT32 */
     const int32_t* value_dtypes; /* host, per value column: GOLAP_DT_INT64 | GOLAP_DT_FLOAT64 */
     uint64_t out_count_ptr;      /* device u64[n_groups] rows per group (0 = not wanted); groups with 0 rows are absent */
+    int32_t  key_mode;           /* GOLAP_KEYS_DENSE (0): slot = key % n_groups exactly as join_kernels.cuh:230 -- a correct GROUP BY when the keys
+                                    lie in [0, n_groups); distinct keys congruent mod n_groups are merged (the reference kernel's behaviour).
+                                    GOLAP_KEYS_HASHED (1): ANY int64 / int32 keys: an open-addressing key -> slot table in device memory
+                                    (aggregate_kernel.rs:76-77 "global-memory hash table with open addressing") gives every distinct key a dense
+                                    slot, then the dense path runs on the slots.  n_groups = upper bound on the number of distinct keys. */
+    int32_t  reserved0;
+    uint64_t out_keys_ptr;       /* HASHED: device int64[n_groups]: the key that owns each slot (slots are numbered in table order: reproducible) */
+    uint64_t out_n_groups_ptr;   /* HASHED: device u32: distinct keys found.  A value above n_groups means the bound was too small: the outputs
+                                    are then meaningless (memory-safe) and the call must be repeated with a larger n_groups. */
 } golap_aggregate_params;
+enum { GOLAP_KEYS_DENSE = 0, GOLAP_KEYS_HASHED = 1 };
 
 /* Results are f64 like the CPU path (executor.rs:330-349): SUM, COUNT (as f64),
  * MIN, MAX, AVG (= sum/count, 0.0 for an empty group, executor.rs:339-345).

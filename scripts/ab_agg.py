@@ -11,7 +11,7 @@ v = ctx.generate(N.GEN_SM64_MOD_F64, n, modulus=1024, seed=8)
 res = {x: [] for x in vals}
 for rnd in range(6):
     for x in vals:
-        os.environ[var] = x
+        ctx.debug_set(var, x)
         ctx.stats_reset()
         ctx.aggregate([(N.AGG_SUM, 0)], [v], group_keys=k, n_groups=G)
         torch.cuda.synchronize()

@@ -13,7 +13,7 @@ out = torch.empty((n, 2), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1
 res = {v: {} for v in vals}
 for rnd in range(5):
     for v in vals:
-        os.environ[var] = v
+        ctx.debug_set(var, v)
         ctx.stats_reset()
         ctx.join(b, p, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH, out_count=cnt)
         torch.cuda.synchronize()

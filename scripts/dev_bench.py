@@ -39,13 +39,13 @@ def main():
     for v in variants:
         mode, _, bits = v.partition(":") if ":" in v else ("", "", v)
         if mode:
-            os.environ["GOLAP_SCATTER"] = mode
+            ctx.debug_set("GOLAP_SCATTER", mode)
         else:
-            os.environ.pop("GOLAP_SCATTER", None)
+            ctx.debug_set("GOLAP_SCATTER", None)
         if bits == "default" or not bits:
-            os.environ.pop("GOLAP_PASS_BITS", None)
+            ctx.debug_set("GOLAP_PASS_BITS", None)
         else:
-            os.environ["GOLAP_PASS_BITS"] = bits
+            ctx.debug_set("GOLAP_PASS_BITS", bits)
         for it in range(3):
             ctx.stats_reset()
             torch.cuda.synchronize()

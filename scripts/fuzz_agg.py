@@ -50,8 +50,7 @@ def main():
         env = {}
         if rng.random() < 0.15:
             env["GOLAP_AGG_PART"] = "0"
-        os.environ.pop("GOLAP_AGG_PART", None)
-        os.environ.update(env)
+        ctx.debug_set("GOLAP_AGG_PART", env.get("GOLAP_AGG_PART"))
         slots = (keys.astype(np.int64) % G)
         ok, ost = oracle.group_aggregate(slots, vals.astype(np.float64))
         out, counts = ctx.aggregate(SPECS, [torch.from_numpy(vals).cuda()], group_keys=torch.from_numpy(keys).cuda(), n_groups=G, want_counts=True)

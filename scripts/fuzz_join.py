@@ -87,8 +87,7 @@ def main():
         exp, me = oracle.hash_join_outer(b, p, jt)
         recipe = f"seed={seed} round={rnd} nb={nb} np={npr} kind={kind} domain={domain} jt={jt} strategy={strategy} env={env}"
         for k in HOOKS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
+            ctx.debug_set(k, env.get(k))
         bt = torch.from_numpy(np.ascontiguousarray(b, dtype=np.int64)).cuda() if nb else torch.empty(0, dtype=torch.int64, device="cuda")
         pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)).cuda() if npr else torch.empty(0, dtype=torch.int64, device="cuda")
         pairs, cnt = ctx.join(bt, pt, max_pairs=max(1, me + 8), strategy=strategy, join_type=jt)

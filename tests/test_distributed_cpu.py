@@ -231,3 +231,58 @@ def test_sharded_aggregate_gloo():
     for rank, out in res:                                   # every rank holds the full reduced table
         assert np.array_equal(out[0], st[:, 0]) and np.array_equal(out[1], st[:, 1]) and np.array_equal(out[2], st[:, 2])
         assert np.array_equal(out[3], st[:, 3]) and np.array_equal(out[4], st[:, 4])
+
+
+# ---- golap_sharded_join's host-side plan (C ABI, no device needed): every rank must derive the same messages ---------------
+def _plan_worker(rank, world, port, n, max_msg, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpu_olap_engine_amd.engine import shard_range, sharded_plan
+        pl = sharded_plan(world, n, max_msg_bytes=max_msg)
+        pl["rows"] = shard_range(n, rank, world)[1] - shard_range(n, rank, world)[0]
+        box = [None] * world
+        dist.all_gather_object(box, pl)
+        q.put((rank, box))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,max_msg", [(2, 1_000_000_000, 0), (4, 1_000_000_000, 1 << 28), (2, 999_999_937, 0)])
+def test_sharded_plan_is_the_same_on_every_rank(world, n, max_msg):
+    """The fast path has no size exchange: the bytes rank s sends to rank d are a function of s's row count alone, so both ends
+    must compute them identically (here: every rank computes the whole table through the C ABI and the tables are compared
+    under gloo), pieces must cover the message, and every bucket's range must hold its expected rows with 6 sigma to spare."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, n, max_msg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mm = max_msg or (1 << 30)
+    for rank, box in res:
+        ref = {k: v for k, v in box[0].items() if k != "rows"}
+        for r in range(world):
+            assert {k: v for k, v in box[r].items() if k != "rows"} == ref       # identical on every rank
+        assert ref["eligible"] and ref["n_buckets"] == 256 << ref["extra_bits"] and ref["buckets_per_rank"] * world == ref["n_buckets"]
+        for side in range(2):
+            for s in range(world):
+                rows = box[s]["rows"]
+                cap, nb = ref["cap_rows"][side][s], ref["n_buckets"]
+                avg = -(-rows // nb)
+                assert cap % 16 == 0 and cap >= avg + 6 * int(avg ** 0.5)          # provisioned range: mean + 6 sigma (Poisson), line aligned
+                assert ref["msg_bytes"][side][s] == ref["buckets_per_rank"] * cap * 8
+                assert (ref["msg_pieces"][side][s] - 1) * mm < ref["msg_bytes"][side][s] <= ref["msg_pieces"][side][s] * mm
+
+
+def test_sharded_plan_small_inputs_take_the_exact_path():
+    from gpu_olap_engine_amd.engine import sharded_plan
+    assert not sharded_plan(2, 3_000_000)["eligible"]          # below the big-tile first pass: histogram partition + size exchange
+    assert sharded_plan(8, 1_000_000_000)["eligible"]
+    assert sharded_plan(8, 1_000_000_000)["extra_bits"] == 1 and sharded_plan(8, 1_000_000_000)["local_bits"] == 9

@@ -130,11 +130,8 @@ def test_grouped_aggregate_partitioned_path(ctx, key_dtype, G):
     assert "agg_partition_scatter" in ctx.stats()
     present = counts > 0
     assert np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
-    os.environ["GOLAP_AGG_PART"] = "0"
-    try:
+    with ctx.knobs(GOLAP_AGG_PART="0"):
         out2 = ctx.aggregate(specs, [dv], group_keys=dk, n_groups=G).cpu().numpy()
-    finally:
-        del os.environ["GOLAP_AGG_PART"]
     assert np.array_equal(out2, out)
 
 
@@ -208,3 +205,78 @@ def test_api_constants(ctx):
     assert E.choose_strategy(500_000) == N.JOIN_BROADCAST_HASH and E.choose_strategy(5_000_000) == N.JOIN_RADIX_HASH   # join_kernel.rs:85-87
     assert E.compute_launch_params(1024) == (4, 256) and E.compute_launch_params(1) == (1, 256)                     # filter_kernel.rs:87-94
     assert E.agg_identity_value(N.AGG_SUM) == 0 and E.agg_identity_value(N.AGG_MIN) == 2**63 - 1 and E.agg_identity_value(N.AGG_MAX) == -2**63
+
+
+def _hashed_check(ctx, keys, vals, bound):
+    ok, ost = oracle.group_aggregate(keys.astype(np.int64), vals.astype(np.float64))
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0)]
+    out, counts, skeys, nd = ctx.aggregate(specs, [dev(vals)], group_keys=dev(keys), n_groups=bound, want_counts=True, hashed=True)
+    nd = int(nd.item())
+    assert nd == ok.size
+    out, counts, skeys = out.cpu().numpy()[:, :nd], counts.cpu().numpy()[:nd], skeys.cpu().numpy()[:nd]
+    order = np.argsort(skeys, kind="stable")
+    assert np.array_equal(skeys[order], ok)                      # every distinct key owns exactly one slot
+    assert np.array_equal(out[:, order].T, ost)                  # sum, count, min, max, avg per key: bit-exact
+    assert np.array_equal(counts[order].astype(np.float64), ost[:, 1])
+    return skeys
+
+
+@pytest.mark.parametrize("key_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("n_distinct", [1, 37, 3000, 150_000])
+def test_hashed_group_by_any_keys(ctx, key_dtype, n_distinct):
+    """GOLAP_KEYS_HASHED (aggregate_kernel.rs:76-77, the open-addressing table the reference's kernel lacks): negative, sparse and
+    congruent keys each get their own group -- what slot = key % n_groups (join_kernels.cuh:230) silently merges."""
+    n = 500_000
+    rng = np.random.default_rng(n_distinct)
+    info = np.iinfo(key_dtype)
+    pool = np.unique(np.concatenate([rng.integers(info.min, info.max, n_distinct, dtype=key_dtype),
+                                     np.array([0, -1, 1, info.min, info.max, 1024, 2048, -1024], key_dtype)[: max(1, min(8, n_distinct))]]))[:n_distinct]
+    keys = pool[rng.integers(0, pool.size, n)]
+    vals = rng.integers(-2048, 2048, n).astype(np.float64)
+    s1 = _hashed_check(ctx, keys, vals, bound=max(8, 2 * pool.size))
+    s2 = _hashed_check(ctx, keys[::-1].copy(), vals[::-1].copy(), bound=max(8, 2 * pool.size))
+    assert np.array_equal(s1, s2)                                # slot numbering is the table order: independent of the row order
+
+
+def test_hashed_group_by_reports_a_bound_that_is_too_small(ctx):
+    n = 100_000
+    keys = np.arange(n, dtype=np.int64) * 7919 - 12345
+    vals = np.ones(n)
+    out, skeys, nd = ctx.aggregate([(N.AGG_SUM, 0)], [dev(vals)], group_keys=dev(keys), n_groups=1000, hashed=True)
+    assert int(nd.item()) > 1000                                 # (2^32-1 when even the table overflowed): the caller must retry with a larger bound
+    _hashed_check(ctx, keys, vals, bound=n)
+
+
+def test_hashed_group_by_empty_and_int64_min(ctx):
+    keys = np.array([np.iinfo(np.int64).min, 5, np.iinfo(np.int64).min, 5, 9], np.int64)
+    _hashed_check(ctx, keys, np.array([1.0, 2.0, 3.0, 4.0, 5.0]), bound=16)
+    out, skeys, nd = ctx.aggregate([(N.AGG_SUM, 0)], [torch.empty(0, dtype=torch.float64, device="cuda")],
+                                   group_keys=torch.empty(0, dtype=torch.int64, device="cuda"), n_groups=8, hashed=True)
+    assert int(nd.item()) == 0
+
+
+def test_sum_of_general_doubles_is_within_the_stated_bound(ctx):
+    """executor.rs:313-327 sums sequentially in row order; the device sums per-block partials folded in a fixed tree order.  For
+    doubles that are not integer-valued the two orders round differently: the difference is bounded by n * eps * sum|x| (a loose
+    forward bound for any summation order), and in practice far smaller.  Integer-valued data is exact in every order (all other tests)."""
+    n = 3_000_017
+    rng = np.random.default_rng(3)
+    x = rng.random(n) * 1e6 - 3e5
+    exp = oracle.execute_aggregate(x)                            # sequential, like the reference
+    got = ctx.aggregate([(N.AGG_SUM, 0), (N.AGG_AVG, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0)], [dev(x)]).cpu().numpy()[:, 0]
+    eps = np.finfo(np.float64).eps
+    bound = n * eps * float(np.abs(x).sum())
+    assert abs(got[0] - exp["sum"]) <= bound and abs(got[0] - exp["sum"]) <= 1e-9 * abs(exp["sum"])
+    assert abs(got[1] - exp["avg"]) <= bound / n + eps * abs(exp["avg"])
+    assert got[2] == exp["min"] and got[3] == exp["max"]         # order-independent
+    again = ctx.aggregate([(N.AGG_SUM, 0)], [dev(x)]).cpu().numpy()[0, 0]
+    assert again == got[0]                                       # fixed fold order: reproducible run to run
+    # grouped (LDS pre-aggregation + fixed-order fold): same bound per group
+    G = 64
+    k = rng.integers(0, G, n).astype(np.int32)
+    gs = ctx.aggregate([(N.AGG_SUM, 0)], [dev(x)], group_keys=dev(k), n_groups=G).cpu().numpy()[0]
+    for g in range(G):
+        xs = x[k == g]
+        seq = 0.0
+        seq = float(np.add.reduce(xs))   # (pairwise in numpy; the sequential sum lies within the same bound)
+        assert abs(gs[g] - seq) <= xs.size * eps * float(np.abs(xs).sum())

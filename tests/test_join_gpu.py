@@ -213,16 +213,8 @@ def test_no_histogram_last_pass_and_its_overflow_fallback(ctx, env, jt):
     b = oracle.gen_sm64_mod(61, 0, n, n)              # duplicates + misses on both sides
     p = oracle.gen_sm64_mod(62, 0, n, n)
     env = dict(env, GOLAP_PASS_BITS="8,6")            # second pass with fan-out 64: the no-histogram form applies (it needs F >= 32)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with ctx.knobs(**env):
         outer_check(ctx, b, p, N.JOIN_RADIX_HASH, jt)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
 
 
 @pytest.mark.parametrize("env", [{}, {"GOLAP_RESERVE_SIGMAS": "0"}, {"GOLAP_RESERVE_SIGMAS": "1"}, {"GOLAP_SLOT_SIGMAS": "0"},
@@ -236,19 +228,11 @@ def test_no_histogram_first_pass_and_its_overflow_fallback(ctx, env, jt):
     b = oracle.gen_sm64_mod(71, 0, n, n)
     p = oracle.gen_sm64_mod(72, 0, n, n)
     env = dict(env, GOLAP_PASS_BITS="8,6", GOLAP_RESERVE="1")
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with ctx.knobs(**env):
         ctx.stats_reset()
         outer_check(ctx, b, p, N.JOIN_RADIX_HASH, jt)
         st = ctx.stats()
         assert "radix_hist_p1" not in st and "radix_hist_p1_standby" in st     # the reserving form ran, the histogram stood by
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
 
 
 def test_no_histogram_first_pass_with_one_hot_key(ctx):
@@ -258,12 +242,8 @@ def test_no_histogram_first_pass_with_one_hot_key(ctx):
     b = np.concatenate([oracle.gen_build_keys(0, n, n), np.full(400_000, 777, np.int64)])
     p = np.concatenate([oracle.gen_probe_keys(0, n, n), np.full(3, 777, np.int64), rng.integers(0, n, 1000)])
     env = dict(GOLAP_PASS_BITS="8,6", GOLAP_RESERVE="1")
-    os.environ.update(env)
-    try:
+    with ctx.knobs(**env):
         check(ctx, b, p, N.JOIN_RADIX_HASH, max_pairs=8_000_000)
-    finally:
-        for k in env:
-            del os.environ[k]
 
 
 def test_no_histogram_pass_with_skewed_groups(ctx):
@@ -272,11 +252,8 @@ def test_no_histogram_pass_with_skewed_groups(ctx):
     rng = np.random.default_rng(8)
     b = np.concatenate([oracle.gen_build_keys(0, n, n), np.full(30_000, 123456, np.int64)])
     p = np.concatenate([oracle.gen_probe_keys(0, n, n), np.full(40, 123456, np.int64), rng.integers(0, n, 1000)])
-    os.environ["GOLAP_PASS_BITS"] = "8,6"
-    try:
+    with ctx.knobs(GOLAP_PASS_BITS="8,6"):
         check(ctx, b, p, N.JOIN_RADIX_HASH, max_pairs=8_000_000)
-    finally:
-        del os.environ["GOLAP_PASS_BITS"]
 
 
 def test_no_histogram_pass_is_taken_and_flag_stays_clear(ctx):
@@ -351,11 +328,8 @@ def test_forced_pass_structures(ctx, bits):
     n = 2_000_000
     b = oracle.gen_sm64_mod(21, 0, n, n)
     p = oracle.gen_sm64_mod(22, 0, n, n)
-    os.environ["GOLAP_PASS_BITS"] = bits
-    try:
+    with ctx.knobs(GOLAP_PASS_BITS=bits):
         check(ctx, b, p, N.JOIN_RADIX_HASH)
-    finally:
-        del os.environ["GOLAP_PASS_BITS"]
 
 
 def test_generators_match_oracle(ctx):
@@ -442,12 +416,8 @@ def test_radix_partition_narrow_tuples(ctx):
 def test_join_partitioned_split_api_with_extra_bits(ctx, narrow):
     """begin / side / side / finish over buckets of 8+1 bits, 2 sources, equals the plain join; also with the rows as tuples
     (the tuple form exists for local fan-outs >= 32, which real inputs reach from ~25M rows per rank: forced here)."""
-    if narrow:
-        os.environ["GOLAP_LOCAL_BITS"] = "6"
-    try:
+    with ctx.knobs(**({"GOLAP_LOCAL_BITS": "6"} if narrow else {})):
         _split_api_case(ctx, narrow)
-    finally:
-        os.environ.pop("GOLAP_LOCAL_BITS", None)
 
 
 def _split_api_case(ctx, narrow):
@@ -506,65 +476,6 @@ def test_bench_sharded_path_single_rank():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["verify"]["matches"] == 20_000_000 and d["verify"]["probe_id_sum_ok"] and d["verify"]["equal_key_pairs"] == 20_000_000
-
-
-def _gloo_gpu_worker(rank, world, port, n, wide, local_bits, q):
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    if local_bits:
-        os.environ["GOLAP_LOCAL_BITS"] = str(local_bits)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import oracle as orc
-        from gpu_olap_engine_amd.distributed import HipBackend, ShardedJoin, shard_range
-        from gpu_olap_engine_amd.engine import Context
-        torch.cuda.set_device(0)
-        c = Context(max_gpu_memory=0)
-        lo, hi = shard_range(n, rank, world)
-        b = orc.gen_sm64_mod(11, lo, hi - lo, n // 2)
-        p = orc.gen_sm64_mod(12, lo, hi - lo, n // 2)
-        if wide and rank == world - 1:
-            b[-1] = -3                                                # ONE wide key on ONE rank: everybody must fall back together
-        sj = ShardedJoin(HipBackend(c))
-        out = torch.empty((4 * n, 2), dtype=torch.int32, device="cuda")      # duplicates on both sides: E[M] ~ 2N
-        pairs, cnt, nb, npr = sj.join(torch.from_numpy(b).cuda(), torch.from_numpy(p).cuda(), lo, lo, n, out_pairs=out)
-        torch.cuda.synchronize()
-        m = int(cnt.item())
-        q.put((rank, pairs[:m].cpu().numpy().view(np.uint32).copy(), nb, npr))
-        dist.barrier()
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world,wide,local_bits", [(2, False, 0), (2, False, 6), (4, False, 6), (2, True, 6)])
-def test_sharded_join_ranks_share_one_gpu_over_gloo(world, wide, local_bits):
-    """Several ranks drive the REAL kernels on this one GPU (HipBackend per rank; the exchange is staged through host memory
-    under gloo): owner-major slices, multi-source segments, global row ids, and -- with local fan-out forced to 64 so that
-    the tuple forms apply at this size -- the narrow exchange and its joint fall-back, bit-exact against the oracle."""
-    import socket
-    import torch.multiprocessing as mp
-    n = 3_000_000
-    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
-    mpc = mp.get_context("spawn")
-    q = mpc.Queue()
-    procs = [mpc.Process(target=_gloo_gpu_worker, args=(r, world, port, n, wide, local_bits, q)) for r in range(world)]
-    for pr_ in procs:
-        pr_.start()
-    res = [q.get(timeout=240) for _ in range(world)]
-    for pr_ in procs:
-        pr_.join(timeout=60)
-        assert pr_.exitcode == 0
-    b, p = oracle.gen_sm64_mod(11, 0, n, n // 2), oracle.gen_sm64_mod(12, 0, n, n // 2)
-    if wide:
-        b[-1] = -3
-    exp, me = oracle.hash_join(b, p)
-    got = canonical(np.concatenate([r[1] for r in res]))
-    assert got.shape[0] == me and np.array_equal(got, exp)
-    assert sum(r[2] for r in res) == n and sum(r[3] for r in res) == n
 
 
 def test_join_partitioned_two_sources(ctx):
@@ -696,10 +607,8 @@ EDGE_SIZES = [1, 63, 64, 65, 511, 512, 4095, 4096, 4097, 8191, 8192, 8193, 12287
 def test_tile_and_chunk_boundaries(ctx, bits):
     """sizes straddling every tile / window / staging boundary of the scatter kernels (4096, 8192, 12288 rows, 16-row lines),
     under forced pass structures (plain, no-histogram second pass, three passes), inner and full outer, vs the oracle."""
-    rng = np.random.default_rng(hash(bits) & 0xFFFF)
-    if bits:
-        os.environ["GOLAP_PASS_BITS"] = bits
-    try:
+    rng = np.random.default_rng(sum(map(ord, bits or "default")))   # (a fixed seed per case: str hashes change per process)
+    with ctx.knobs(**({"GOLAP_PASS_BITS": bits} if bits else {})):
         for trial in range(len(EDGE_SIZES)):
             nb = EDGE_SIZES[trial]
             npr = EDGE_SIZES[(trial * 7 + 3) % len(EDGE_SIZES)]
@@ -707,8 +616,6 @@ def test_tile_and_chunk_boundaries(ctx, bits):
             b = rng.integers(-span, span, nb).astype(np.int64)
             p = rng.integers(-span, span, npr).astype(np.int64)
             outer_check(ctx, b, p, N.JOIN_RADIX_HASH, N.JT_FULL if trial % 2 else N.JT_INNER)
-    finally:
-        os.environ.pop("GOLAP_PASS_BITS", None)
 
 
 def test_sort_merge_unsupported(ctx):

@@ -73,3 +73,26 @@ def test_device_info_is_mi355x(ctx):
     assert info["wavefront_size"] == 64
     assert "gfx950" in info["gcn_arch"]
     assert info["compute_units"] >= 200
+
+
+def test_workspace_is_guarded_while_a_partitioned_join_is_open(ctx):
+    """golap_join_partitioned_begin keeps pointers into the context's cached workspace across calls: until finish / abort every
+    other compute call on that context must fail loudly instead of overwriting the partitioned rows (golap.h)."""
+    import numpy as np
+    import torch
+    from gpu_olap_engine_amd.engine import GolapError
+    k = torch.arange(100_000, dtype=torch.int64, device="cuda")
+    ctx.join_partitioned_begin(256, 1, 8, 100_000, 100_000, 100_000)
+    try:
+        with pytest.raises(GolapError) as e:
+            ctx.radix_partition(k)
+        assert "workspace" in str(e.value)
+        with pytest.raises(GolapError):
+            ctx.join(k, k)
+        with pytest.raises(GolapError):
+            ctx.join_partitioned_begin(256, 1, 8, 100_000, 100_000, 100_000)      # a second begin is refused as well
+    finally:
+        ctx.join_partitioned_abort()
+    pairs, cnt = ctx.join(k, k)                                                   # usable again, and the sticky error is gone
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 100_000

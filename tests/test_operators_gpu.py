@@ -173,3 +173,38 @@ def test_null_values_become_zero(ctx):
     batch = pa.RecordBatch.from_arrays([pa.array([5, None, 25], pa.int64())], names=["a"])
     out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(0, "a"), "<", O.Literal("10"))), ctx)
     assert out[0].column(0).to_pylist() == [5, 0]
+
+
+def test_aggregate_group_by_sparse_and_negative_keys(ctx):
+    """GROUP BY over keys no dense table can index (negative, 2^40 apart): the operator switches to the key -> slot hash table."""
+    n = 200_000
+    rng = np.random.default_rng(11)
+    pool = np.array([-(1 << 40), -7, 0, 3, 1 << 33, (1 << 62) + 1, np.iinfo(np.int64).min], np.int64)
+    k = pool[rng.integers(0, pool.size, n)]
+    v = rng.integers(-1000, 1000, n).astype(np.float64)
+    out = O.execute(O.GpuAggregate(O.Batches([rb(g=k[:70_000], v=v[:70_000]), rb(g=k[70_000:], v=v[70_000:])]), [O.Column(0, "g")],
+                                   [O.Sum(O.Column(1, "v")), O.Count(O.Column(1, "v")), O.Min(O.Column(1, "v")), O.Avg(O.Column(1, "v"))]), ctx)
+    ks, st = oracle.group_aggregate(k, v)
+    assert np.array_equal(out[0].column(0).to_numpy(), ks)                      # sorted by key
+    assert np.array_equal(out[0].column(1).to_numpy(), st[:, 0]) and np.array_equal(out[0].column(2).to_numpy(), st[:, 1])
+    assert np.array_equal(out[0].column(3).to_numpy(), st[:, 2]) and np.array_equal(out[0].column(4).to_numpy(), st[:, 4])
+
+
+def test_group_by_many_aggregates_on_a_fresh_context():
+    """A fresh context, a small table, six aggregates over six distinct columns: more than eight same-class slabs are alive at once
+    (one per column + keys + outputs); the slab pool's per-class limit is a config field (slab_allocator.rs:25-28), not 8."""
+    from gpu_olap_engine_amd.engine import Context
+    import torch
+    torch.cuda.set_device(0)
+    with Context(max_gpu_memory=0) as c:
+        n = 1000
+        rng = np.random.default_rng(5)
+        cols = {f"c{i}": rng.integers(0, 100, n).astype(np.float64) for i in range(6)}
+        g = rng.integers(0, 10, n).astype(np.int64)
+        aggs = [O.Sum(O.Column(i + 1, f"c{i}")) for i in range(6)]
+        out = O.execute(O.GpuAggregate(O.Batches([rb(g=g, **cols)]), [O.Column(0, "g")], aggs), c)
+        for i in range(6):
+            ks, st = oracle.group_aggregate(g, cols[f"c{i}"])
+            assert np.array_equal(out[0].column(0).to_numpy(), ks) and np.array_equal(out[0].column(i + 1).to_numpy(), st[:, 0])
+        out = O.execute(O.GpuAggregate(O.Batches([rb(**cols, c6=cols["c0"])]), [], aggs + [O.Sum(O.Column(6, "c6"))]), c)   # 7 ungrouped value columns
+        assert out[0].column(6).to_pylist()[0] == float(cols["c0"].sum())

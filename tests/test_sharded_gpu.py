@@ -1,0 +1,197 @@
+"""golap_sharded_join (the C++ multi-GPU join, csrc/golap_shard.inc.h) through the C ABI.
+
+The GPU box has ONE device, so more than one rank can only be rehearsed by letting several processes share it: the library's
+transport callbacks are served by gloo with host staging (distributed.StagedTransport) -- the SAME C++ orchestration, kernels,
+message sizes and segment tables as with the built-in RCCL transport; only the bytes move differently.  RCCL itself is exercised
+at world size 1 (communicator setup, all-gather, the status protocol) and by the message-size probe.  Results are compared
+bit-exactly with the oracle's canonical pair list."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _keys(variant, n, lo, cnt):
+    import oracle
+    if variant == "unique":
+        return oracle.gen_build_keys(lo, cnt, n), oracle.gen_probe_keys(lo, cnt, n)
+    return oracle.gen_sm64_mod(11, lo, cnt, n // 2), oracle.gen_sm64_mod(12, lo, cnt, n // 2)
+
+
+def _worker(rank, world, port, n, variant, mode, join_type, wide_rank, max_msg, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if mode == "fast":
+        os.environ["GOLAP_DEBUG_ENV"] = "1"        # (the library imports GOLAP_* knobs from the environment only when asked to)
+        os.environ["GOLAP_SHARD_FAST"] = "1"       # the fast path at test sizes (its size condition is a speed rule, not a correctness one)
+        os.environ["GOLAP_LOCAL_BITS"] = "6"       # ... with a ring-sized local fan-out (64) although the tables would fit LDS with less
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpu_olap_engine_amd.distributed import NativeShardedJoin
+        from gpu_olap_engine_amd.engine import Context, shard_range
+        torch.cuda.set_device(0)
+        c = Context(max_gpu_memory=0)
+        lo, hi = shard_range(n, rank, world)
+        b, p = _keys(variant, n, lo, hi - lo)
+        if wide_rank == rank:
+            b[-1] = -3                                  # ONE key outside [0, 2^32) on ONE rank: every rank must leave the fast path together
+        sj = NativeShardedJoin(c, transport="staged", max_msg_bytes=max_msg)
+        out = torch.empty((4 * n + 16, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt, info = sj.join(torch.from_numpy(b).cuda(), torch.from_numpy(p).cuda(), lo, lo, n, out_pairs=out, join_type=join_type,
+                                   force_exact=(mode == "exact"))
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        q.put((rank, pairs[:m].cpu().numpy().view(np.uint32).copy(), info))
+        dist.barrier()
+        sj.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, n, variant, mode, join_type=0, wide_rank=-1, max_msg=0):
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n, variant, mode, join_type, wide_rank, max_msg, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    return sorted(res, key=lambda r: r[0])
+
+
+def _expected(n, variant, join_type, world, wide_rank):
+    import oracle
+    b, p = _keys(variant, n, 0, n)
+    if wide_rank >= 0:
+        from gpu_olap_engine_amd.engine import shard_range
+        b[shard_range(n, wide_rank, world)[1] - 1] = -3
+    if join_type == 0:
+        return oracle.hash_join(b, p)
+    return oracle.hash_join_outer(b, p, join_type)
+
+
+@pytest.mark.parametrize("world,variant,mode", [(2, "dups", "fast"), (4, "unique", "fast"), (2, "unique", "exact"), (4, "dups", "exact")])
+def test_sharded_join_ranks_share_one_gpu(world, variant, mode):
+    """2 and 4 ranks, both paths: owner-major slices, per-source segments, global row ids -- bit-exact against the oracle."""
+    from np_twin import canonical
+    n = 3_000_000
+    res = _run(world, n, variant, mode)
+    exp, me = _expected(n, variant, 0, world, -1)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+    for _, _, info in res:
+        assert info["fast_path"] == (mode == "fast") and not info["fast_path_abandoned"]
+        assert info["host_syncs"] == (1 if mode == "fast" else 3)
+
+
+def test_sharded_join_one_wide_key_sends_every_rank_to_the_exact_path():
+    """The fast path's status word is gathered: ONE key outside [0, 2^32) on ONE rank and all ranks redo the join exactly."""
+    from np_twin import canonical
+    n, world = 2_000_000, 2
+    res = _run(world, n, "dups", "fast", wide_rank=1)
+    exp, me = _expected(n, "dups", 0, world, 1)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+    assert all(r[2]["fast_path_abandoned"] and not r[2]["fast_path"] for r in res)
+
+
+@pytest.mark.parametrize("mode,join_type", [("fast", 3), ("exact", 1), ("exact", 2)])
+def test_sharded_outer_joins(mode, join_type):
+    """Left / Right / Full on the sharded path: all rows of a key meet on one rank, so unmatched rows are found locally."""
+    from np_twin import canonical
+    n, world = 1_500_000, 2
+    res = _run(world, n, "dups", mode, join_type=join_type)
+    exp, me = _expected(n, "dups", join_type, world, -1)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+
+
+def test_sharded_join_small_messages_are_split():
+    """max_msg_bytes far below a message: every (source, destination) message travels in many pieces, both ends agree on them."""
+    from np_twin import canonical
+    n, world = 1_000_000, 2
+    for mode in ("fast", "exact"):
+        res = _run(world, n, "unique", mode, max_msg=100_000)
+        exp, me = _expected(n, "unique", 0, world, -1)
+        got = canonical(np.concatenate([r[1] for r in res]))
+        assert got.shape[0] == me and np.array_equal(got, exp)
+
+
+def _rccl_world1(fn):
+    """run fn(comm, ctx) with a world-size-1 built-in RCCL communicator on this GPU"""
+    from gpu_olap_engine_amd.engine import Context, comm_unique_id
+    torch.cuda.set_device(0)
+    c = Context(max_gpu_memory=0)
+    comm = c.comm_create_rccl(comm_unique_id(), 1, 0)
+    try:
+        return fn(comm, c)
+    finally:
+        comm.close()
+        c.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_sharded_join_rccl_world1(mode):
+    """Built-in RCCL transport, one rank: communicator from a unique id, ncclAllGather of the bucket counts and of the status
+    word, the whole partition -> local pass -> join flow at 25M rows; checked on the device."""
+    from gpu_olap_engine_amd import _native as N
+    n = 25_000_000
+
+    def body(comm, c):
+        if mode == "fast":
+            c.debug_set("GOLAP_SHARD_FAST", "1")
+        b = c.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+        p = c.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+        out = torch.empty((n + 16, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt = comm.sharded_join(b, p, 0, 0, n, out_pairs=out, force_exact=(mode == "exact"))
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        v = c.verify_pairs(pairs, m, b, p).cpu()
+        assert m == n and int(v[0]) == n and (int(v[2]) & (2**64 - 1)) == (n * (n - 1) // 2) & (2**64 - 1)
+        return comm.info()
+
+    info = _rccl_world1(body)
+    assert info["fast_path"] == (mode == "fast")
+
+
+def test_rccl_message_size_boundary():
+    """Where do large single RCCL messages stop arriving intact on this stack?  Round 1 saw an 8 GB self-message deliver wrong
+    data (scripts/dbg_sharded.py CHECK_BIG).  golap_sharded_join never sends more than max_msg_bytes (default 1 GiB) in one
+    message; this pins that the default is on the safe side and records the first failing size (if any) in the log."""
+    sizes = [(1 << 30), (1 << 31) - 64, (1 << 31) + 64, (1 << 32) - 64, (1 << 32) + 64, (1 << 33)]
+
+    def body(comm, c):
+        out = []
+        for s in sizes:
+            bad, first = comm.selftest(s)
+            out.append((s, bad, first))
+        return out
+
+    res = _rccl_world1(body)
+    print("rccl self-message check (bytes, wrong words, first wrong word):", res)
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_selftest.log"), "w") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else open(os.devnull, "w") as f:
+        f.write(repr(res) + "\n")
+    assert res[0][1] == 0, "a 1 GiB message (the default max_msg_bytes) must arrive intact"
