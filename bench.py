@@ -10,9 +10,9 @@ A "step" is one complete pass of the operator over the synthetic, device-residen
 exchange over xGMI when N > 1,] LDS build/probe, pair output).  value = rows of the WHOLE job / max-over-ranks time per
 step; join scaling is "strong" (the 1B x 1B table pair is fixed, N GPUs share it).  Rank 0 prints ONE JSON line.
 
-The default C5 run also times the same join with genuinely 64-bit keys (both key columns + 2^40, `wide_keys` in the line):
-BASELINE's generators emit keys below 2^32, which take the 8-byte tuple pipeline; any key outside [0, 2^32) takes the
-64-bit-row pipeline instead.
+The default C5 run also times the same join with keys outside [0, 2^32) (`wide_keys` in the line): both key columns + 2^40
+(all keys share one upper half: still 8-byte tuples, frame of reference) and with two different upper halves (the
+64-bit-row pipeline).  BASELINE's own generators emit keys below 2^32.
 """
 import argparse
 import hashlib
@@ -249,25 +249,32 @@ def bench_join(args, n_total, label):
     if join_info:
         line["sharded_join"] = join_info
 
-    # ---- second leg: the same join with genuinely 64-bit keys (the 64-bit-row pipeline) -------
+    # ---- further legs: the same join with keys outside [0, 2^32) -------------------------------
+    # (a) both key columns + 2^40: every key is a genuine 64-bit value, all share one upper half -> still 8-byte tuples (frame of
+    #     reference on the first build key); (b) two different upper halves -> the 64-bit-row pipeline (12-byte rows)
     if label == "C5" and not args.no_wide and not sharded:
+        def leg(name, what):
+            torch.cuda.synchronize()
+            (pr, cn), dtw = timed(step, args.steps, args.warmup, barrier, ctx)
+            msw = max_over_ranks(dtw) / args.steps * 1e3
+            statsw = ctx.stats()
+            mw = int(cn.item())
+            assert mw == n_total, f"{name}: {mw} matches"
+            if not args.no_verify:
+                v = ctx.verify_pairs(pr, mw, bkeys, pkeys)
+                assert int(v[0].item()) == mw, f"{name} emitted pairs with unequal keys"
+            gb = alg_join / (msw * 1e-3) / 1e9
+            return {"ms_per_step": round(msw, 3), "value": round(2 * n_total / (msw * 1e-3), 1), "unit": "rows/s", "join_alg_GBps": round(gb, 1),
+                    "join_roofline_frac": round(gb / HBM_PEAK_GBPS, 4), "roofline": roofline_of(statsw, n_total, 1, False),
+                    "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in statsw.items() if v["total_ms"] / args.steps > 0.02},
+                    "workload": what}
         bkeys += 1 << 40
         pkeys += 1 << 40
-        torch.cuda.synchronize()
-        (pairs, count), dtw = timed(step, args.steps, args.warmup, barrier, ctx)
-        msw = max_over_ranks(dtw) / args.steps * 1e3
-        statsw = ctx.stats()
-        mw = int(count.item())
-        assert mw == n_total, f"64-bit-key leg: {mw} matches"
-        if not args.no_verify:
-            v = ctx.verify_pairs(pairs, mw, bkeys, pkeys)
-            assert int(v[0].item()) == mw, "64-bit-key leg emitted pairs with unequal keys"
-        gb = alg_join / (msw * 1e-3) / 1e9
-        line["wide_keys"] = {"ms_per_step": round(msw, 3), "value": round(2 * n_total / (msw * 1e-3), 1), "unit": "rows/s",
-                             "join_alg_GBps": round(gb, 1), "join_roofline_frac": round(gb / HBM_PEAK_GBPS, 4),
-                             "roofline": roofline_of(statsw, n_total, 1, False),
-                             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in statsw.items() if v["total_ms"] / args.steps > 0.02},
-                             "workload": "the same generators + 2^40 on both key columns (every key outside [0, 2^32))"}
+        wk = leg("offset_2p40", "the same generators + 2^40 on both key columns: every key outside [0, 2^32), one common upper half")
+        bkeys += (bkeys & 1) << 41
+        pkeys += (pkeys & 1) << 41
+        wk["two_upper_halves"] = leg("two_upper_halves", "as above, odd keys moved by another 2^41: two upper halves -> the 64-bit-row pipeline")
+        line["wide_keys"] = wk
     sample = args.cpu_sample if args.cpu_sample >= 0 else 32_000_000
     cb = cpu_join_baseline(min(sample, n_total), rank) if world == 1 else None
     if cb:

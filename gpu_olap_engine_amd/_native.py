@@ -62,14 +62,16 @@ class FilterPredicate(C.Structure):
 class FilterParams(C.Structure):
     """filter_kernel.rs:17-28."""
     _fields_ = [("column_ptr", C.c_uint64), ("n_rows", C.c_uint64), ("out_mask_ptr", C.c_uint64),
-                ("grid_dim", C.c_uint32), ("block_dim", C.c_uint32)]
+                ("grid_dim", C.c_uint32), ("block_dim", C.c_uint32), ("validity_ptr", C.c_uint64)]
 
 
 class JoinParams(C.Structure):
     """join_kernel.rs:20-27 + extensions."""
     _fields_ = [("build_key_ptr", C.c_uint64), ("probe_key_ptr", C.c_uint64), ("n_build", C.c_uint64),
                 ("n_probe", C.c_uint64), ("out_pairs_ptr", C.c_uint64), ("out_count_ptr", C.c_uint64),
-                ("max_pairs", C.c_uint64), ("build_rid_base", C.c_uint32), ("probe_rid_base", C.c_uint32), ("join_type", C.c_int32)]
+                ("max_pairs", C.c_uint64), ("build_rid_base", C.c_uint32), ("probe_rid_base", C.c_uint32), ("join_type", C.c_int32),
+                ("n_key_cols", C.c_uint32), ("build_key_extra", C.c_uint64 * 3), ("probe_key_extra", C.c_uint64 * 3),
+                ("build_validity", C.c_uint64 * 4), ("probe_validity", C.c_uint64 * 4)]
 
 
 class PartitionParams(C.Structure):
@@ -124,7 +126,7 @@ class ShardedJoinInfo(C.Structure):
 
 class ShardedPlan(C.Structure):
     _fields_ = [("eligible", C.c_uint32), ("extra_bits", C.c_uint32), ("n_buckets", C.c_uint32), ("buckets_per_rank", C.c_uint32),
-                ("local_bits", C.c_uint32), ("cap_rows", (C.c_uint64 * 64) * 2), ("msg_bytes", (C.c_uint64 * 64) * 2),
+                ("local_bits", C.c_uint32), ("sub_ranges", C.c_uint32), ("reserved0", C.c_uint32), ("cap_rows", (C.c_uint64 * 64) * 2), ("msg_bytes", (C.c_uint64 * 64) * 2),
                 ("msg_pieces", (C.c_uint32 * 64) * 2)]
 
 
@@ -177,6 +179,8 @@ SIGNATURES = {
     "golap_compute_launch_params": (None, [C.c_uint64, _P(C.c_uint32), _P(C.c_uint32)]),
     "golap_filter_launch": (C.c_int32, [_VP, _P(FilterPredicate), _P(FilterParams), _VP]),
     "golap_filter_compact": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_filter_compact_nullable": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_filter_sum_nullable": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, _VP]),
     "golap_take_8byte": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_filter_sum": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, _VP]),
     "golap_choose_strategy": (C.c_int32, [C.c_uint64]),

@@ -120,7 +120,11 @@ struct PassCfg {
                            //    owner-major, refined by e1 further hash bits
     uint32_t e1;           // extra bits of the first pass (F = 256 << e1)
     uint32_t owners_log2;  // log2(n_owners)
+    const uint32_t* key_hi;   // tuple kernels only, may be null (= 0): the upper 32 bits every key of this join shares.  The tuples carry
+                              // the LOWER 32 bits; hash_int64(key) = hash_int32(lo ^ hi) (join_kernels.cuh:37-41), so the partitions stay the
+                              // reference's for any common upper half -- not just 0.
 };
+__device__ __forceinline__ uint32_t key_hi_of(const PassCfg& c) { return c.key_hi ? *c.key_hi : 0u; }
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t h, const PassCfg& c) {
     if (c.mode == 0) return (h >> c.shift) & (c.F - 1u);

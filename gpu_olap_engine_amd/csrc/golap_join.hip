@@ -1924,6 +1924,8 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
 // Optimistic narrow pipeline for one side (see ReserveArgs): reserving first pass + no-histogram second pass over
 // (key32, row id) tuples.  Anything that does not fit -- a key outside [0, 2^32), a bucket or slot overflow -- raises
 // *wide and the 64-bit pipeline behind takes over; there is no stand-by path of its own.
+__global__ void k_key_hi(const long long* __restrict__ keys, uint32_t* __restrict__ out) { *out = (uint32_t)((unsigned long long)keys[0] >> 32); }
+
 // A/B hooks for the round-2 narrow kernels (scripts/ab_env.py): GOLAP_P1N = 0 (k_scatter_big) | 24 | 18 | 16, GOLAP_P2R = 0 (k_scatter_wc) | 4 | 2
 static int p1n_variant() { const char* e = knob("GOLAP_P1N"); return e ? atoi(e) : 118; }
 static int p2r_variant() { const char* e = knob("GOLAP_P2R"); return e ? atoi(e) : 104; }
@@ -1975,7 +1977,8 @@ static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint
 }
 
 static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, uint64_t in_keys, uint32_t rid_base, uint64_t n_rows,
-                               uint64_t tmp_rows, uint64_t final_rows_ptr, uint32_t* wide, const uint32_t* zero_word, SideResult& res) {
+                               uint64_t tmp_rows, uint64_t final_rows_ptr, uint32_t* wide, const uint32_t* zero_word, SideResult& res,
+                               const uint32_t* key_hi = nullptr) {
     const PassPlan& p1 = plan.passes[0];
     const PassPlan& p2 = plan.passes[1];
     const uint32_t F1 = p1.cfg.F, G = p2.G, F2 = p2.cfg.F;
@@ -1998,6 +2001,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     {
         PassCfg cfg = p1.cfg;
         cfg.S = nc;
+        cfg.key_hi = key_hi;
         KernelTimer t(ctx, "radix_scatter_p1", st, 16 * n_rows);
         const ReserveArgs rsa{cursor, cap1, wide, wide, nullptr, nsub};
         launch_part1_narrow(st, in_keys, rid_base, nc, c_off, c_len, tmp_rows, cfg, rsa);
@@ -2011,6 +2015,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
         FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, wide, wide};
         PassCfg cfg = p2.cfg;
         cfg.S = 1;
+        cfg.key_hi = key_hi;
         KernelTimer t(ctx, "radix_scatter_p2", st, 16 * n_rows);
         if (p2r_variant() != 0 && F2 <= (uint32_t)P2R_MAX_F)
             launch_part2_ring(st, G, tmp_rows, final_rows_ptr, cfg, fx, SegSrc{nullptr, nullptr, 0});
@@ -2079,9 +2084,17 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     uint32_t* probe_hit = nullptr;
     if (use_narrow_keys(plan, p->n_build, p->n_probe)) {
         // optimistic 32-bit pipeline first (its big buffers alias the 64-bit pipeline's: only one of the two does any work)
-        uint32_t* words = (uint32_t*)ws_take(ctx, 8);   // [0] wide flag, [1] constant 0
+        uint32_t* words = (uint32_t*)ws_take(ctx, 16);   // [0] wide flag, [1] constant 0, [2] the upper key half the attempt stands on
         if (!words) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
-        GOLAP_TRY(zero_async(ctx, st, (void*)words, 8));
+        GOLAP_TRY(zero_async(ctx, st, (void*)words, 16));
+        // Frame of reference: the tuples carry the lower 32 key bits, valid while every key of BOTH sides shares its upper 32 bits
+        // with the first build key (0 for the usual small non-negative ids, 0xFFFFFFFF for small negative ones, anything for keys
+        // offset into a common 4 Gi window).  Only the new tuple kernels know about it (knobs that select the old ones keep 0).
+        const uint32_t* key_hi = nullptr;
+        if (p1n_variant() != 0 && p2r_variant() != 0 && plan.passes[1].cfg.F <= (uint32_t)P2R_MAX_F) {
+            hipLaunchKernelGGL(k_key_hi, dim3(1), dim3(1), 0, st, (const long long*)p->build_key_ptr, words + 2);
+            key_hi = words + 2;
+        }
         if (p->join_type & 2) {
             const uint64_t nw = ceil_div(std::max<uint64_t>(1, std::max(p->n_probe, fp)), 32) + 1;
             probe_hit = (uint32_t*)ws_take(ctx, nw * 4);
@@ -2089,8 +2102,8 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
             GOLAP_TRY(zero_async(ctx, st, (void*)probe_hit, nw * 4));
         }
         SideResult nb_, np_;
-        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->build_key_ptr, p->build_rid_base, p->n_build, bb.tmp_keys[0], bb.final_keys, words, words + 1, nb_));
-        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->probe_key_ptr, p->probe_rid_base, p->n_probe, pb.tmp_keys[0], pb.final_keys, words, words + 1, np_));
+        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->build_key_ptr, p->build_rid_base, p->n_build, bb.tmp_keys[0], bb.final_keys, words, words + 1, nb_, key_hi));
+        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->probe_key_ptr, p->probe_rid_base, p->n_probe, pb.tmp_keys[0], pb.final_keys, words, words + 1, np_, key_hi));
         GOLAP_TRY(launch_lds_join(ctx, st, plan, nb_, np_, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type,
                                   true, nullptr, words, probe_hit));
         gate = words;
@@ -2151,6 +2164,207 @@ static int32_t broadcast_hash_join(golap_ctx* ctx, const golap_join_params* p, h
     return GOLAP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Composite keys and NULLs.  physical_plan.rs:35-36 carries Vec<PhysicalExpr> keys and
+// column_buffer.rs:59-60 a byte-per-row validity; the reference's kernels and executor use neither (one Int64 key,
+// executor.rs:245; nulls -> 0, record_batch_convert.rs:102-110).  Here, without touching the partition / LDS-join kernels:
+//   k_surrogate   one 64-bit SURROGATE key per row: the key itself (one column, row valid), a 64-bit mix of the columns
+//                 (composite key), or -- for a row with a NULL in any key column -- a mix of (side, row index): NULL rows get
+//                 pairwise different keys that are also different per side, so they match nothing, they do not pile up in one
+//                 partition, and an outer join emits them as unmatched rows by itself;
+//   the ordinary join runs on the surrogates (row ids stay positions: nothing is compacted, nothing synchronises);
+//   k_verify      every emitted pair is checked against the REAL columns and validity bytes.  A surrogate is 64 bits: two
+//                 different composite keys (or a NULL row and a real key) collide with probability 2^-64 per candidate pair,
+//                 i.e. ~0.05 expected false pairs in a 1B x 1B join -- rare, not never.  False pairs are recorded (<= 64);
+//   k_repair_scan / k_repair_fix (no-ops unless a false pair was found): the false pair is removed; in an outer join a row
+//                 that thereby lost its only match gets its unmatched pair.  More than 64 false pairs: status GOLAP_ERR_CAPACITY
+//                 is raised through the count word's companion (never seen in practice; the probability is < 1e-60).
+// ---------------------------------------------------------------------------
+struct KeyCols {
+    const long long* col[4];
+    const uint8_t* valid[4];
+    uint32_t n_cols;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// keep_mask: all ones; the test knob GOLAP_GJ_HASH_BITS narrows the surrogates so that false pairs actually occur
+__global__ __launch_bounds__(256) void k_surrogate(KeyCols k, unsigned long long n, unsigned long long side_seed, unsigned long long keep_mask,
+                                                   long long* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        bool null = false;
+        for (uint32_t c = 0; c < k.n_cols; ++c) null = null || (k.valid[c] && !k.valid[c][i]);
+        unsigned long long s;
+        if (null) {
+            s = mix64(side_seed + i * 0x9E3779B97F4A7C15ull);
+        } else if (k.n_cols == 1) {
+            s = (unsigned long long)k.col[0][i];
+        } else {
+            s = 0x243F6A8885A308D3ull;
+            for (uint32_t c = 0; c < k.n_cols; ++c) s = mix64(s ^ (unsigned long long)k.col[c][i]) + 0x9E3779B97F4A7C15ull * (c + 1);
+        }
+        out[i] = (long long)(s & keep_mask);
+    }
+}
+
+constexpr uint32_t GJ_MAX_HOLES = 64;
+struct GjCtl {                 // device control block of one generalised join
+    uint32_t n_holes;          // false pairs found (may exceed GJ_MAX_HOLES: then only the first ones are listed and `overflow` is set)
+    uint32_t overflow;
+    uint32_t hole_pos[GJ_MAX_HOLES];     // position of the false pair in out_pairs
+    uint32_t hole_b[GJ_MAX_HOLES], hole_p[GJ_MAX_HOLES];
+    uint32_t b_has_other[GJ_MAX_HOLES], p_has_other[GJ_MAX_HOLES];   // a surviving pair with the same build / probe row exists
+};
+
+__device__ __forceinline__ bool gj_real_match(const KeyCols& B, const KeyCols& P, uint32_t bi, uint32_t pi) {
+    for (uint32_t c = 0; c < B.n_cols; ++c) {
+        if (B.valid[c] && !B.valid[c][bi]) return false;
+        if (P.valid[c] && !P.valid[c][pi]) return false;
+        if (B.col[c][bi] != P.col[c][pi]) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_gj_verify(const uint2* __restrict__ pairs, const unsigned long long* __restrict__ count, unsigned long long max_pairs,
+                                                   KeyCols B, KeyCols P, uint32_t b_base, uint32_t p_base, GjCtl* __restrict__ ctl) {
+    const unsigned long long n = *count < max_pairs ? *count : max_pairs;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const uint2 pr = pairs[i];
+        if (pr.x == JN_NULL || pr.y == JN_NULL) continue;
+        if (!gj_real_match(B, P, pr.x - b_base, pr.y - p_base)) {
+            const uint32_t h = atomicAdd(&ctl->n_holes, 1u);
+            if (h < GJ_MAX_HOLES) { ctl->hole_pos[h] = (uint32_t)i; ctl->hole_b[h] = pr.x; ctl->hole_p[h] = pr.y; }
+            else ctl->overflow = 1u;
+        }
+    }
+}
+
+// only when false pairs exist: which of their rows still have a true partner among the surviving pairs?
+__global__ __launch_bounds__(256) void k_gj_repair_scan(const uint2* __restrict__ pairs, const unsigned long long* __restrict__ count, unsigned long long max_pairs,
+                                                        KeyCols B, KeyCols P, uint32_t b_base, uint32_t p_base, GjCtl* __restrict__ ctl) {
+    const uint32_t nh = ctl->n_holes < GJ_MAX_HOLES ? ctl->n_holes : GJ_MAX_HOLES;
+    if (nh == 0) return;
+    const unsigned long long n = *count < max_pairs ? *count : max_pairs;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const uint2 pr = pairs[i];
+        if (pr.x == JN_NULL || pr.y == JN_NULL) continue;
+        for (uint32_t h = 0; h < nh; ++h) {
+            if (pr.x != ctl->hole_b[h] && pr.y != ctl->hole_p[h]) continue;
+            if (!gj_real_match(B, P, pr.x - b_base, pr.y - p_base)) continue;   // (another false pair)
+            if (pr.x == ctl->hole_b[h]) ctl->b_has_other[h] = 1u;
+            if (pr.y == ctl->hole_p[h]) ctl->p_has_other[h] = 1u;
+        }
+    }
+}
+
+// one thread: false pairs leave the list; in an outer join a row that lost its only partner gets its unmatched pair
+__global__ void k_gj_repair_fix(uint2* __restrict__ pairs, unsigned long long* __restrict__ count, unsigned long long max_pairs, int join_type,
+                                GjCtl* __restrict__ ctl) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint32_t nh = ctl->n_holes < GJ_MAX_HOLES ? ctl->n_holes : GJ_MAX_HOLES;
+    if (nh == 0) return;
+    unsigned long long cnt = *count;
+    const bool keep_b = (join_type & 1) != 0, keep_p = (join_type & 2) != 0;
+    // replacements first (they reuse the holes' places)
+    uint32_t hole_free[GJ_MAX_HOLES];
+    for (uint32_t h = 0; h < nh; ++h) hole_free[h] = 1u;
+    auto put = [&](uint2 v) {
+        for (uint32_t h = 0; h < nh; ++h)
+            if (hole_free[h]) { pairs[ctl->hole_pos[h]] = v; hole_free[h] = 0u; return; }
+        if (cnt < max_pairs) pairs[cnt] = v;
+        ++cnt;
+    };
+    for (uint32_t h = 0; h < nh; ++h) {
+        bool first_b = true, first_p = true;   // a row may sit in several false pairs: one unmatched pair at most
+        for (uint32_t g = 0; g < h; ++g) {
+            first_b = first_b && ctl->hole_b[g] != ctl->hole_b[h];
+            first_p = first_p && ctl->hole_p[g] != ctl->hole_p[h];
+        }
+        if (keep_b && first_b && !ctl->b_has_other[h]) put(make_uint2(ctl->hole_b[h], JN_NULL));
+        if (keep_p && first_p && !ctl->p_has_other[h]) put(make_uint2(JN_NULL, ctl->hole_p[h]));
+    }
+    // remaining holes: filled from the end of the list (highest hole first, so a moved pair is never itself a hole)
+    for (;;) {
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t h = 0; h < nh; ++h)
+            if (hole_free[h] && (best == 0xFFFFFFFFu || ctl->hole_pos[h] > ctl->hole_pos[best])) best = h;
+        if (best == 0xFFFFFFFFu) break;
+        hole_free[best] = 0u;
+        --cnt;
+        if (cnt < max_pairs && ctl->hole_pos[best] != cnt) pairs[ctl->hole_pos[best]] = pairs[cnt];
+    }
+    *count = cnt;
+}
+
+static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipStream_t st);
+static int32_t broadcast_hash_join(golap_ctx* ctx, const golap_join_params* p, hipStream_t st);
+
+static bool join_is_general(const golap_join_params* p) {
+    if (p->n_key_cols > 1) return true;
+    for (int c = 0; c < 4; ++c)
+        if (p->build_validity[c] || p->probe_validity[c]) return true;
+    return false;
+}
+
+static int32_t general_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_join_params* p, hipStream_t st) {
+    const uint32_t nc = p->n_key_cols ? p->n_key_cols : 1;
+    KeyCols B{}, P{};
+    B.n_cols = P.n_cols = nc;
+    for (uint32_t c = 0; c < nc; ++c) {
+        B.col[c] = (const long long*)(c ? p->build_key_extra[c - 1] : p->build_key_ptr);
+        P.col[c] = (const long long*)(c ? p->probe_key_extra[c - 1] : p->probe_key_ptr);
+        B.valid[c] = (const uint8_t*)p->build_validity[c];
+        P.valid[c] = (const uint8_t*)p->probe_validity[c];
+        if ((p->n_build && !B.col[c]) || (p->n_probe && !P.col[c])) return fail(ctx, GOLAP_ERR_INVALID_ARG, "key column %u is null", c);
+    }
+    const uint64_t nb = p->n_build, np = p->n_probe;
+    GOLAP_TRY(aux_begin(ctx, round_up(std::max<uint64_t>(nb, 1) * 8, 256) + round_up(std::max<uint64_t>(np, 1) * 8, 256) + 8192, st));
+    long long* sb = (long long*)aux_take(ctx, std::max<uint64_t>(nb, 1) * 8);
+    long long* sp = (long long*)aux_take(ctx, std::max<uint64_t>(np, 1) * 8);
+    GjCtl* ctl = (GjCtl*)aux_take(ctx, sizeof(GjCtl));
+    if (!sb || !sp || !ctl) return fail(ctx, GOLAP_ERR_OOM, "join scratch exhausted (surrogate keys)");
+    GOLAP_TRY(zero_async(ctx, st, ctl, sizeof(GjCtl)));
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    auto grid_for = [&](uint64_t n) { return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, ceil_div(std::max<uint64_t>(n, 1), 1024))); };
+    {
+        KernelTimer t(ctx, "join_surrogate_keys", st, (8ull * nc + 8) * (nb + np));
+        unsigned long long keep = ~0ull;
+        if (const char* e = knob("GOLAP_GJ_HASH_BITS")) { const int b = atoi(e); if (b >= 1 && b < 64) keep = (1ull << b) - 1; }   // test knob: provoke false pairs
+        if (nb) hipLaunchKernelGGL(k_surrogate, dim3(grid_for(nb)), dim3(256), 0, st, B, (unsigned long long)nb, 0x6A09E667F3BCC908ull, keep, sb);
+        if (np) hipLaunchKernelGGL(k_surrogate, dim3(grid_for(np)), dim3(256), 0, st, P, (unsigned long long)np, 0xBB67AE8584CAA73Bull, keep, sp);
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    golap_join_params q = *p;
+    q.build_key_ptr = (uint64_t)sb;
+    q.probe_key_ptr = (uint64_t)sp;
+    q.n_key_cols = 1;
+    for (int c = 0; c < 4; ++c) q.build_validity[c] = q.probe_validity[c] = 0;
+    int32_t rc;
+    if (nb == 0 || np == 0) {
+        const bool keep = nb ? (p->join_type & 1) != 0 : (np && (p->join_type & 2) != 0);
+        rc = keep ? broadcast_hash_join(ctx, &q, st) : GOLAP_OK;
+    } else {
+        rc = strategy == GOLAP_JOIN_BROADCAST_HASH ? broadcast_hash_join(ctx, &q, st) : radix_hash_join(ctx, &q, st);
+    }
+    if (rc == GOLAP_OK && nb && np) {
+        KernelTimer t(ctx, "join_verify_pairs", st, 0);
+        const uint32_t g = grid_for(std::min<uint64_t>(p->max_pairs, (uint64_t)cus * 8 * 1024 * 64));
+        hipLaunchKernelGGL(k_gj_verify, dim3(g), dim3(256), 0, st, (const uint2*)p->out_pairs_ptr, (const unsigned long long*)p->out_count_ptr,
+                           (unsigned long long)p->max_pairs, B, P, p->build_rid_base, p->probe_rid_base, ctl);
+        hipLaunchKernelGGL(k_gj_repair_scan, dim3(g), dim3(256), 0, st, (const uint2*)p->out_pairs_ptr, (const unsigned long long*)p->out_count_ptr,
+                           (unsigned long long)p->max_pairs, B, P, p->build_rid_base, p->probe_rid_base, ctl);
+        hipLaunchKernelGGL(k_gj_repair_fix, dim3(1), dim3(64), 0, st, (uint2*)p->out_pairs_ptr, (unsigned long long*)p->out_count_ptr,
+                           (unsigned long long)p->max_pairs, p->join_type, ctl);
+        GOLAP_HIP_TRY(ctx, hipGetLastError());
+    }
+    aux_end(ctx, st);
+    return rc;
+}
+
 }  // namespace golap
 
 using namespace golap;
@@ -2172,6 +2386,8 @@ int32_t golap_join(golap_ctx* ctx, golap_join_strategy strategy, const golap_joi
     hipStream_t st = pick_stream(ctx, stream);
     GOLAP_TRY(zero_async(ctx, st, (void*)((void*)p->out_count_ptr), 8));
     if (p->join_type < 0 || p->join_type > 3) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad join_type %d", p->join_type);
+    if (p->n_key_cols > 4) return fail(ctx, GOLAP_ERR_INVALID_ARG, "at most 4 key columns");
+    if (join_is_general(p)) return general_join(ctx, strategy, p, st);
     if (p->n_build == 0 || p->n_probe == 0) {
         // executor.rs:231-233: nothing to join.  An outer join still keeps the non-empty preserved side.
         const bool keep = p->n_build ? (p->join_type & 1) != 0 : (p->n_probe && (p->join_type & 2) != 0);

@@ -57,10 +57,11 @@ __global__ __launch_bounds__(OP_THREADS) void k_filter_mask4(const longlong2* __
     }
 }
 
+// valid (may be null): byte per row, 0 = NULL (column_buffer.rs:59-60).  A comparison with NULL is not true: the row does not pass.
 __global__ __launch_bounds__(OP_THREADS) void k_filter_mask1(const long long* __restrict__ col, unsigned long long first, unsigned long long n, int op,
-                                                             long long lit, uint8_t* __restrict__ mask) {
+                                                             long long lit, uint8_t* __restrict__ mask, const uint8_t* __restrict__ valid = nullptr) {
     for (unsigned long long i = first + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
-        mask[i] = cmp_i64(op, col[i], lit) ? 1 : 0;
+        mask[i] = (cmp_i64(op, col[i], lit) && (!valid || valid[i])) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -74,7 +75,8 @@ constexpr int FC_RPT = FC_ROWS / OP_THREADS;   // 16 rows per thread, interleave
 // `bits` (may be null): the pass/fail ballot of every 64-row strip, [block][wave][strip] -- 1 bit per row, so that the
 // write pass reads n/8 bytes instead of the 8n-byte column again (1B rows: 4.03 -> see DESIGN.md 5).
 __global__ __launch_bounds__(OP_THREADS) void k_filter_count(const long long* __restrict__ col, unsigned long long n, int op, long long lit,
-                                                             uint32_t* __restrict__ counts, unsigned long long* __restrict__ bits) {
+                                                             uint32_t* __restrict__ counts, unsigned long long* __restrict__ bits,
+                                                             const uint8_t* __restrict__ valid = nullptr) {
     __shared__ uint32_t s_w[OP_WAVES];
     const unsigned long long base = (unsigned long long)blockIdx.x * FC_ROWS;
     uint32_t c = 0;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_filter_count(const long long* __
 #pragma unroll
     for (int r = 0; r < FC_RPT; ++r) {
         const unsigned long long i = base + r * OP_THREADS + threadIdx.x;
-        const bool keep = i < n && cmp_i64(op, v[r], lit);
+        const bool keep = i < n && cmp_i64(op, v[r], lit) && (!valid || valid[i < n ? i : n - 1]);
         c += keep ? 1u : 0u;
         const unsigned long long m = __ballot(keep);
         if ((threadIdx.x & 63) == (uint32_t)r) mine = m;
@@ -171,9 +173,12 @@ __device__ __forceinline__ void block_reduce_acc(Acc4& a, double* s /*[4*OP_WAVE
 
 #define GOLAP_F64_MAX 1.7976931348623157e308
 
+// key_valid / val_valid (may be null): byte per row, 0 = NULL.  A row whose predicate column is NULL does not pass; a NULL value
+// does not take part in SUM / COUNT / MIN / MAX / AVG (SQL aggregates skip NULLs).
 template <bool VAL_F64, bool HAS_PRED>
 __global__ __launch_bounds__(OP_THREADS) void k_reduce_partials(const long long* __restrict__ key, const void* __restrict__ val, unsigned long long n, int op,
-                                                                long long lit, double* __restrict__ partials) {
+                                                                long long lit, double* __restrict__ partials,
+                                                                const uint8_t* __restrict__ key_valid = nullptr, const uint8_t* __restrict__ val_valid = nullptr) {
     __shared__ double s[4 * OP_WAVES];
     Acc4 a{0.0, 0.0, GOLAP_F64_MAX, -GOLAP_F64_MAX};   // executor.rs:308-311 seeds
     const long long* vi = (const long long*)val;
@@ -192,8 +197,11 @@ __global__ __launch_bounds__(OP_THREADS) void k_reduce_partials(const long long*
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            bool keep = i0 + u * stride < n;
+            const unsigned long long i = i0 + u * stride;
+            bool keep = i < n;
             if (HAS_PRED) keep = keep && cmp_i64(op, k[u], lit);
+            if (keep && key_valid) keep = key_valid[i] != 0;
+            if (keep && val_valid) keep = val_valid[i] != 0;
             if (keep) {
                 a.sum += x[u]; a.cnt += 1.0;                       // :317-318
                 a.mn = x[u] < a.mn ? x[u] : a.mn;                  // :319-321
@@ -734,7 +742,11 @@ int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, 
     KernelTimer t(ctx, "filter_mask", st, 9 * p->n_rows);
     const bool aligned = (p->column_ptr % 16 == 0) && (p->out_mask_ptr % 4 == 0);
     uint64_t done = 0;
-    if (aligned && p->n_rows >= 4) {
+    if (p->validity_ptr) {   // NULL-aware form: one row per lane
+        hipLaunchKernelGGL(k_filter_mask1, dim3(stream_grid(ctx, p->n_rows, OP_THREADS)), dim3(OP_THREADS), 0, st, (const long long*)p->column_ptr,
+                           0ull, (unsigned long long)p->n_rows, pred->op, (long long)pred->literal, (uint8_t*)p->out_mask_ptr, (const uint8_t*)p->validity_ptr);
+        done = p->n_rows;
+    } else if (aligned && p->n_rows >= 4) {
         const uint64_t n4 = p->n_rows / 4;
         hipLaunchKernelGGL(k_filter_mask4, dim3(stream_grid(ctx, n4, OP_THREADS)), dim3(OP_THREADS), 0, st, (const longlong2*)p->column_ptr,
                            (unsigned long long)n4, pred->op, (long long)pred->literal, (uint32_t*)p->out_mask_ptr);
@@ -749,6 +761,11 @@ int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, 
 
 int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t n_rows, uint64_t out_indices_ptr,
                              uint64_t out_count_ptr, void* stream) {
+    return golap_filter_compact_nullable(ctx, pred, column_ptr, 0, n_rows, out_indices_ptr, out_count_ptr, stream);
+}
+
+int32_t golap_filter_compact_nullable(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t validity_ptr, uint64_t n_rows,
+                                      uint64_t out_indices_ptr, uint64_t out_count_ptr, void* stream) {
     if (!ctx || !pred) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (!out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
     if (n_rows && (!column_ptr || !out_indices_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column/indices pointer");
@@ -770,7 +787,7 @@ int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred,
     {
         KernelTimer t(ctx, "filter_count", st, 8 * n_rows);
         hipLaunchKernelGGL(k_filter_count, dim3(n_blocks), dim3(OP_THREADS), 0, st, (const long long*)column_ptr, (unsigned long long)n_rows, pred->op,
-                           (long long)pred->literal, counts, bits);
+                           (long long)pred->literal, counts, bits, (const uint8_t*)validity_ptr);
     }
     GOLAP_TRY(flat_scan(ctx, st, counts, n_blocks + 1, bsums));
     {
@@ -802,6 +819,12 @@ int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_p
 
 int32_t golap_filter_sum(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t key_column_ptr, uint64_t value_column_ptr, int32_t value_is_f64,
                          uint64_t n_rows, uint64_t out_ptr, void* stream) {
+    return golap_filter_sum_nullable(ctx, pred, key_column_ptr, 0, value_column_ptr, 0, value_is_f64, n_rows, out_ptr, stream);
+}
+
+int32_t golap_filter_sum_nullable(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t key_column_ptr, uint64_t key_validity_ptr,
+                                  uint64_t value_column_ptr, uint64_t value_validity_ptr, int32_t value_is_f64, uint64_t n_rows, uint64_t out_ptr,
+                                  void* stream) {
     if (!ctx || !pred || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (n_rows && (!key_column_ptr || !value_column_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
     if (pred->op < 0 || pred->op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", pred->op);
@@ -818,10 +841,12 @@ int32_t golap_filter_sum(golap_ctx* ctx, const golap_filter_predicate* pred, uin
         KernelTimer t(ctx, "filter_sum", st, 16 * n_rows);
         if (value_is_f64)
             hipLaunchKernelGGL((k_reduce_partials<true, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)key_column_ptr,
-                               (const void*)value_column_ptr, (unsigned long long)n_rows, pred->op, (long long)pred->literal, partials);
+                               (const void*)value_column_ptr, (unsigned long long)n_rows, pred->op, (long long)pred->literal, partials,
+                               (const uint8_t*)key_validity_ptr, (const uint8_t*)value_validity_ptr);
         else
             hipLaunchKernelGGL((k_reduce_partials<false, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)key_column_ptr,
-                               (const void*)value_column_ptr, (unsigned long long)n_rows, pred->op, (long long)pred->literal, partials);
+                               (const void*)value_column_ptr, (unsigned long long)n_rows, pred->op, (long long)pred->literal, partials,
+                               (const uint8_t*)key_validity_ptr, (const uint8_t*)value_validity_ptr);
         hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, grid, out4);
     }
     GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)out_ptr, out4, 16, hipMemcpyDeviceToDevice, st));   // sum, kept-count

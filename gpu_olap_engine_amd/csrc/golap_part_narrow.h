@@ -40,6 +40,48 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ld16_hidden(u32x4& v, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void ld8_hidden(u32x2& v, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
+// Hidden loads of the ring pass go into FIXED registers v[104:119] that hipcc never allocates: k_part2_ring caps the compiler's
+// budget at 96 VGPRs (amdgpu_waves_per_eu(5); the kernel still gets what the asm statements name, occupancy is set by its LDS
+// anyway), the load names its destination in the asm text, and ld8_take copies the pair out AFTER the counted wait.  No
+// compiler-visible value ever lives in a register with a load in flight, so no copy, phi or reuse of such a register can exist
+// (the first form of that kernel returned the data as asm outputs: at a loop back edge hipcc copied the "loaded" pair to
+// another register right behind the load, and reused the original one as a store address -- a memory fault on the GPU).
+template <int SLOT> __device__ __forceinline__ void ld8_fixed(const void* p);
+template <int SLOT> __device__ __forceinline__ u32x2 ld8_take();
+#define GOLAP_FIXED_PAIR(SLOT, LO, HI)                                                                                            \
+    template <> __device__ __forceinline__ void ld8_fixed<SLOT>(const void* p) {                                                   \
+        asm volatile("global_load_dwordx2 v[" #LO ":" #HI "], %0, off" ::"v"(p) : "memory", "v" #LO, "v" #HI);                   \
+    }                                                                                                                              \
+    template <> __device__ __forceinline__ u32x2 ld8_take<SLOT>() {                                                               \
+        uint32_t x, y;                                                                                                             \
+        asm volatile("v_mov_b32 %0, v" #LO "\n\tv_mov_b32 %1, v" #HI : "=v"(x), "=v"(y)::"memory");                              \
+        return u32x2{x, y};                                                                                                        \
+    }
+GOLAP_FIXED_PAIR(0, 104, 105)
+GOLAP_FIXED_PAIR(1, 106, 107)
+GOLAP_FIXED_PAIR(2, 108, 109)
+GOLAP_FIXED_PAIR(3, 110, 111)
+GOLAP_FIXED_PAIR(4, 112, 113)
+GOLAP_FIXED_PAIR(5, 114, 115)
+GOLAP_FIXED_PAIR(6, 116, 117)
+GOLAP_FIXED_PAIR(7, 118, 119)
+#undef GOLAP_FIXED_PAIR
+constexpr int P2R_FIXED_FIRST = 104, P2R_FIXED_PAIRS = 8;   // (tests/test_isa_audit.py reads these)
+template <int SET, int RPT, int R = 0>
+__device__ __forceinline__ void ld8_fixed_tile(const uint2* src, uint32_t tid, uint32_t tn, uint32_t nt) {
+    if constexpr (R < RPT) {
+        const uint32_t i = (uint32_t)R * nt + tid;
+        ld8_fixed<SET * RPT + R>(src + (i < tn ? i : tn - 1));
+        ld8_fixed_tile<SET, RPT, R + 1>(src, tid, tn, nt);
+    }
+}
+template <int SET, int RPT, int R = 0>
+__device__ __forceinline__ void ld8_take_tile(u32x2 (&t)[RPT]) {
+    if constexpr (R < RPT) {
+        t[R] = ld8_take<SET * RPT + R>();
+        ld8_take_tile<SET, RPT, R + 1>(t);
+    }
+}
 // 8-byte store of the lanes with ok != 0; the instruction itself is always issued (one vmcnt event per call)
 __device__ __forceinline__ void st8_hidden_if(void* p, u32x2 v, uint32_t ok) {
     unsigned long long saved;
@@ -96,6 +138,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t F = cfg.F;   // <= NT: one bucket per thread in the scan
     if (tid < F) s_cnt[tid] = 0;
+    const uint32_t khi = __builtin_amdgcn_readfirstlane(key_hi_of(cfg));   // the upper key half this attempt stands on (see PassCfg::key_hi)
 
     // keys of the tile: kv[h] = (lo, hi) of key 2h, (lo, hi) of key 2h + 1
     u32x4 kv[(RPT + 1) / 2];
@@ -160,10 +203,10 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             k32[r] = (r & 1) ? kv[r >> 1].z : kv[r >> 1].x;
-            hi |= (r & 1) ? kv[r >> 1].w : kv[r >> 1].y;   // clamped duplicates are real keys too
+            hi |= ((r & 1) ? kv[r >> 1].w : kv[r >> 1].y) ^ khi;   // clamped duplicates are real keys too
             br[r] = 0xFFFFFFFFu;
             if (tile_pos(r) < tn) {
-                const uint32_t b = bucket_of(hash_int32((int32_t)k32[r]), cfg);   // == hash_int64 of the zero-extended key
+                const uint32_t b = bucket_of(hash_int32((int32_t)(k32[r] ^ khi)), cfg);   // == hash_int64 of the whole key
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);                    // b < 1024, rank < 32768
             }
         }
@@ -267,11 +310,12 @@ struct SegSrc {
 constexpr int P2R_MAX_SRC = 64;
 
 template <int RPT, int R, bool ASM, int DIAG = 0>   // DIAG 2: timing-only build without the flush stores (wrong results; scripts/ab_p12.py)
-__global__ __launch_bounds__(P2R_THREADS) void k_part2_ring(const uint2* __restrict__ in_rows, uint2* __restrict__ out_rows, PassCfg cfg, FixedArgs fx,
+__global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_part2_ring(const uint2* __restrict__ in_rows, uint2* __restrict__ out_rows, PassCfg cfg, FixedArgs fx,
                                                             SegSrc seg) {
     constexpr int NT = P2R_THREADS, TILE = NT * RPT, LINE = P2R_LINE;
     constexpr int FLUSH_ITERS = P2R_MAX_F / (NT / LINE);   // buckets per 16-lane group (ASM: always this many store instructions per flush)
-    static_assert(RPT % 2 == 0 && (R & (R - 1)) == 0 && R >= 2 * LINE, "ring geometry");
+    static_assert((R & (R - 1)) == 0 && R >= 2 * LINE, "ring geometry");
+    static_assert(!ASM || 2 * RPT <= P2R_FIXED_PAIRS, "two tiles of hidden loads in the fixed registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t F = cfg.F;
     uint2* s_ring = reinterpret_cast<uint2*>(s_raw);                          // [F][R]
@@ -304,6 +348,7 @@ __global__ __launch_bounds__(P2R_THREADS) void k_part2_ring(const uint2* __restr
     // them sits in front of the tile loop; left to their first use inside the loop it becomes a vmcnt(0) per tile, which would
     // also drain the hidden prefetch)
     const uint32_t slot0 = __builtin_amdgcn_readfirstlane(fx.slot_base[g]), cap = __builtin_amdgcn_readfirstlane(fx.slot_cap[g]);
+    const uint32_t khi = __builtin_amdgcn_readfirstlane(key_hi_of(cfg));
     if (n_tiles == 0) {
         if (tid < F) { fx.sub_start[(size_t)g * F + tid] = slot0 + tid * cap; fx.sub_len[(size_t)g * F + tid] = 0; }
         return;
@@ -326,35 +371,22 @@ __global__ __launch_bounds__(P2R_THREADS) void k_part2_ring(const uint2* __restr
         tn = c.len - t0 < (uint32_t)TILE ? c.len - t0 : (uint32_t)TILE;
     };
     PieceCursor cur_load = cursor_init(), cur_proc = cursor_init();
-    // rows 2q, 2q+1 of a tile travel in one 16-byte load of thread q % NT
-    // A tile arrives as RPT/2 16-byte words (v) or, when it is the short last tile of a piece (or starts on an odd row), as RPT
-    // 8-byte words (t, `split`): both hidden, both waited for by the same counted wait -- a piece boundary does not drain the pipeline.
-    auto load_tile = [&](u32x4 (&v)[RPT / 2], u32x2 (&t)[RPT], bool& split, uint32_t k) {
-        split = false;
-        if (k >= n_tiles) return;
+    // Row r * NT + tid of a tile travels in 8-byte load r of thread tid.  Always RPT load instructions, indices clamped into the
+    // tile: short tiles (the last one of a piece) need no other code, and for a tile beyond the group's last one every lane
+    // re-reads one row (a single line per instruction) -- the number of memory operations between a tile's loads and its
+    // counted wait never depends on the data.
+    auto load_tile = [&](auto set, u32x2 (&t)[RPT], uint32_t k) {
         uint32_t row0, tn;
-        locate(cur_load, k, row0, tn);
+        locate(cur_load, k < n_tiles ? k : n_tiles - 1, row0, tn);
+        if (k >= n_tiles) tn = 1;
         const uint2* __restrict__ src = in_rows + row0;
-        if (tn == (uint32_t)TILE && (row0 & 1u) == 0) {   // work-group-uniform
-#pragma unroll
-            for (int h = 0; h < RPT / 2; ++h) {
-                const uint2* p = src + 2u * ((uint32_t)h * NT + tid);
-                if (ASM) ld16_hidden(v[h], p);
-                else v[h] = *reinterpret_cast<const u32x4*>(p);
-            }
-        } else if (ASM) {   // (a load hipcc tracks would make it wait vmcnt(0) at every use of these registers, on the fast path too)
-            split = true;
+        if constexpr (ASM) ld8_fixed_tile<decltype(set)::value, RPT>(src, tid, tn, (uint32_t)NT);
+        else {
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                const uint32_t i = 2u * ((uint32_t)(r >> 1) * NT + tid) + (uint32_t)(r & 1);
-                ld8_hidden(t[r], src + (i < tn ? i : tn - 1));
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < RPT / 2; ++h) {
-                const uint32_t i = 2u * ((uint32_t)h * NT + tid);
-                const uint2 a = src[i < tn ? i : tn - 1], b = src[i + 1 < tn ? i + 1 : tn - 1];
-                v[h] = u32x4{a.x, a.y, b.x, b.y};
+                const uint32_t i = (uint32_t)r * NT + tid;
+                const uint2 a = src[i < tn ? i : tn - 1];
+                t[r] = u32x2{a.x, a.y};
             }
         }
     };
@@ -403,30 +435,26 @@ __global__ __launch_bounds__(P2R_THREADS) void k_part2_ring(const uint2* __restr
         return false;
     };
     uint32_t tile_no = 0;
-    auto process = [&](u32x4 (&v)[RPT / 2], u32x2 (&t)[RPT], bool& split, uint32_t k) {
+    auto process = [&](auto set, u32x2 (&t)[RPT], uint32_t k) {   // k may be n_tiles (odd tile counts): a tile without rows
         uint32_t row0_unused, tn;
-        locate(cur_proc, k, row0_unused, tn);
-        if (ASM) {
-            // this tile's rows were requested two tiles ago, before two flushes of FLUSH_ITERS stores each (whatever was
-            // loaded in between only adds to the younger operations); the first two tiles follow the prologue's full wait
+        locate(cur_proc, k < n_tiles ? k : n_tiles - 1, row0_unused, tn);
+        if (k >= n_tiles) tn = 0;
+        if constexpr (ASM) {
+            // this tile's rows were requested two tiles ago, before two flushes of FLUSH_ITERS stores each (the RPT loads of the
+            // tile in between only add to the younger operations); the first two tiles follow the prologue's full wait
             if (tile_no >= 2) wait_vmcnt<2 * FLUSH_ITERS>(); else wait_vmcnt<0>();
-#pragma unroll
-            for (int h = 0; h < RPT / 2; ++h) pin(v[h]);
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) pin(t[r]);
+            ld8_take_tile<decltype(set)::value, RPT>(t);
         }
         ++tile_no;
-        const bool was_split = split;
         uint32_t key[RPT], rid[RPT], bk[RPT], pos[RPT];
         uint32_t pend = 0;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            key[r] = was_split ? t[r].x : ((r & 1) ? v[r >> 1].z : v[r >> 1].x);
-            rid[r] = was_split ? t[r].y : ((r & 1) ? v[r >> 1].w : v[r >> 1].y);
-            const uint32_t i = 2u * ((uint32_t)(r >> 1) * NT + tid) + (uint32_t)(r & 1);
+            key[r] = t[r].x;
+            rid[r] = t[r].y;
             bk[r] = 0xFFFFFFFFu;
-            if (i < tn) {
-                bk[r] = bucket_of(hash_int32((int32_t)key[r]), cfg);
+            if ((uint32_t)r * NT + tid < tn) {
+                bk[r] = bucket_of(hash_int32((int32_t)(key[r] ^ khi)), cfg);
                 pos[r] = atomicAdd(&s_wr[bk[r]], 1u);
             }
         }
@@ -434,11 +462,9 @@ __global__ __launch_bounds__(P2R_THREADS) void k_part2_ring(const uint2* __restr
         for (int r = 0; r < RPT; ++r)
             if (bk[r] != 0xFFFFFFFFu && place(key[r], rid[r], bk[r], pos[r])) pend |= 1u << r;
         if (__ballot(pend != 0) != 0ull && lane == 0) s_flag[it & 1] = 1;
-        bool first = true;
+        lds_barrier();                       // ring rows + pending flag visible
+        load_tile(set, t, k + 2);            // this tile's registers are free: the tile after next streams in behind two flushes
         for (;;) {
-            lds_barrier();                       // ring rows + pending flag visible
-            if (first) load_tile(v, t, split, k + 2);   // this tile's registers are free: the tile after next streams in behind two flushes
-            first = false;
             flush(false);
             const bool more = s_flag[it & 1] != 0;
             if (tid == 0) s_flag[(it + 1) & 1] = 0;
@@ -450,20 +476,19 @@ __global__ __launch_bounds__(P2R_THREADS) void k_part2_ring(const uint2* __restr
                 if ((pend >> r) & 1u)
                     if (!place(key[r], rid[r], bk[r], pos[r])) pend &= ~(1u << r);
             if (__ballot(pend != 0) != 0ull && lane == 0) s_flag[it & 1] = 1;
+            lds_barrier();                       // ring rows + pending flag visible
         }
     };
-    u32x4 va[RPT / 2], vb[RPT / 2];
     u32x2 ta[RPT], tb[RPT];
-    bool split_a = false, split_b = false;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) { ta[r] = u32x2{0u, 0u}; tb[r] = u32x2{0u, 0u}; }
-#pragma unroll
-    for (int h = 0; h < RPT / 2; ++h) { va[h] = u32x4{0u, 0u, 0u, 0u}; vb[h] = u32x4{0u, 0u, 0u, 0u}; }
-    load_tile(va, ta, split_a, 0);
-    load_tile(vb, tb, split_b, 1);
+    constexpr std::integral_constant<int, 0> set_a{};
+    constexpr std::integral_constant<int, 1> set_b{};
+    load_tile(set_a, ta, 0);
+    load_tile(set_b, tb, 1);
     for (uint32_t k = 0; k < n_tiles; k += 2) {
-        process(va, ta, split_a, k);
-        if (k + 1 < n_tiles) process(vb, tb, split_b, k + 1);
+        process(set_a, ta, k);
+        process(set_b, tb, k + 1);
     }
     if (ASM) wait_vmcnt<0>();
     flush(true);   // (the barrier at the end of the last process() ordered every ring write before this)

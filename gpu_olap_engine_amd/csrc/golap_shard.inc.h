@@ -150,6 +150,7 @@ static void rows_per_rank(uint64_t n_total, uint32_t world, const uint64_t* give
 struct ShardPlan {
     bool eligible = false;
     uint32_t world = 1, e1 = 0, F1 = 256, per = 256, local_bits = 0, F2 = 1;
+    uint32_t nsub = 1;                         // sub-ranges per bucket of the exchange-time partition (ReserveArgs::nsub): a bucket is nsub * cap rows
     std::vector<uint64_t> rows[2], cap[2];     // [side][rank]
     JoinPlan local;                            // the one local pass
 };
@@ -179,9 +180,14 @@ static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_p
     make_local_plan(&pl, sp.local);
     sp.local_bits = sp.local.total_bits - pl.pre_bits;
     sp.F2 = sp.local.passes.empty() ? 1 : sp.local.passes[0].cfg.F;
+    sp.nsub = std::max<uint32_t>(1, std::min<uint32_t>(narrow_nsub(), (uint32_t)P2R_MAX_SRC / world));   // world * nsub pieces per group in the ring pass
     for (int side = 0; side < 2; ++side) {
         sp.cap[side].resize(world);
-        for (uint32_t r = 0; r < world; ++r) sp.cap[side][r] = reserve_cap(sp.rows[side][r], sp.F1);
+        for (uint32_t r = 0; r < world; ++r) {
+            uint32_t chunk_rows = 0;
+            const uint32_t chunks = first_pass_chunks(sp.rows[side][r], &chunk_rows, part1_narrow_tile());
+            sp.cap[side][r] = reserve_cap_sub(sp.rows[side][r], sp.F1, sp.nsub, chunks, chunk_rows);
+        }
     }
     // the fast path is the two-pass tuple pipeline: one local pass with a ring-sized fan-out, every rank's first pass large
     // enough for the big-tile kernel, positions within u32
@@ -191,7 +197,7 @@ static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_p
             uint32_t chunk_rows = 0;
             const uint32_t chunks = first_pass_chunks(sp.rows[side][r], &chunk_rows, part1_narrow_tile());
             if (chunks < 224 || sp.rows[side][r] / chunks < 4 * 24576) ok = false;
-            if (sp.cap[side][r] * sp.F1 >= 0xFFFFFFF0ull) ok = false;
+            if (sp.cap[side][r] * sp.F1 * sp.nsub >= 0xFFFFFFF0ull) ok = false;
         }
     const char* env = knob("GOLAP_SHARD_FAST");   // test hook: "1" drops the size condition, "0" disables the fast path
     if (env && !strcmp(env, "1"))
@@ -213,7 +219,7 @@ struct ShardSrcTable {
 //   hdr[r * hdr_stride + b] = rows source r put into bucket b (b owner-major: my buckets are [me * per, (me + 1) * per)),
 //   hdr[r * hdr_stride + F1] = source r's "narrow attempt failed" word.
 __global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restrict__ hdr, uint32_t hdr_stride, uint32_t F1, uint32_t world, uint32_t me,
-                                                        uint32_t per, ShardSrcTable src, uint32_t F2, uint32_t sigmas, uint32_t pad,
+                                                        uint32_t per, uint32_t nsub, ShardSrcTable src, uint32_t F2, uint32_t sigmas, uint32_t pad,
                                                         uint32_t* __restrict__ seg_off, uint32_t* __restrict__ seg_len, uint32_t* __restrict__ slot_base,
                                                         uint32_t* __restrict__ slot_cap, uint32_t* __restrict__ status) {
     __shared__ uint32_t s_w[16];
@@ -221,19 +227,20 @@ __global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restr
     uint32_t total = 0;
     if (g < per) {
         uint32_t n_g = 0;
-        for (uint32_t r = 0; r < world; ++r) {
-            const uint32_t c = hdr[(size_t)r * hdr_stride + me * per + g];
-            const uint32_t len = c < src.cap[r] ? c : src.cap[r];   // (an overflowing bucket raised source r's word; the result is discarded)
-            seg_off[g * world + r] = src.base[r] + g * src.cap[r];
-            seg_len[g * world + r] = len;
-            n_g += len;
-        }
+        for (uint32_t r = 0; r < world; ++r)
+            for (uint32_t s = 0; s < nsub; ++s) {
+                const uint32_t c = hdr[(size_t)r * hdr_stride + (me * per + g) * nsub + s];
+                const uint32_t len = c < src.cap[r] ? c : src.cap[r];   // (an overflowing range raised source r's word; the result is discarded)
+                seg_off[(g * world + r) * nsub + s] = src.base[r] + (g * nsub + s) * src.cap[r];
+                seg_len[(g * world + r) * nsub + s] = len;
+                n_g += len;
+            }
         const uint32_t avg = (n_g + F2 - 1) / F2;
         const uint32_t cap = (avg + sigmas * isqrt_u32(avg) + pad + 15u) & ~15u;
         slot_cap[g] = cap;
         total = cap * F2;
     }
-    if (g < world && hdr[(size_t)g * hdr_stride + F1]) atomicOr(status, 1u);   // some rank met a wide key / an overflowing bucket
+    if (g < world && hdr[(size_t)g * hdr_stride + F1 * nsub]) atomicOr(status, 1u);   // some rank met a wide key / an overflowing bucket
     const uint32_t inc = wave_inclusive_scan(total);
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
@@ -268,7 +275,7 @@ static int32_t ensure_host_words(golap_comm* cm, uint64_t bytes) {
 // fast path
 // ---------------------------------------------------------------------------
 static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, bool* failed) {
-    const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2;
+    const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2, nsub = sp.nsub;
     const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : (1ull << 30);
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
     const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
@@ -279,13 +286,13 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     // ---- workspace: per side [send: F1 x cap_me | recv: per x cap_r for r != me | final (slot-provisioned)] + small arrays ----
     uint64_t send_rows[2], recv_rows[2], final_rows_[2], recv_off_rows[2][P2R_MAX_SRC];
     for (int side = 0; side < 2; ++side) {
-        send_rows[side] = (uint64_t)F1 * sp.cap[side][me];
+        send_rows[side] = (uint64_t)F1 * nsub * sp.cap[side][me];
         uint64_t ro = send_rows[side], n_g_max = 0;
         for (uint32_t r = 0; r < P; ++r) {
-            n_g_max += sp.cap[side][r];
-            if (r == me) { recv_off_rows[side][r] = (uint64_t)me * per * sp.cap[side][me]; continue; }   // own buckets are read in place
+            n_g_max += (uint64_t)nsub * sp.cap[side][r];
+            if (r == me) { recv_off_rows[side][r] = (uint64_t)me * per * nsub * sp.cap[side][me]; continue; }   // own buckets are read in place
             recv_off_rows[side][r] = ro;
-            ro += (uint64_t)per * sp.cap[side][r];
+            ro += (uint64_t)per * nsub * sp.cap[side][r];
         }
         recv_rows[side] = ro - send_rows[side];
         const uint64_t avg = ceil_div(n_g_max, F2);
@@ -293,10 +300,10 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         if (send_rows[side] + recv_rows[side] >= 0xFFFFFFF0ull || final_rows_[side] >= 0xFFFFFFF0ull)
             return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: positions exceed u32");
     }
-    const uint32_t hdr_stride = F1 + 4;
+    const uint32_t hdr_stride = F1 * nsub + 4;
     uint64_t small = 0;
     small += 2 * (round_up((uint64_t)hdr_stride * 4, 256) + round_up((uint64_t)P * hdr_stride * 4, 256));          // cursors + gathered
-    small += 2 * (2 * round_up((uint64_t)per * P * 4, 256) + 2 * round_up((uint64_t)(per + 1) * 4, 256) + 2 * round_up((uint64_t)per * F2 * 4, 256));
+    small += 2 * (2 * round_up((uint64_t)per * P * nsub * 4, 256) + 2 * round_up((uint64_t)(per + 1) * 4, 256) + 2 * round_up((uint64_t)per * F2 * 4, 256));
     small += 2 * 2 * round_up(2048 * 4, 256) + 4096 + round_up((uint64_t)P * 4, 256);
     uint64_t need = small + (1 << 20);
     for (int side = 0; side < 2; ++side) need += round_up((send_rows[side] + recv_rows[side]) * 8, 256) + round_up(final_rows_[side] * 8, 256);
@@ -342,7 +349,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         {
             KernelTimer t(ctx, side ? "partition_scatter_probe" : "partition_scatter_build", st, 16 * n_local[side]);
             launch_part1_narrow(st, keys_in[side], rid_base[side], nc, c_off, c_len, tuples[side], cfg,
-                                ReserveArgs{hdr[side], (uint32_t)sp.cap[side][me], hdr[side] + F1, hdr[side] + F1, nullptr});
+                                ReserveArgs{hdr[side], (uint32_t)sp.cap[side][me], hdr[side] + F1 * nsub, hdr[side] + F1 * nsub, nullptr, nsub});
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
         GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side], st));
@@ -351,20 +358,20 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         std::vector<golap_p2p_op> ops;
         for (uint32_t r = 0; r < P; ++r) {
             if (r == me) continue;
-            const uint64_t sbytes = (uint64_t)per * sp.cap[side][me] * 8, rbytes = (uint64_t)per * sp.cap[side][r] * 8;
-            split_message((int32_t)r, true, tuples[side] + (uint64_t)r * per * sp.cap[side][me] * 8, sbytes, max_msg, ops);
+            const uint64_t sbytes = (uint64_t)per * nsub * sp.cap[side][me] * 8, rbytes = (uint64_t)per * nsub * sp.cap[side][r] * 8;
+            split_message((int32_t)r, true, tuples[side] + (uint64_t)r * per * nsub * sp.cap[side][me] * 8, sbytes, max_msg, ops);
             split_message((int32_t)r, false, tuples[side] + recv_off_rows[side][r] * 8, rbytes, max_msg, ops);
             cm->info.bytes_sent[side] += sbytes;
         }
         GOLAP_TRY(comm_exchange(cm, ops, cm->stream));
         GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[side], cm->stream));
-        cm->info.rows_received[side] = recv_rows[side] + (uint64_t)per * sp.cap[side][me];
+        cm->info.rows_received[side] = recv_rows[side] + (uint64_t)per * nsub * sp.cap[side][me];
     }
     // ---- ring pass per side, as soon as that side's rows are in ----
     for (int side = 0; side < 2; ++side) {
         GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_xchg[side], 0));
-        uint32_t* seg_off = (uint32_t*)ws_take(ctx, (uint64_t)per * P * 4);
-        uint32_t* seg_len = (uint32_t*)ws_take(ctx, (uint64_t)per * P * 4);
+        uint32_t* seg_off = (uint32_t*)ws_take(ctx, (uint64_t)per * P * nsub * 4);
+        uint32_t* seg_len = (uint32_t*)ws_take(ctx, (uint64_t)per * P * nsub * 4);
         uint32_t* slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(per + 1) * 4);
         uint32_t* slot_cap = (uint32_t*)ws_take(ctx, (uint64_t)per * 4);
         uint32_t* sub_start = (uint32_t*)ws_take(ctx, (uint64_t)per * F2 * 4);
@@ -378,14 +385,14 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         }
         uint32_t sigmas, pad;
         provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
-        hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)hdr_all[side], hdr_stride, F1, P, me, per, tab, F2, sigmas, pad,
+        hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)hdr_all[side], hdr_stride, F1, P, me, per, nsub, tab, F2, sigmas, pad,
                            seg_off, seg_len, slot_base, slot_cap, words);
         FixedArgs fx{GroupSrc{}, slot_base, slot_cap, sub_start, sub_len, words, nullptr};
         PassCfg cfg = sp.local.passes[0].cfg;
         cfg.S = 1;
         {
             KernelTimer t(ctx, side ? "local_scatter_probe" : "local_scatter_build", st, 16 * cm->info.rows_received[side]);
-            launch_part2_ring(st, per, tuples[side], finals[side], cfg, fx, SegSrc{seg_off, seg_len, P});
+            launch_part2_ring(st, per, tuples[side], finals[side], cfg, fx, SegSrc{seg_off, seg_len, P * nsub});
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
         res[side] = SideResult();
@@ -639,11 +646,12 @@ int32_t golap_sharded_plan_get(uint32_t world, uint64_t n_build_total, uint64_t 
     out->n_buckets = sp.F1;
     out->buckets_per_rank = sp.per;
     out->local_bits = sp.local_bits;
+    out->sub_ranges = sp.nsub;
     const uint64_t mm = max_msg_bytes ? max_msg_bytes : (1ull << 30);
     for (int side = 0; side < 2; ++side)
         for (uint32_t r = 0; r < world; ++r) {
             out->cap_rows[side][r] = sp.cap[side][r];
-            out->msg_bytes[side][r] = (uint64_t)sp.per * sp.cap[side][r] * 8;
+            out->msg_bytes[side][r] = (uint64_t)sp.per * sp.nsub * sp.cap[side][r] * 8;
             out->msg_pieces[side][r] = (uint32_t)ceil_div(out->msg_bytes[side][r], mm);
         }
     return GOLAP_OK;

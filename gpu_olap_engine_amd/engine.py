@@ -170,25 +170,25 @@ class Context:
         self._ck(self._lib.golap_xfer_synchronize(self._h))
 
     # ---- GpuFilter ------------------------------------------------------------
-    def filter_mask(self, column, op, literal):
-        """FilterKernel::launch -> u8 mask (1 = pass)."""
+    def filter_mask(self, column, op, literal, valid=None):
+        """FilterKernel::launch -> u8 mask (1 = pass).  valid: uint8 per row, 0 = NULL (never passes)."""
         _chk_tensor(column, torch.int64, "column")
         n = column.numel()
         mask = torch.empty(n, dtype=torch.uint8, device=column.device)
         pred = N.FilterPredicate(0, op if isinstance(op, int) else parse_cmp_op(op), int(literal))
         g, b = compute_launch_params(n)
-        prm = N.FilterParams(_ptr(column), n, _ptr(mask), g, b)
+        prm = N.FilterParams(_ptr(column), n, _ptr(mask), g, b, _ptr(valid))
         self._ck(self._lib.golap_filter_launch(self._h, C.byref(pred), C.byref(prm), _stream()))
         return mask
 
-    def filter_compact(self, column, op, literal):
+    def filter_compact(self, column, op, literal, valid=None):
         """-> (indices u32 as int32 tensor view [n], count tensor u64 as int64[1]); indices[:count] are valid."""
         _chk_tensor(column, torch.int64, "column")
         n = column.numel()
         idx = torch.empty(max(n, 1), dtype=torch.int32, device=column.device)
         cnt = torch.zeros(1, dtype=torch.int64, device=column.device)
         pred = N.FilterPredicate(0, op if isinstance(op, int) else parse_cmp_op(op), int(literal))
-        self._ck(self._lib.golap_filter_compact(self._h, C.byref(pred), _ptr(column), n, _ptr(idx), _ptr(cnt), _stream()))
+        self._ck(self._lib.golap_filter_compact_nullable(self._h, C.byref(pred), _ptr(column), _ptr(valid), n, _ptr(idx), _ptr(cnt), _stream()))
         return idx, cnt
 
     def take(self, column, indices, count=None, n_max=None):
@@ -199,7 +199,7 @@ class Context:
         self._ck(self._lib.golap_take_8byte(self._h, _ptr(column), _ptr(indices), _ptr(count), n_max, _ptr(out), _stream()))
         return out
 
-    def filter_sum(self, key_column, value_column, op, literal):
+    def filter_sum(self, key_column, value_column, op, literal, key_valid=None, value_valid=None):
         """-> f64[2] device tensor: (sum of kept values as f64, kept rows)."""
         _chk_tensor(key_column, torch.int64, "key_column")
         n = key_column.numel()
@@ -207,19 +207,28 @@ class Context:
             raise TypeError("value_column must be int64/float64 with >= n rows")
         out = torch.zeros(2, dtype=torch.float64, device=key_column.device)
         pred = N.FilterPredicate(0, op if isinstance(op, int) else parse_cmp_op(op), int(literal))
-        self._ck(self._lib.golap_filter_sum(self._h, C.byref(pred), _ptr(key_column), _ptr(value_column),
-                                            1 if value_column.dtype == torch.float64 else 0, n, _ptr(out), _stream()))
+        self._ck(self._lib.golap_filter_sum_nullable(self._h, C.byref(pred), _ptr(key_column), _ptr(key_valid), _ptr(value_column), _ptr(value_valid),
+                                                     1 if value_column.dtype == torch.float64 else 0, n, _ptr(out), _stream()))
         return out
 
     # ---- GpuHashJoin ------------------------------------------------------------
     def join(self, build_keys, probe_keys, out_pairs=None, max_pairs=None, strategy=None, build_rid_base=0, probe_rid_base=0,
-             out_count=None, join_type=0):
+             out_count=None, join_type=0, build_valid=None, probe_valid=None):
         """JoinKernel::join.  -> (pairs int32[max_pairs,2] holding u32 (build_rid, probe_rid), count int64[1] device).
 
         Pair order is unspecified; the count keeps counting past max_pairs (join_kernels.cuh:155-160).
+        Composite keys: build_keys / probe_keys may be lists of up to 4 int64 tensors (rows match when every column is equal).
+        NULLs: build_valid / probe_valid = list (one entry per key column) of None or uint8 tensors, 0 = NULL (matches nothing).
         """
-        _chk_tensor(build_keys, torch.int64, "build_keys")
-        _chk_tensor(probe_keys, torch.int64, "probe_keys")
+        bcols = list(build_keys) if isinstance(build_keys, (list, tuple)) else [build_keys]
+        pcols = list(probe_keys) if isinstance(probe_keys, (list, tuple)) else [probe_keys]
+        if len(bcols) != len(pcols) or not 1 <= len(bcols) <= 4:
+            raise ValueError("1..4 key columns per side, the same number on both sides")
+        for t in bcols + pcols:
+            _chk_tensor(t, torch.int64, "key column")
+        build_keys, probe_keys = bcols[0], pcols[0]
+        bval = list(build_valid) if build_valid is not None else [None] * len(bcols)
+        pval = list(probe_valid) if probe_valid is not None else [None] * len(pcols)
         nb, npr = build_keys.numel(), probe_keys.numel()
         if strategy is None:
             strategy = choose_strategy(nb)
@@ -232,7 +241,11 @@ class Context:
         if out_count is None:
             out_count = torch.zeros(1, dtype=torch.int64, device=build_keys.device)
         prm = N.JoinParams(_ptr(build_keys), _ptr(probe_keys), nb, npr, _ptr(out_pairs), _ptr(out_count), max_pairs,
-                           build_rid_base, probe_rid_base, join_type)
+                           build_rid_base, probe_rid_base, join_type, len(bcols),
+                           (C.c_uint64 * 3)(*([_ptr(t) for t in bcols[1:]] + [0] * (4 - len(bcols)))),
+                           (C.c_uint64 * 3)(*([_ptr(t) for t in pcols[1:]] + [0] * (4 - len(pcols)))),
+                           (C.c_uint64 * 4)(*([_ptr(t) for t in bval] + [0] * (4 - len(bval)))),
+                           (C.c_uint64 * 4)(*([_ptr(t) for t in pval] + [0] * (4 - len(pval)))))
         self._ck(self._lib.golap_join(self._h, strategy, C.byref(prm), _stream()))
         return out_pairs, out_count
 
@@ -406,7 +419,7 @@ def sharded_plan(world, n_build_total, n_probe_total=None, max_msg_bytes=0):
     N.check(None, N.load().golap_sharded_plan_get(world, n_build_total, n_build_total if n_probe_total is None else n_probe_total,
                                                   None, None, max_msg_bytes, C.byref(pl)))
     return {"eligible": bool(pl.eligible), "extra_bits": pl.extra_bits, "n_buckets": pl.n_buckets, "buckets_per_rank": pl.buckets_per_rank,
-            "local_bits": pl.local_bits,
+            "local_bits": pl.local_bits, "sub_ranges": pl.sub_ranges,
             "cap_rows": [[pl.cap_rows[s][r] for r in range(world)] for s in range(2)],
             "msg_bytes": [[pl.msg_bytes[s][r] for r in range(world)] for s in range(2)],
             "msg_pieces": [[pl.msg_pieces[s][r] for r in range(world)] for s in range(2)]}

@@ -34,7 +34,10 @@ struct Column {
     std::string name;
     DType dtype = DType::Other;
     std::vector<uint8_t> data;   // packed little-endian values, nulls -> 0 (record_batch_convert.rs:102-110)
-    std::vector<uint8_t> valid;  // Arrow validity bitmap of an OUTPUT column (empty = all valid); only outer joins produce nulls
+    std::vector<uint8_t> valid;  // Arrow validity bitmap of an exported column (empty = all valid)
+    std::vector<uint8_t> in_valid;   // byte per row, 0 = NULL (ColumnBuffer.validity, column_buffer.rs:59-60); empty = no NULLs.  Travels with
+                                     // the column through the operators; GpuFilter and GpuHashJoin hand it to the kernels (NULL keys
+                                     // match nothing), aggregates read the zero the ingest leaves in a NULL slot (record_batch_convert.rs:102-110)
     uint64_t null_count = 0;
     uint64_t rows = 0;
     size_t width() const { return dtype == DType::Int32 ? 4 : 8; }
@@ -85,9 +88,13 @@ bool import_batch(ArrowArray* arr, ArrowSchema* sch, RecordBatch& out, std::stri
             if (out.num_rows && !src) { err = "column '" + col.name + "' has no data buffer"; return false; }
             if (out.num_rows) memcpy(col.data.data(), src + (size_t)off * w, (size_t)out.num_rows * w);
             if (valid && ca->null_count != 0) {
+                col.in_valid.assign((size_t)out.num_rows, 1);
                 for (uint64_t i = 0; i < out.num_rows; ++i) {
                     const int64_t j = off + (int64_t)i;
-                    if (!((valid[j >> 3] >> (j & 7)) & 1)) memset(col.data.data() + i * w, 0, w);   // null -> 0
+                    if (!((valid[j >> 3] >> (j & 7)) & 1)) {
+                        memset(col.data.data() + i * w, 0, w);   // null -> 0
+                        col.in_valid[i] = 0;
+                    }
                 }
             }
         }
@@ -133,6 +140,17 @@ void export_batch(RecordBatch&& b, ArrowArray* oa, ArrowSchema* os) {
     priv->child_schemas.resize(nc);
     priv->names.resize(nc);
     for (size_t c = 0; c < nc; ++c) {
+        Column& col = b.cols[c];
+        if (col.valid.empty() && !col.in_valid.empty()) {   // byte-per-row validity -> Arrow bitmap
+            uint64_t nulls = 0;
+            col.valid.assign((size_t)(b.num_rows + 7) / 8, 0);
+            for (uint64_t i = 0; i < b.num_rows; ++i) {
+                if (col.in_valid[i]) col.valid[i >> 3] |= (uint8_t)(1u << (i & 7));
+                else ++nulls;
+            }
+            col.null_count = nulls;
+            if (!nulls) col.valid.clear();
+        }
         priv->data[c] = std::move(b.cols[c].data);
         priv->valid[c] = std::move(b.cols[c].valid);
         priv->names[c] = b.cols[c].name;
@@ -298,19 +316,32 @@ int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::
         if (b.cols[ci].dtype != DType::Int64 || !parse_i64(litx->value, lit)) { out.push_back(std::move(b)); continue; }
         const uint64_t n = b.num_rows;
         if (n == 0) continue;   // empty batches are dropped (:173)
-        DevBuf dkey, didx, dcnt;
+        DevBuf dkey, didx, dcnt, dval;
         H_TRY(dkey.alloc(ctx, n * 8));
         H_TRY(didx.alloc(ctx, n * 4));
         H_TRY(dcnt.alloc(ctx, 8));
         H_TRY(h2d(b.cols[ci].data.data(), dkey.ptr, n * 8));
+        const bool key_has_nulls = !b.cols[ci].in_valid.empty();
+        if (key_has_nulls) {   // a comparison with NULL is not true: such rows do not pass
+            H_TRY(dval.alloc(ctx, n));
+            H_TRY(h2d(b.cols[ci].in_valid.data(), dval.ptr, n));
+        }
         H_TRY(xsync());
         golap_filter_predicate fp{(uint64_t)ci, (int32_t)op, lit};
-        H_TRY(golap_filter_compact(ctx, &fp, dkey.ptr, n, didx.ptr, dcnt.ptr, nullptr));
+        H_TRY(golap_filter_compact_nullable(ctx, &fp, dkey.ptr, key_has_nulls ? dval.ptr : 0, n, didx.ptr, dcnt.ptr, nullptr));
         H_TRY(ksync());
         uint64_t kept = 0;
         H_TRY(d2h(dcnt.ptr, &kept, 8));
         H_TRY(xsync());
         if (kept == 0) continue;
+        std::vector<uint32_t> hidx;   // the kept row ids on the host too, when some column carries NULLs (their validity is gathered here)
+        bool any_nulls = false;
+        for (const Column& c : b.cols) any_nulls = any_nulls || !c.in_valid.empty();
+        if (any_nulls) {
+            hidx.resize(kept);
+            H_TRY(d2h(didx.ptr, hidx.data(), kept * 4));
+            H_TRY(xsync());
+        }
         RecordBatch ob;
         ob.num_rows = kept;
         for (Column& c : b.cols) {
@@ -328,6 +359,10 @@ int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::
             oc.data.resize(kept * 8);
             H_TRY(d2h(dout.ptr, oc.data.data(), kept * 8));
             H_TRY(xsync());
+            if (!c.in_valid.empty()) {
+                oc.in_valid.resize(kept);
+                for (uint64_t i = 0; i < kept; ++i) oc.in_valid[i] = c.in_valid[hidx[i]];
+            }
             ob.cols.push_back(std::move(oc));
         }
         out.push_back(std::move(ob));
@@ -365,15 +400,25 @@ int32_t Exec::projection(std::vector<RecordBatch>& in, const std::vector<std::un
     return GOLAP_OK;
 }
 
-// concatenates column `ci(b)` of every batch; returns false if any batch's column is not Int64
-static bool concat_i64(const std::vector<RecordBatch>& bs, const golap_expr& key, std::vector<int64_t>& out, std::string& err) {
+// concatenates column `ci(b)` of every batch (+ its validity bytes: `valid` stays empty when no batch has NULLs in it);
+// returns false if any batch's column is not Int64
+static bool concat_i64(const std::vector<RecordBatch>& bs, const golap_expr& key, std::vector<int64_t>& out, std::vector<uint8_t>& valid, std::string& err) {
+    bool any_nulls = false;
     for (const RecordBatch& b : bs) {
         const int ci = Exec::resolve_column(key, b);
         if (ci < 0) { err = "Column '" + key.name + "' not found in batch"; return false; }
         if (b.cols[ci].dtype != DType::Int64) { err = "join key '" + key.name + "' must be Int64 (executor.rs:246)"; return false; }
+        any_nulls = any_nulls || !b.cols[ci].in_valid.empty();
+    }
+    for (const RecordBatch& b : bs) {
+        const int ci = Exec::resolve_column(key, b);
         const size_t o = out.size();
         out.resize(o + b.num_rows);
         if (b.num_rows) memcpy(out.data() + o, b.cols[ci].data.data(), b.num_rows * 8);
+        if (any_nulls) {
+            valid.resize(o + b.num_rows, 1);
+            if (!b.cols[ci].in_valid.empty() && b.num_rows) memcpy(valid.data() + o, b.cols[ci].in_valid.data(), b.num_rows);
+        }
     }
     return true;
 }
@@ -384,13 +429,20 @@ static bool concat_i64(const std::vector<RecordBatch>& bs, const golap_expr& key
 int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out) {
     if (left.empty() || right.empty()) return GOLAP_OK;                 // :231-233 -> vec![]
     if (p.left_keys.empty() || p.right_keys.empty()) return herr(GOLAP_ERR_INVALID_ARG, "GpuHashJoin needs one key per side");
-    // FIRST key expression only (:245)
-    const golap_expr &lk = *p.left_keys[0], &rk = *p.right_keys[0];
-    if (lk.kind != golap_expr::Column || rk.kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: key expressions must be column references");
-    std::vector<int64_t> bkeys, pkeys;
+    // The reference executor reads the FIRST key expression only (:245) although the plan carries vectors (physical_plan.rs:35-36);
+    // here every key column takes part (up to 4), and NULL keys match nothing (SQL; the reference has turned them into 0 by now).
+    const size_t nk = p.left_keys.size();
+    if (p.right_keys.size() != nk) return herr(GOLAP_ERR_INVALID_ARG, "GpuHashJoin: left_keys and right_keys differ in length");
+    if (nk > 4) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: at most 4 key columns");
+    std::vector<std::vector<int64_t>> bkc(nk), pkc(nk);
+    std::vector<std::vector<uint8_t>> bvc(nk), pvc(nk);
     std::string err;
-    if (!concat_i64(left, lk, bkeys, err) || !concat_i64(right, rk, pkeys, err)) return herr(GOLAP_ERR_INVALID_ARG, err);
-    const uint64_t nb = bkeys.size(), np = pkeys.size();   // global row index = running offset over batches (:249, :252)
+    for (size_t k = 0; k < nk; ++k) {
+        const golap_expr &lk = *p.left_keys[k], &rk = *p.right_keys[k];
+        if (lk.kind != golap_expr::Column || rk.kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: key expressions must be column references");
+        if (!concat_i64(left, lk, bkc[k], bvc[k], err) || !concat_i64(right, rk, pkc[k], pvc[k], err)) return herr(GOLAP_ERR_INVALID_ARG, err);
+    }
+    const uint64_t nb = bkc[0].size(), np = pkc[0].size();   // global row index = running offset over batches (:249, :252)
     RecordBatch ob;
     // output schema: left fields then right fields
     for (const Column& c : left[0].cols) { Column oc; oc.name = c.name; oc.dtype = c.dtype; ob.cols.push_back(oc); }
@@ -403,21 +455,32 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
     const bool outer_keeps_something = (nb && (p.join_type == GOLAP_JOIN_LEFT || p.join_type == GOLAP_JOIN_FULL)) ||
                                        (np && (p.join_type == GOLAP_JOIN_RIGHT || p.join_type == GOLAP_JOIN_FULL));
     if ((nb && np) || outer_keeps_something) {
-        DevBuf db, dp, dcnt;
-        H_TRY(db.alloc(ctx, nb * 8));
-        H_TRY(dp.alloc(ctx, np * 8));
+        DevBuf dcnt;
+        std::vector<DevBuf> db(nk), dp(nk), dbv(nk), dpv(nk);
         H_TRY(dcnt.alloc(ctx, 8));
-        H_TRY(h2d(bkeys.data(), db.ptr, nb * 8));
-        H_TRY(h2d(pkeys.data(), dp.ptr, np * 8));
+        for (size_t k = 0; k < nk; ++k) {
+            H_TRY(db[k].alloc(ctx, nb * 8));
+            H_TRY(dp[k].alloc(ctx, np * 8));
+            H_TRY(h2d(bkc[k].data(), db[k].ptr, nb * 8));
+            H_TRY(h2d(pkc[k].data(), dp[k].ptr, np * 8));
+            if (!bvc[k].empty()) { H_TRY(dbv[k].alloc(ctx, nb)); H_TRY(h2d(bvc[k].data(), dbv[k].ptr, nb)); }
+            if (!pvc[k].empty()) { H_TRY(dpv[k].alloc(ctx, np)); H_TRY(h2d(pvc[k].data(), dpv[k].ptr, np)); }
+        }
         H_TRY(xsync());
         uint64_t cap = std::max<uint64_t>(np + ((p.join_type & 1) ? nb : 0), 1);   // first guess; the count is the TRUE total (join_kernels.cuh:155-160)
         for (int attempt = 0; attempt < 2; ++attempt) {
             H_TRY(dpairs.alloc(ctx, cap * 8));
             golap_join_params jp;
             memset(&jp, 0, sizeof jp);
-            jp.build_key_ptr = db.ptr; jp.probe_key_ptr = dp.ptr; jp.n_build = nb; jp.n_probe = np;
+            jp.build_key_ptr = db[0].ptr; jp.probe_key_ptr = dp[0].ptr; jp.n_build = nb; jp.n_probe = np;
             jp.out_pairs_ptr = dpairs.ptr; jp.out_count_ptr = dcnt.ptr; jp.max_pairs = cap;
             jp.join_type = (int32_t)p.join_type;
+            jp.n_key_cols = (uint32_t)nk;
+            for (size_t k = 0; k < nk; ++k) {
+                if (k) { jp.build_key_extra[k - 1] = db[k].ptr; jp.probe_key_extra[k - 1] = dp[k].ptr; }
+                jp.build_validity[k] = bvc[k].empty() ? 0 : dbv[k].ptr;
+                jp.probe_validity[k] = pvc[k].empty() ? 0 : dpv[k].ptr;
+            }
             H_TRY(golap_join(ctx, golap_choose_strategy(nb), &jp, nullptr));   // JoinKernel::choose_strategy, join_kernel.rs:71-77
             H_TRY(ksync());
             H_TRY(d2h(dcnt.ptr, &m, 8));
@@ -449,11 +512,15 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
             const std::vector<RecordBatch>& side = is_left ? left : right;
             const size_t sc = is_left ? c : c - n_left_cols;
             const uint64_t rows = is_left ? nb : np;
-            std::vector<uint8_t> whole(rows * 8);
+            std::vector<uint8_t> whole(rows * 8), src_valid;
             size_t o = 0;
+            bool src_nulls = false;
+            for (const RecordBatch& b : side) src_nulls = src_nulls || (sc < b.cols.size() && !b.cols[sc].in_valid.empty());
+            if (src_nulls) src_valid.assign(rows, 1);
             for (const RecordBatch& b : side) {
                 if (sc >= b.cols.size() || b.cols[sc].dtype != ob.cols[c].dtype) return herr(GOLAP_ERR_INVALID_ARG, "batches of one side differ in schema");
                 if (b.num_rows) memcpy(whole.data() + o, b.cols[sc].data.data(), b.num_rows * 8);
+                if (src_nulls && !b.cols[sc].in_valid.empty() && b.num_rows) memcpy(src_valid.data() + o / 8, b.cols[sc].in_valid.data(), b.num_rows);
                 o += b.num_rows * 8;
             }
             DevBuf dcol, dout;
@@ -467,12 +534,13 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
             {   // rows whose source side is missing (NULL row id of an outer join) become Arrow nulls
                 const std::vector<uint32_t>& ix = is_left ? lidx : ridx;
                 uint64_t nulls = 0;
-                for (uint64_t i = 0; i < m; ++i) nulls += ix[i] == 0xFFFFFFFFu;
+                auto is_null = [&](uint64_t i) { return ix[i] == 0xFFFFFFFFu || (src_nulls && !src_valid[ix[i]]); };   // missing side, or a NULL in the source row
+                for (uint64_t i = 0; i < m; ++i) nulls += is_null(i);
                 if (nulls) {
                     ob.cols[c].null_count = nulls;
                     ob.cols[c].valid.assign((m + 7) / 8, 0);
                     for (uint64_t i = 0; i < m; ++i)
-                        if (ix[i] != 0xFFFFFFFFu) ob.cols[c].valid[i >> 3] |= (uint8_t)(1u << (i & 7));
+                        if (!is_null(i)) ob.cols[c].valid[i >> 3] |= (uint8_t)(1u << (i & 7));
                 }
             }
             ob.cols[c].data.resize(m * 8);

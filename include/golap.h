@@ -140,6 +140,9 @@ typedef struct golap_filter_params {      /* filter_kernel.rs:17-28 */
     uint64_t out_mask_ptr;  /* device, u8[n_rows], 1 = pass */
     uint32_t grid_dim;      /* accepted for API parity; 0 = library chooses */
     uint32_t block_dim;
+    uint64_t validity_ptr;  /* extension: device u8[n_rows], 0 = NULL (ColumnBuffer.validity, column_buffer.rs:59-60); 0 pointer = no NULLs.
+                               A comparison with NULL is not true: the row does not pass (the reference's ingest turns NULL into 0,
+                               record_batch_convert.rs:102-110, which would let it pass `col < 10`). */
 } golap_filter_params;
 
 /* filter_kernel.rs:75-79 (and aggregate_kernel.rs:127-131): block 256, grid ceil(n/256) >= 1 */
@@ -151,6 +154,9 @@ int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, 
  * (original order, executor.rs:479-484) and their count (u64, device). */
 int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t n_rows,
                              uint64_t out_indices_ptr /*u32[n_rows]*/, uint64_t out_count_ptr /*u64*/, void* stream);
+/* The same with a validity byte per row (0 = NULL; 0 pointer = no NULLs): NULL rows never pass. */
+int32_t golap_filter_compact_nullable(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t validity_ptr, uint64_t n_rows,
+                                      uint64_t out_indices_ptr, uint64_t out_count_ptr, void* stream);
 /* take_int64, executor.rs:496-507: out[i] = col[indices[i]] for 8-byte columns (index 0xFFFFFFFF = NULL row -> 0). */
 int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_ptr, uint64_t count_ptr /*u64 device, or 0*/,
                          uint64_t n_indices_max, uint64_t out_ptr, void* stream);
@@ -160,6 +166,11 @@ int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_p
  * out[1] = (f64) number of kept rows. */
 int32_t golap_filter_sum(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t key_column_ptr, uint64_t value_column_ptr,
                          int32_t value_is_f64, uint64_t n_rows, uint64_t out_ptr /*f64[2] device*/, void* stream);
+
+/* NULL-aware form: rows whose key is NULL do not pass, NULL values are skipped by the sum and the count (SQL aggregates). */
+int32_t golap_filter_sum_nullable(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t key_column_ptr, uint64_t key_validity_ptr,
+                                  uint64_t value_column_ptr, uint64_t value_validity_ptr, int32_t value_is_f64, uint64_t n_rows,
+                                  uint64_t out_ptr /*f64[2] device*/, void* stream);
 
 /* ---- GpuHashJoin ---------------------------------------------------------
  * JoinStrategy join_kernel.rs:14-18, JoinParams :20-27, JoinKernel::join :39-45,
@@ -189,6 +200,17 @@ typedef struct golap_join_params {
     int32_t  join_type;       /* JoinType, logical_plan.rs:53-58: 0 Inner, 1 Left (every build row kept),
                                  2 Right (every probe row kept), 3 Full; the missing side of an unmatched
                                  row is row id 0xFFFFFFFF.  The reference's kernels are inner-only.  */
+    /* --- composite keys and NULLs (ABI 2) --- */
+    uint32_t n_key_cols;      /* 0 / 1: one key column per side (build_key_ptr / probe_key_ptr).  2..4: composite key -- physical_plan.rs:35-36
+                                 declares left_keys / right_keys as Vec<PhysicalExpr>, the reference executor only ever reads [0]
+                                 (executor.rs:245) -- the further columns are *_key_extra[0..n_key_cols-2]; rows match when EVERY column is equal */
+    uint64_t build_key_extra[3];   /* device int64[n_build] */
+    uint64_t probe_key_extra[3];   /* device int64[n_probe] */
+    uint64_t build_validity[4];    /* per key column: device u8[n_build], 0 = NULL -- the byte-per-row validity of ColumnBuffer
+                                      (column_buffer.rs:59-60); a 0 pointer = that column has no NULLs.  SQL semantics (README.md:411
+                                      "null handling" is on the reference's roadmap): a row with a NULL in any key column matches nothing,
+                                      and on the preserved side of an outer join it survives as an unmatched row */
+    uint64_t probe_validity[4];
 } golap_join_params;
 
 /* Join on int64 keys; row ids are 0-based positions + *_rid_base.  Pair
@@ -340,7 +362,9 @@ void    golap_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint6
 typedef struct golap_sharded_plan {
     uint32_t eligible;           /* 1: the fast path applies to these sizes */
     uint32_t extra_bits, n_buckets, buckets_per_rank, local_bits;
-    uint64_t cap_rows[2][64];    /* [side][source rank] rows provisioned per bucket */
+    uint32_t sub_ranges;         /* every bucket is sub_ranges ranges of cap_rows rows (one per XCD of the partitioning GPU) */
+    uint32_t reserved0;
+    uint64_t cap_rows[2][64];    /* [side][source rank] rows provisioned per bucket sub-range */
     uint64_t msg_bytes[2][64];   /* [side][source rank] bytes every peer receives from that rank */
     uint32_t msg_pieces[2][64];  /* pieces that message is split into (max_msg_bytes) */
 } golap_sharded_plan;

@@ -133,6 +133,35 @@ def hash_join_outer(build_keys, probe_keys, join_type):
     return out, m
 
 
+def hash_join_multi(build_cols, probe_cols, join_type=0, build_valid=None, probe_valid=None):
+    """Equi-join on several Int64 key columns with NULLs (SQL semantics: NULL keys match nothing; outer joins keep such rows as
+    unmatched).  *_cols: lists of int64 arrays; *_valid: None or lists of (None | uint8 array, 0 = NULL).
+    -> canonical (M,2) uint32 [build_rid, probe_rid], NULL = 0xFFFFFFFF."""
+    nc = len(build_cols)
+    assert nc == len(probe_cols) and nc >= 1
+    b = [_c(x, np.int64) for x in build_cols]
+    p = [_c(x, np.int64) for x in probe_cols]
+    nb, npr = b[0].size, p[0].size
+
+    def vlist(v, n):
+        if v is None:
+            return None, [None] * nc
+        keep = [None if x is None else _c(x, np.uint8) for x in v]
+        arr = (C.POINTER(C.c_uint8) * nc)(*[C.cast(None, C.POINTER(C.c_uint8)) if x is None else _p(x, C.c_uint8) for x in keep])
+        return arr, keep
+    bv, _kb = vlist(build_valid, nb)
+    pv, _kp = vlist(probe_valid, npr)
+    bc = (C.POINTER(C.c_int64) * nc)(*[_p(x, C.c_int64) for x in b])
+    pc = (C.POINTER(C.c_int64) * nc)(*[_p(x, C.c_int64) for x in p])
+    f = lib().orc_hash_join_multi
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64]
+    m = f(bc, bv, nb, pc, pv, npr, nc, join_type, None, 0)
+    out = np.empty((m, 2), np.uint32)
+    f(bc, bv, nb, pc, pv, npr, nc, join_type, out.ctypes.data if m else None, m)
+    return out, m
+
+
 def execute_hash_join(left_batches, right_batches):
     """executor.rs:220-265 semantics over lists of int64 key arrays (one per RecordBatch)."""
     if len(left_batches) == 0 or len(right_batches) == 0:

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -177,6 +178,55 @@ uint64_t orc_hash_join_outer_i64(const int64_t* build_keys, uint64_t n_build, co
             if (!hit[i]) pairs.push_back((0xFFFFFFFFull << 32) | (uint32_t)i);
     std::sort(pairs.begin(), pairs.end());
     uint64_t mm = pairs.size(), w = std::min(mm, max_pairs);
+    if (out_pairs)
+        for (uint64_t i = 0; i < w; ++i) {
+            out_pairs[2 * i] = (uint32_t)(pairs[i] & 0xFFFFFFFFu);
+            out_pairs[2 * i + 1] = (uint32_t)(pairs[i] >> 32);
+        }
+    return mm;
+}
+
+// Equi-join on SEVERAL key columns with NULLs (physical_plan.rs:35-36 declares
+// left_keys / right_keys as Vec<PhysicalExpr>, column_buffer.rs:59-60 a byte-per-row validity).  SQL semantics, which the
+// reference's roadmap (README.md:411) names and none of its code reaches: two rows match iff EVERY key column is equal
+// and none of them is NULL; a row with a NULL key matches nothing and, on a preserved side of an outer join, survives
+// as an unmatched row.  keys: n_cols column pointers per side; valid: n_cols pointers per side, each null (all valid)
+// or a byte per row (0 = NULL).  Canonical (probe, build) order like the joins above.
+uint64_t orc_hash_join_multi(const int64_t* const* build_cols, const uint8_t* const* build_valid, uint64_t n_build,
+                             const int64_t* const* probe_cols, const uint8_t* const* probe_valid, uint64_t n_probe, uint32_t n_cols,
+                             int join_type, uint32_t* out_pairs, uint64_t max_pairs) {
+    auto is_null = [&](const uint8_t* const* v, uint64_t i) {
+        for (uint32_t c = 0; c < n_cols; ++c)
+            if (v && v[c] && !v[c][i]) return true;
+        return false;
+    };
+    std::map<std::vector<int64_t>, std::vector<uint32_t>> m;
+    std::vector<int64_t> k(n_cols);
+    for (uint64_t i = 0; i < n_build; ++i) {
+        if (is_null(build_valid, i)) continue;
+        for (uint32_t c = 0; c < n_cols; ++c) k[c] = build_cols[c][i];
+        m[k].push_back((uint32_t)i);
+    }
+    std::vector<uint8_t> hit(n_build, 0);
+    std::vector<uint64_t> pairs;
+    const bool keep_build = join_type == 1 || join_type == 3, keep_probe = join_type == 2 || join_type == 3;
+    for (uint64_t j = 0; j < n_probe; ++j) {
+        bool matched = false;
+        if (!is_null(probe_valid, j)) {
+            for (uint32_t c = 0; c < n_cols; ++c) k[c] = probe_cols[c][j];
+            auto it = m.find(k);
+            if (it != m.end()) {
+                matched = true;
+                for (uint32_t b : it->second) { hit[b] = 1; pairs.push_back(((uint64_t)(uint32_t)j << 32) | b); }
+            }
+        }
+        if (!matched && keep_probe) pairs.push_back(((uint64_t)(uint32_t)j << 32) | 0xFFFFFFFFull);
+    }
+    if (keep_build)
+        for (uint64_t i = 0; i < n_build; ++i)
+            if (!hit[i]) pairs.push_back((0xFFFFFFFFull << 32) | (uint32_t)i);
+    std::sort(pairs.begin(), pairs.end());
+    const uint64_t mm = pairs.size(), w = std::min(mm, max_pairs);
     if (out_pairs)
         for (uint64_t i = 0; i < w; ++i) {
             out_pairs[2 * i] = (uint32_t)(pairs[i] & 0xFFFFFFFFu);

@@ -274,10 +274,10 @@ def test_sharded_plan_is_the_same_on_every_rank(world, n, max_msg):
         for side in range(2):
             for s in range(world):
                 rows = box[s]["rows"]
-                cap, nb = ref["cap_rows"][side][s], ref["n_buckets"]
-                avg = -(-rows // nb)
-                assert cap % 16 == 0 and cap >= avg + 6 * int(avg ** 0.5)          # provisioned range: mean + 6 sigma (Poisson), line aligned
-                assert ref["msg_bytes"][side][s] == ref["buckets_per_rank"] * cap * 8
+                cap, nb, ns = ref["cap_rows"][side][s], ref["n_buckets"], ref["sub_ranges"]
+                avg = -(-rows // (nb * ns))
+                assert cap % 16 == 0 and cap >= avg + 6 * int(avg ** 0.5)          # provisioned sub-range: mean + 6 sigma (Poisson), line aligned
+                assert ref["msg_bytes"][side][s] == ref["buckets_per_rank"] * ns * cap * 8
                 assert (ref["msg_pieces"][side][s] - 1) * mm < ref["msg_bytes"][side][s] <= ref["msg_pieces"][side][s] * mm
 
 

@@ -47,9 +47,13 @@ def test_arrow_roundtrip_offsets_and_nulls(O):
     sl = full.slice(1, 5)                                     # non-zero offset + validity bitmap
     out = O.execute(O.GpuSort(O.Batches([full, sl])), NoCtx())
     assert [b.num_rows for b in out] == [7, 5]
-    assert out[0].column(0).to_pylist() == [1, 0, 3, 4, 5, 0, 7]          # null -> 0 (record_batch_convert.rs:102-110)
-    assert out[0].column(1).to_pylist() == [0.5, 1.5, 0.0, 3.5, 4.5, 5.5, 6.5]
-    assert out[1].column(0).to_pylist() == [0, 3, 4, 5, 0] and out[1].column(2).to_pylist() == [20, 30, 40, 50, 60]
+    # the value buffer holds 0 under a null (record_batch_convert.rs:102-110) and the validity bitmap travels with the column
+    # (nulls survive the operator layer instead of turning into zeros)
+    assert out[0].column(0).to_pylist() == [1, None, 3, 4, 5, None, 7]
+    assert out[0].column(0).fill_null(-1).to_pylist() == [1, -1, 3, 4, 5, -1, 7]
+    assert np.frombuffer(out[0].column(0).buffers()[1], dtype=np.int64, count=7).tolist() == [1, 0, 3, 4, 5, 0, 7]
+    assert out[0].column(1).to_pylist() == [0.5, 1.5, None, 3.5, 4.5, 5.5, 6.5]
+    assert out[1].column(0).to_pylist() == [None, 3, 4, 5, None] and out[1].column(2).to_pylist() == [20, 30, 40, 50, 60]
     assert out[1].schema.names == ["a", "f", "i"] and out[1].schema.field(2).type == pa.int32()
 
 

@@ -1,0 +1,118 @@
+"""Static audit of the kernels that hide memory operations from hipcc (csrc/golap_part_narrow.h, ASM forms).
+
+Those kernels issue their loads and stores in `asm volatile` statements and wait for them with hand-counted `s_waitcnt vmcnt(N)`
+(cdna_hip_programming.md 5.7).  That is only sound while the compiler (1) never spills -- a spilled or reloaded register may be the
+destination of a load that has not landed (wrong data, or a memory fault when it held an address: seen once on MI355X with a build
+that had 36 bytes of scratch), (2) never touches a hidden load's destination registers between the load and the counted wait, and
+(3) adds no `vmcnt` wait of its own inside the tile loop (it would drain the prefetch on every tile).  All three are properties of
+the generated code, so they are checked on the generated code: golap_join.hip is compiled to gfx950 assembly (no GPU needed)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gpu_olap_engine_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+KERNELS = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0E", "k_part1_narrowILi16ELi16384ELb1ELb1ELi0E", "k_part2_ringILi4ELi32ELb1ELi0E"]
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "golap_join.s"
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-inline-asm", "-Wno-pass-failed"]      # the Makefile's flags
+    subprocess.check_call([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(CSRC, "golap_join.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _body(asm, key):
+    m = re.search(r"^(_ZN5golap\d+" + re.escape(key) + r"\w*):\s*;", asm, re.M)
+    assert m, f"kernel {key} not found in the assembly"
+    name = m.group(1)
+    end = asm.index(".amdhsa_kernel " + name)
+    meta = asm[asm.index(f".name:           {name}") if f".name:           {name}" in asm else 0:]
+    return name, asm[m.start():end].split("\n")
+
+
+def _regs(line):
+    out = set()
+    for a, b in re.findall(r"v\[(\d+):(\d+)\]", line):
+        out |= set(range(int(a), int(b) + 1))
+    out |= {int(x) for x in re.findall(r"\bv(\d+)\b", line)}
+    return out
+
+
+@pytest.mark.parametrize("key", KERNELS)
+def test_hidden_memory_kernels_have_no_scratch_and_no_stray_waits(asm, key):
+    name, lines = _body(asm, key)
+    # (1) no spills, no scratch
+    assert not [l for l in lines if "scratch_" in l], f"{key}: scratch instructions (spills) next to hidden loads"
+    md = re.search(r"\.name:\s+" + re.escape(name) + r"\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", asm)
+    sp = re.search(re.escape(name) + r"\.private_seg_size,\s*(\d+)", asm)
+    if sp:
+        assert int(sp.group(1)) == 0, f"{key}: private segment {sp.group(1)} bytes"
+    # (2) between a hidden load (or returning atomic) and the next hand-counted wait, nothing outside the asm statements touches
+    #     its destination registers: a copy placed there (e.g. a phi copy at a control-flow merge) reads data that has not
+    #     landed, and the original registers -- free again in the compiler's eyes -- get overwritten by the late data while they
+    #     hold something else (seen on MI355X: a store address, i.e. a memory fault).  The scan is linear over the program text,
+    #     which covers every fall-through and forward path; it is conservative (code of a sibling branch counts too), so the
+    #     kernels keep their hidden loads in straight-line code.
+    in_asm, hidden, dirty = False, set(), {}
+    for ln, l in enumerate(lines):
+        s = l.strip()
+        if "ASMSTART" in s:
+            in_asm = True
+            continue
+        if "ASMEND" in s:
+            in_asm = False
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        if in_asm:
+            m = re.match(r"global_(?:load_dword(?:x[24])?|atomic_add) (v\[(\d+):(\d+)\]|v(\d+)),", s)
+            if m:
+                r = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
+                hidden |= r
+                for x in r:
+                    dirty[x] = ln
+            if s.startswith("s_waitcnt vmcnt"):
+                dirty = {}
+            continue
+        touched = _regs(s) & set(dirty)
+        assert not touched, (f"{key}: line {ln} `{s}` uses v{sorted(touched)} while a hidden load into them (line "
+                             f"{dirty[sorted(touched)[0]]}) may still be in flight")
+    assert hidden, f"{key}: no hidden loads found (is this still the ASM form?)"
+    if "k_part2_ring" in key:
+        # the ring pass loads into fixed registers outside hipcc's budget (golap_part_narrow.h, ld8_fixed): hipcc itself must
+        # never name them, and the kernel descriptor must cover them
+        src = open(os.path.join(CSRC, "golap_part_narrow.h")).read()
+        first = int(re.search(r"P2R_FIXED_FIRST = (\d+)", src).group(1))
+        pairs = int(re.search(r"P2R_FIXED_PAIRS = (\d+)", src).group(1))
+        fixed = set(range(first, first + 2 * pairs))
+        assert hidden == fixed, f"{key}: hidden loads go to {sorted(hidden)}, expected the fixed registers {first}..{first + 2 * pairs - 1}"
+        in_asm = False
+        for ln, l in enumerate(lines):
+            if "ASMSTART" in l:
+                in_asm = True
+            elif "ASMEND" in l:
+                in_asm = False
+            elif not in_asm and not l.strip().startswith(";"):
+                assert not (_regs(l) & fixed), f"{key}: line {ln} `{l.strip()}`: hipcc allocated a register reserved for hidden loads"
+        nv = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\n(?:.*\n)*?\s+\.amdhsa_next_free_vgpr (\d+)", asm)
+        assert nv and int(nv.group(1)) >= first + 2 * pairs, f"{key}: kernel descriptor does not cover the fixed registers"
+    # (3) every vmcnt wait in the kernel is one of ours (inside an asm statement), except before the main loop / after it
+    stray, in_asm, seen_loop = [], False, False
+    for i, l in enumerate(lines):
+        if "ASMSTART" in l:
+            in_asm = True
+        elif "ASMEND" in l:
+            in_asm = False
+        elif "Loop Header" in l and "Depth=1" in l:
+            seen_loop = True
+        elif "s_waitcnt" in l and "vmcnt" in l and not in_asm and seen_loop and "in Loop" in "".join(lines[max(0, i - 40):i]):
+            stray.append((i, l.strip()))
+    assert not stray, f"{key}: compiler-inserted vmcnt waits inside the tile loop: {stray[:3]}"

@@ -291,18 +291,25 @@ def test_asymmetric_sides_mix_first_pass_forms(ctx, nb, npr):
         assert int(v[0]) == npr and int(v[2]) == npr * (npr - 1) // 2
 
 
-@pytest.mark.parametrize("shape", ["narrow", "all_wide", "one_wide_key_last", "negative_key_first"])
+@pytest.mark.parametrize("shape", ["narrow", "common_upper_half", "negative_small", "two_upper_halves", "one_wide_key_last", "negative_key_first"])
 def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
-    """Large joins first try 8-byte (key32, row id) tuples; any key outside [0, 2^32) -- in the first tile or in the very last
-    row -- must hand the whole join over to the 64-bit pipeline on the device, with identical results (checked on the device:
-    every pair key-equal, probe ids a permutation)."""
+    """Large joins first try 8-byte (key32, row id) tuples, which stand while every key of both sides shares its upper 32 bits with
+    the first build key (0 for small ids, but also keys offset by 2^40, or small negative keys); any other key -- in the first
+    tile or in the very last row -- must hand the whole join over to the 64-bit pipeline on the device, with identical results
+    (checked on the device: every pair key-equal, probe ids a permutation)."""
     n = 60_000_000
     bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
     pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
     orphans = 0
-    if shape == "all_wide":
+    if shape == "common_upper_half":
         bt += 1 << 40
         pt += 1 << 40
+    elif shape == "negative_small":
+        bt -= n + 5
+        pt -= n + 5
+    elif shape == "two_upper_halves":
+        bt += (bt & 1) << 40
+        pt += (pt & 1) << 40
     elif shape != "narrow":
         idx, key = (n - 1, (1 << 35) + 7) if shape == "one_wide_key_last" else (0, -5)
         old = int(bt[idx].item())
@@ -319,7 +326,8 @@ def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
     if orphans == 0:
         assert int(v[2]) == n * (n - 1) // 2                           # every probe row exactly once
     wide_ms, narrow_ms = st["join_build_probe_lds_wide"]["total_ms"], st["join_build_probe_lds"]["total_ms"]
-    assert (wide_ms < narrow_ms) if shape == "narrow" else (wide_ms > narrow_ms)   # which pipeline did the work (the other returns at once)
+    tuples = shape in ("narrow", "common_upper_half", "negative_small")
+    assert (wide_ms < narrow_ms) if tuples else (wide_ms > narrow_ms)   # which pipeline did the work (the other returns at once)
 
 
 @pytest.mark.parametrize("bits", ["8,4,4", "10,6", "8,7"])
@@ -624,3 +632,77 @@ def test_sort_merge_unsupported(ctx):
     with pytest.raises(GolapError) as e:
         ctx.join(t, t, strategy=N.JOIN_SORT_MERGE)
     assert e.value.code == N.ERR_UNSUPPORTED
+
+
+# ---- composite keys and NULLs ------------------------------------------------------------------
+def _multi_check(ctx, bcols, pcols, jt, strategy, bvalid=None, pvalid=None, knobs=None):
+    exp, me = oracle.hash_join_multi(bcols, pcols, jt, bvalid, pvalid)
+    tb = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.int64)).cuda() for c in bcols]
+    tp = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.int64)).cuda() for c in pcols]
+    tv = lambda v: None if v is None else [None if x is None else torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint8)).cuda() for x in v]
+    with ctx.knobs(**(knobs or {})):
+        pairs, cnt = ctx.join(tb, tp, max_pairs=max(1, me + 64), strategy=strategy, join_type=jt, build_valid=tv(bvalid), probe_valid=tv(pvalid))
+        torch.cuda.synchronize()
+    m = int(cnt.item())
+    assert m == me, f"jt={jt}: count {m} != oracle {me}"
+    assert np.array_equal(canonical(pairs[:m].cpu().numpy().view(np.uint32)), exp), f"jt={jt}"
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+@pytest.mark.parametrize("jt", [N.JT_INNER, N.JT_LEFT, N.JT_RIGHT, N.JT_FULL])
+def test_composite_key_join(ctx, strategy, jt):
+    """physical_plan.rs:35-36: left_keys / right_keys are vectors; rows match when EVERY key column is equal (the reference
+    executor only reads [0], executor.rs:245).  Two and three Int64 columns, duplicates, values of either sign and width."""
+    rng = np.random.default_rng(41 + jt)
+    nb, npr = 60_000, 90_000
+    b = [rng.integers(-40, 40, nb), rng.integers(0, 30, nb) << 35]
+    p = [rng.integers(-40, 40, npr), rng.integers(0, 30, npr) << 35]
+    _multi_check(ctx, b, p, jt, strategy)
+    b3 = b + [rng.integers(0, 3, nb)]
+    p3 = p + [rng.integers(0, 3, npr)]
+    _multi_check(ctx, b3, p3, jt, strategy)
+    # the same first column everywhere: only the second one decides
+    _multi_check(ctx, [np.full(1000, 7), np.arange(1000)], [np.full(500, 7), np.arange(250, 750)], jt, strategy)
+
+
+@pytest.mark.parametrize("strategy", STRATS)
+@pytest.mark.parametrize("jt", [N.JT_INNER, N.JT_LEFT, N.JT_RIGHT, N.JT_FULL])
+def test_null_keys_match_nothing(ctx, strategy, jt):
+    """column_buffer.rs:59-60 validity (a byte per row): a NULL key matches nothing -- not even another NULL -- and on the preserved
+    side of an outer join the row survives as an unmatched row (SQL semantics; the reference turns nulls into key 0)."""
+    rng = np.random.default_rng(17 + jt)
+    nb, npr = 50_000, 70_000
+    b, p = rng.integers(0, 20_000, nb), rng.integers(0, 20_000, npr)
+    bv, pv = (rng.random(nb) > 0.1).astype(np.uint8), (rng.random(npr) > 0.2).astype(np.uint8)
+    b[bv == 0] = 0                                  # what ingest leaves in a NULL slot (record_batch_convert.rs:102-110): must NOT join with key 0
+    p[pv == 0] = 0
+    _multi_check(ctx, [b], [p], jt, strategy, [bv], [pv])
+    _multi_check(ctx, [b], [p], jt, strategy, [bv], None)          # NULLs on one side only
+    _multi_check(ctx, [b], [p], jt, strategy, None, [pv])
+    _multi_check(ctx, [b, b // 3], [p, p // 3], jt, strategy, [None, bv], [pv, None])   # composite key, NULLs in different columns
+    _multi_check(ctx, [b], [p], jt, strategy, [np.zeros(nb, np.uint8)], [pv])           # a side that is all NULL
+
+
+@pytest.mark.parametrize("jt", [N.JT_INNER, N.JT_LEFT, N.JT_FULL])
+def test_surrogate_collisions_are_repaired(ctx, jt):
+    """The composite key travels as a 64-bit surrogate; every emitted pair is verified against the real columns and a false pair
+    (probability 2^-64 per candidate pair) is removed -- in an outer join its rows get their unmatched pairs back.  The knob
+    narrows the surrogate so that false pairs actually happen (a handful, below the repair's capacity of 64)."""
+    rng = np.random.default_rng(23)
+    nb, npr = 3000, 3000
+    b = [np.arange(nb) * 2, rng.integers(0, 5, nb)]                        # build keys even, probe keys odd in column 0: NOTHING really matches ...
+    p = [np.arange(npr) * 2 + 1, rng.integers(0, 5, npr)]
+    _multi_check(ctx, b, p, jt, N.JOIN_RADIX_HASH, knobs={"GOLAP_GJ_HASH_BITS": "19"})      # ... but ~17 surrogates collide
+    b[0][:100] = p[0][:100]                                                # a few true matches beside the false ones
+    b[1][:100] = p[1][:100]
+    _multi_check(ctx, b, p, jt, N.JOIN_BROADCAST_HASH, knobs={"GOLAP_GJ_HASH_BITS": "20"})
+
+
+def test_composite_key_join_large_radix(ctx):
+    """4M x 6M rows, two key columns, through the radix path (surrogates are 64-bit: the 64-bit-row pipeline) -- device-checked."""
+    n, m = 4_000_000, 6_000_000
+    rng = np.random.default_rng(5)
+    b = [np.arange(n) % 100_000, np.arange(n) // 100_000]                  # unique (c0, c1) pairs
+    pi = rng.integers(0, n, m)
+    p = [b[0][pi], b[1][pi]]
+    _multi_check(ctx, b, p, N.JT_INNER, N.JOIN_RADIX_HASH)

@@ -168,11 +168,65 @@ def test_scan_sort_projection_passthrough(ctx):
     assert out[0].schema.names == ["b", "lit(7)"] and out[0].column(1).to_pylist() == [7, 7, 7]
 
 
-def test_null_values_become_zero(ctx):
-    """record_batch_convert.rs:102-110: nulls are replaced by 0 on the way to the device."""
-    batch = pa.RecordBatch.from_arrays([pa.array([5, None, 25], pa.int64())], names=["a"])
+def test_filter_null_is_not_true(ctx):
+    """SQL semantics on the roadmap of the reference (README.md:411): a comparison with NULL is not true.  The reference's ingest
+    turns NULL into 0 (record_batch_convert.rs:102-110), which WOULD pass `a < 10`; here the byte-per-row validity
+    (column_buffer.rs:59-60) reaches the kernel and the NULL row is dropped.  NULLs in other columns travel through as Arrow nulls."""
+    batch = pa.RecordBatch.from_arrays([pa.array([5, None, 25, 7], pa.int64()), pa.array([1.5, 2.5, None, None], pa.float64())], names=["a", "b"])
     out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(0, "a"), "<", O.Literal("10"))), ctx)
-    assert out[0].column(0).to_pylist() == [5, 0]
+    assert out[0].column(0).to_pylist() == [5, 7] and out[0].column(1).to_pylist() == [1.5, None]
+    out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(0, "a"), "!=", O.Literal("5"))), ctx)
+    assert out[0].column(0).to_pylist() == [25, 7]                     # NULL != 5 is not true either
+    out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(0, "a"), ">=", O.Literal("0"))), ctx)
+    assert out[0].column(0).to_pylist() == [5, 25, 7] and out[0].column(1).null_count == 2
+
+
+def _materialise(pairs, cols_left, cols_right):
+    """expected output rows of a join from canonical (build, probe) pairs; None where the side is missing or the source is NULL"""
+    rows = []
+    for b, p in pairs:
+        rows.append(tuple((None if b == 0xFFFFFFFF else c[int(b)]) for c in cols_left) + tuple((None if p == 0xFFFFFFFF else c[int(p)]) for c in cols_right))
+    return rows
+
+
+@pytest.mark.parametrize("jt,code", [("Inner", 0), ("Left", 1), ("Right", 2), ("Full", 3)])
+def test_hash_join_null_keys_match_nothing(ctx, jt, code):
+    """A NULL key matches nothing -- not key 0 (what the reference's ingest would have made of it), not another NULL -- and an
+    outer join keeps the row as unmatched."""
+    lk = [1, None, 0, 3, None, 7]
+    lp = [10.0, 11.0, 12.0, None, 14.0, 15.0]
+    rk = [0, None, 3, 3, 9, None, 1]
+    rp = [100, 101, 102, 103, 104, 105, None]
+    left = pa.RecordBatch.from_arrays([pa.array(lk, pa.int64()), pa.array(lp, pa.float64())], names=["id", "lpay"])
+    right = pa.RecordBatch.from_arrays([pa.array(rk, pa.int64()), pa.array(rp, pa.int64())], names=["fk", "rpay"])
+    out = O.execute(O.GpuHashJoin(O.Batches([left]), O.Batches([right]), [O.Column(0, "id")], [O.Column(0, "fk")], join_type=jt), ctx)
+    bv, pv = np.array([x is not None for x in lk], np.uint8), np.array([x is not None for x in rk], np.uint8)
+    pairs, m = oracle.hash_join_multi([np.array([x or 0 for x in lk])], [np.array([x or 0 for x in rk])], code, [bv], [pv])
+    exp = _materialise(pairs, [lk, lp], [rk, rp])
+    got = list(zip(*[out[0].column(i).to_pylist() for i in range(4)])) if out and out[0].num_rows else []
+    assert got == exp
+
+
+def test_hash_join_composite_key(ctx):
+    """left_keys / right_keys are vectors (physical_plan.rs:35-36); the reference executor reads [0] only (executor.rs:245).  Two key
+    columns over two batches per side, with a NULL in the second key column: every column must be equal and non-NULL."""
+    rng = np.random.default_rng(4)
+    n, m = 3000, 4000
+    l0, l1 = rng.integers(0, 40, n), rng.integers(0, 25, n)
+    r0, r1 = rng.integers(0, 40, m), rng.integers(0, 25, m)
+    l1m = [None if i % 97 == 0 else int(v) for i, v in enumerate(l1)]
+    lpay, rpay = rng.random(n), rng.integers(0, 10**6, m)
+    mk = lambda a, b, c, names, lo, hi: pa.RecordBatch.from_arrays([pa.array(a[lo:hi], pa.int64()), pa.array(b[lo:hi], pa.int64()), pa.array(c[lo:hi])], names=names)
+    left = O.Batches([mk(l0, l1m, lpay, ["a", "b", "lp"], 0, 1000), mk(l0, l1m, lpay, ["a", "b", "lp"], 1000, n)])
+    right = O.Batches([mk(r0, list(map(int, r1)), rpay, ["x", "y", "rp"], 0, 2500), mk(r0, list(map(int, r1)), rpay, ["x", "y", "rp"], 2500, m)])
+    out = O.execute(O.GpuHashJoin(left, right, [O.Column(0, "a"), O.Column(1, "b")], [O.Column(0, "x"), O.Column(1, "y")]), ctx)
+    bv = np.array([x is not None for x in l1m], np.uint8)
+    pairs, cnt = oracle.hash_join_multi([l0, np.array([x or 0 for x in l1m])], [r0, r1], 0, [None, bv], None)
+    assert out[0].num_rows == cnt
+    bi, pi = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    assert np.array_equal(out[0].column(0).to_numpy(), l0[bi]) and np.array_equal(out[0].column(1).to_numpy(), l1[bi])
+    assert np.array_equal(out[0].column(2).to_numpy(), lpay[bi]) and np.array_equal(out[0].column(5).to_numpy(), rpay[pi])
+    assert np.array_equal(out[0].column(0).to_numpy(), out[0].column(3).to_numpy()) and np.array_equal(out[0].column(1).to_numpy(), out[0].column(4).to_numpy())
 
 
 def test_aggregate_group_by_sparse_and_negative_keys(ctx):
