@@ -1848,7 +1848,9 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
                                 (const void*)k_part1_narrow<24, 12288, false, false>, (const void*)k_part1_narrow<18, 18432, true, false, 1>,
                                 (const void*)k_part1_narrow<18, 18432, true, false, 2>, (const void*)k_part1_narrow<18, 18432, true, false, 3>};
             for (const void* f : p1) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part1_narrow_lds_bytes(PT_MAX_F, 18432)));
-            const void* p2[] = {(const void*)k_part2_ring<4, 32, true>, (const void*)k_part2_ring<4, 32, false>, (const void*)k_part2_ring<2, 32, false>, (const void*)k_part2_ring<4, 32, false, 2>};
+            const void* p2[] = {(const void*)k_part2_ring<4, 32, true>, (const void*)k_part2_ring<4, 64, true>, (const void*)k_part2_ring<4, 128, true>,
+                                (const void*)k_part2_ring<4, 256, true>, (const void*)k_part2_ring<4, 32, false>, (const void*)k_part2_ring<4, 64, false>,
+                                (const void*)k_part2_ring<4, 128, false>, (const void*)k_part2_ring<4, 256, false>, (const void*)k_part2_ring<4, 32, false, 2>};
             for (const void* f : p2) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_ring_lds_bytes(P2R_MAX_F, 32)));
         }
         const void* wcn[] = {(const void*)k_scatter_wc<1, false, 16, true>, (const void*)k_scatter_wc<2, false, 16, true>,
@@ -1966,13 +1968,21 @@ static void launch_part1_narrow(hipStream_t st, uint64_t in_keys, uint32_t rid_b
 // last pass of the narrow pipeline: per-bucket LDS rings (k_part2_ring); F <= P2R_MAX_F
 static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint64_t out_rows, const PassCfg& cfg, const FixedArgs& fx, const SegSrc& seg) {
     const int v2 = p2r_variant();
-#define GOLAP_P2R(RPT, ASM, ...)                                                                                                          \
-    hipLaunchKernelGGL((k_part2_ring<RPT, 32, ASM, ##__VA_ARGS__>), dim3(G), dim3(P2R_THREADS), part2_ring_lds_bytes(cfg.F, 32), st, (const uint2*)in_rows, \
+    const uint32_t R = part2_ring_rows(cfg.F);
+#define GOLAP_P2R(RR, ASM, ...)                                                                                                           \
+    hipLaunchKernelGGL((k_part2_ring<4, RR, ASM, ##__VA_ARGS__>), dim3(G), dim3(P2R_THREADS), part2_ring_lds_bytes(cfg.F, RR), st, (const uint2*)in_rows, \
                        (uint2*)out_rows, cfg, fx, seg)
-    if (v2 == 902) GOLAP_P2R(4, false, 2);
-    else if (v2 == 4) GOLAP_P2R(4, false);
-    else if (v2 == 2) GOLAP_P2R(2, false);
-    else GOLAP_P2R(4, true);
+#define GOLAP_P2R_BY_R(ASM, ...)                                                                                                          \
+    do {                                                                                                                                  \
+        if (R == 32) GOLAP_P2R(32, ASM, ##__VA_ARGS__);                                                                                   \
+        else if (R == 64) GOLAP_P2R(64, ASM, ##__VA_ARGS__);                                                                              \
+        else if (R == 128) GOLAP_P2R(128, ASM, ##__VA_ARGS__);                                                                            \
+        else GOLAP_P2R(256, ASM, ##__VA_ARGS__);                                                                                          \
+    } while (0)
+    if (v2 == 902) GOLAP_P2R(32, false, 2);       // timing-only diagnostic (scripts/ab_p12.py)
+    else if (v2 == 4) GOLAP_P2R_BY_R(false);      // plain loads and stores, hipcc's own waits (A/B reference)
+    else GOLAP_P2R_BY_R(true);
+#undef GOLAP_P2R_BY_R
 #undef GOLAP_P2R
 }
 

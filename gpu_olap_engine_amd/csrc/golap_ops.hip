@@ -860,7 +860,8 @@ int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint3
     if (n_specs == 0) return GOLAP_OK;
     if (!p->out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_ptr is null");
     if (p->n_groups == 0) return fail(ctx, GOLAP_ERR_INVALID_ARG, "n_groups must be >= 1");
-    if (!p->group_key_ptr && p->n_groups != 1) return fail(ctx, GOLAP_ERR_INVALID_ARG, "ungrouped aggregate needs n_groups == 1");
+    const bool hashed_empty = p->key_mode == GOLAP_KEYS_HASHED && p->n_rows == 0;   // (an empty key column may come without a pointer)
+    if (!p->group_key_ptr && p->n_groups != 1 && !hashed_empty) return fail(ctx, GOLAP_ERR_INVALID_ARG, "ungrouped aggregate needs n_groups == 1");
     if (p->key_dtype != GOLAP_DT_INT64 && p->key_dtype != GOLAP_DT_INT32) return fail(ctx, GOLAP_ERR_INVALID_ARG, "key_dtype must be INT64 or INT32");
     for (uint32_t i = 0; i < n_specs; ++i) {
         if (specs[i].func < GOLAP_AGG_SUM || specs[i].func > GOLAP_AGG_AVG) return fail(ctx, GOLAP_ERR_INVALID_ARG, "spec %u: bad func %d", i, specs[i].func);
@@ -1135,9 +1136,16 @@ template <typename KeyT>
 __global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict__ keys, unsigned long long n, const long long* __restrict__ table,
                                                           const uint32_t* __restrict__ ids, uint32_t mask, uint32_t cap, uint32_t n_groups,
                                                           uint32_t* __restrict__ slot_out) {
-    __shared__ volatile long long s_key[HK_CACHE];   // (volatile: the reader's two looks at the key must be two loads)
+    // direct-mapped cache of (key, id) in LDS.  An entry is two words, so it carries a version (a seqlock): a writer takes the
+    // entry by moving the version from even to odd with ONE compare-and-swap (lanes of one wave that want the same entry are
+    // serialised by the LDS atomic: one wins, the others go without caching), stores key and id, and releases it with version + 2;
+    // a reader uses the entry only if the version is even and unchanged around its two reads.  (The first form published
+    // "key = EMPTY, id, key" with plain stores from every lane: two lanes of one wave with different keys for the same entry
+    // write in the same instructions, and the 8-byte key store and the 4-byte id store need not pick the same winner.)
+    __shared__ volatile long long s_key[HK_CACHE];
     __shared__ volatile uint32_t s_id[HK_CACHE];
-    for (uint32_t i = threadIdx.x; i < HK_CACHE; i += OP_THREADS) s_key[i] = HK_EMPTY;
+    __shared__ uint32_t s_ver[HK_CACHE];
+    for (uint32_t i = threadIdx.x; i < HK_CACHE; i += OP_THREADS) { s_key[i] = HK_EMPTY; s_ver[i] = 0; }
     __syncthreads();
     const uint32_t used = ids[cap];
     for (unsigned long long i = (unsigned long long)blockIdx.x * OP_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * OP_THREADS) {
@@ -1148,20 +1156,23 @@ __global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict
         } else {
             const uint32_t h = hk_hash(key, mask);
             const uint32_t c = h & (HK_CACHE - 1);
-            // the cache entry is (key, id) written as two words: take the id only if the key matches before AND after reading it
+            const uint32_t v1 = __hip_atomic_load(&s_ver[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const long long ck = s_key[c];
             const uint32_t cid = s_id[c];
-            if (ck == key && s_key[c] == key) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t v2 = __hip_atomic_load(&s_ver[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v1 == v2 && !(v1 & 1u) && ck == key) {
                 id = cid;
             } else {
                 uint32_t s = h, probes = 0;
                 while (table[s] != key && probes <= mask) { s = (s + 1) & mask; ++probes; }   // (the key is there unless the table overflowed)
                 id = ids[s];
-                s_key[c] = HK_EMPTY;   // invalidate, publish the id, publish the key: a reader never pairs a key with another key's id
-                __threadfence_block();
-                s_id[c] = id;
-                __threadfence_block();
-                s_key[c] = key;
+                if (!(v2 & 1u) && atomicCAS(&s_ver[c], v2, v2 + 1u) == v2) {
+                    s_key[c] = key;
+                    s_id[c] = id;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(&s_ver[c], v2 + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         slot_out[i] = id < n_groups ? id : id % n_groups;   // (ids beyond the bound only occur when the bound was too small: results are void, stay in range)
@@ -1169,7 +1180,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict
 }
 
 static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st) {
-    if (!p->group_key_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "GOLAP_KEYS_HASHED needs a group key column");
+    if (!p->group_key_ptr && p->n_rows) return fail(ctx, GOLAP_ERR_INVALID_ARG, "GOLAP_KEYS_HASHED needs a group key column");
     if (p->n_groups > (1u << 23)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^23 groups (key table of 2^24 entries)");
     if (p->n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^32-16 rows");
     uint32_t cap = 1024;

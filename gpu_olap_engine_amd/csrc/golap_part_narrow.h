@@ -298,7 +298,10 @@ constexpr int P2R_THREADS = 1024;
 constexpr int P2R_LINE = 16;     // rows per 128-byte line
 constexpr int P2R_MAX_F = 512;
 
-static inline size_t part2_ring_lds_bytes(uint32_t F, uint32_t R) { return (size_t)F * R * 8 + (size_t)F * 8 + 64 + 3 * 64 * 4; }
+static inline size_t part2_ring_lds_bytes(uint32_t F, uint32_t R) { return (size_t)F * R * 8 + (size_t)F * 12 + 64 + 3 * 64 * 4; }
+// ring length for a fan-out: F * R = 16384 rows of LDS (128 KiB) whatever the fan-out -- a tile brings TILE / F rows per bucket,
+// and a ring must hold that on top of an unfinished line (R = 32 at F = 512 ... 256 at F <= 64)
+static inline uint32_t part2_ring_rows(uint32_t F) { return F >= 512 ? 32u : F >= 256 ? 64u : F >= 128 ? 128u : 256u; }
 
 // Rows of a group: one extent of the previous pass's output (fx.groups), or -- after a partition exchange -- one segment
 // per source rank (SegSrc: row offsets relative to in_rows, [group][source]); the rings do not care where rows come from.
@@ -313,15 +316,18 @@ template <int RPT, int R, bool ASM, int DIAG = 0>   // DIAG 2: timing-only build
 __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_part2_ring(const uint2* __restrict__ in_rows, uint2* __restrict__ out_rows, PassCfg cfg, FixedArgs fx,
                                                             SegSrc seg) {
     constexpr int NT = P2R_THREADS, TILE = NT * RPT, LINE = P2R_LINE;
-    constexpr int FLUSH_ITERS = P2R_MAX_F / (NT / LINE);   // buckets per 16-lane group (ASM: always this many store instructions per flush)
-    static_assert((R & (R - 1)) == 0 && R >= 2 * LINE, "ring geometry");
+    constexpr int FLUSH_ITERS = P2R_MAX_F / (NT / LINE);   // line items per 16-lane group (ASM: always this many store instructions per flush)
+    constexpr int LPB = R / (2 * LINE);                    // lines a bucket gets per regular flush (half a ring); F * LPB <= 512 line items
+    constexpr int FB = 4;                                  // line items whose LDS reads are in flight together (8 would spill at 96 VGPRs)
+    static_assert((R & (R - 1)) == 0 && R >= 2 * LINE && R <= 256, "ring geometry");
     static_assert(!ASM || 2 * RPT <= P2R_FIXED_PAIRS, "two tiles of hidden loads in the fixed registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t F = cfg.F;
     uint2* s_ring = reinterpret_cast<uint2*>(s_raw);                          // [F][R]
     uint32_t* s_wr = reinterpret_cast<uint32_t*>(s_raw + (size_t)F * R * 8);  // [F] rows that have taken a position so far
-    uint32_t* s_rd = s_wr + F;                                                // [F] rows written out so far (multiple of LINE)
-    uint32_t* s_flag = s_rd + F;                                              // [2] "rows are pending" (alternating)
+    uint32_t* s_rd2 = s_wr + F;                                               // [2][F] rows written out so far (multiple of LINE): a flush reads one
+                                                                              // copy and writes the other (several 16-lane groups serve one bucket)
+    uint32_t* s_flag = s_rd2 + 2 * F;                                         // [2] "rows are pending" (alternating)
     uint32_t* s_poff = s_flag + 2;                                            // [n_pieces] first row of the piece
     uint32_t* s_plen = s_poff + P2R_MAX_SRC;                                  // [n_pieces] rows of the piece
     uint32_t* s_pend = s_plen + P2R_MAX_SRC;                                  // [n_pieces] tiles up to and including the piece
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
             s_poff[s] = o; s_plen[s] = l; s_pend[s] = tiles;
         }
     }
-    if (tid < F) { s_wr[tid] = 0; s_rd[tid] = 0; }
+    if (tid < F) { s_wr[tid] = 0; s_rd2[tid] = 0; s_rd2[F + tid] = 0; }
     if (tid < 2) s_flag[tid] = 0;
     lds_barrier();
     const uint32_t n_tiles = s_pend[n_pieces - 1];
@@ -393,27 +399,52 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
     // bank rotation of a bucket's ring: neighbouring buckets (flushed by one 32-lane group) start on opposite halves
     auto ring_at = [&](uint32_t b, uint32_t p) -> uint32_t { return b * R + ((p + ((b & 1u) << 4)) & (uint32_t)(R - 1)); };
     uint32_t it = 0;
-    // complete lines of every bucket leave the rings; `fin`: also the unfinished last line
+    uint32_t cur = 0;                                    // which copy of s_rd2 is current (flips behind every regular flush)
+    const uint32_t lgF = 31u - (uint32_t)__builtin_clz(F);
+    // complete lines of every bucket leave the rings; `fin`: also the unfinished last line (no s_rd update: nothing follows)
     auto flush = [&](bool fin) {
         const uint32_t q = tid >> 4, l = tid & 15;
+        const uint32_t* s_rd = s_rd2 + cur * F;
+        uint32_t* s_rd_next = s_rd2 + (cur ^ 1u) * F;
         if (ASM && !fin) {
-#pragma unroll 2
-            for (int j = 0; j < FLUSH_ITERS; ++j) {   // fixed trip count, one (predicated) store instruction per iteration at uniform control flow
-                const uint32_t b = q + (uint32_t)j * (NT / LINE);
-                const bool live = b < F;
-                const uint32_t bc = live ? b : 0u;
-                const uint32_t wr = s_wr[bc], rd = s_rd[bc];
-                uint32_t end = wr < cap ? wr : cap;
-                if (end > rd + R) end = rd + R;
-                end = rd + ((end - rd) & ~(uint32_t)(LINE - 1));
-                uint2* __restrict__ dst = out_rows + slot0 + bc * cap;
-                const uint2 row = s_ring[ring_at(bc, rd + l)];
-                st8_hidden_if(dst + rd + l, u32x2{row.x, row.y}, (live && end != rd) ? 1u : 0u);
-                if (__ballot(live && end - rd > (uint32_t)LINE) != 0ull) {   // rare: a second complete line (extra stores only make the counted wait stricter)
-                    const uint2 row2 = s_ring[ring_at(bc, rd + LINE + l)];
-                    st8_hidden_if(dst + rd + LINE + l, u32x2{row2.x, row2.y}, (live && end - rd > (uint32_t)LINE) ? 1u : 0u);
+            // FLUSH_ITERS line items per 16-lane group, FB at a time: all their cursor reads are issued together, then all their
+            // ring reads, then the (predicated) stores -- two LDS round trips per batch instead of two per item (the reads of s_rd
+            // and the writes of the other copy cannot alias, so nothing orders them)
+#pragma unroll 1
+            for (int j0 = 0; j0 < FLUSH_ITERS; j0 += FB) {
+                uint32_t wr[FB], rd[FB], nl[FB];
+                uint2 row[FB];
+                auto bucket_of_item = [&](int j) -> uint32_t { return (q + (uint32_t)(j0 + j) * (NT / LINE)) & (F - 1u); };   // line li of bucket b's complete lines
+                auto line_of_item = [&](int j) -> uint32_t { return (q + (uint32_t)(j0 + j) * (NT / LINE)) >> lgF; };
+#pragma unroll
+                for (int j = 0; j < FB; ++j) {
+                    wr[j] = s_wr[bucket_of_item(j)];
+                    rd[j] = s_rd[bucket_of_item(j)];
                 }
-                if (l == 0 && live && end != rd) s_rd[bc] = end;
+#pragma unroll
+                for (int j = 0; j < FB; ++j) {
+                    uint32_t end = wr[j] < cap ? wr[j] : cap;
+                    if (end > rd[j] + R) end = rd[j] + R;
+                    nl[j] = line_of_item(j) < (uint32_t)LPB ? (end - rd[j]) / (uint32_t)LINE : 0u;   // (items beyond F * LPB: no lines)
+                    row[j] = s_ring[ring_at(bucket_of_item(j), rd[j] + line_of_item(j) * (uint32_t)LINE + l)];
+                }
+                bool extra = false;
+#pragma unroll
+                for (int j = 0; j < FB; ++j) {   // one store instruction per item at uniform control flow
+                    const uint32_t b = bucket_of_item(j), li = line_of_item(j);
+                    st8_hidden_if(out_rows + slot0 + b * cap + rd[j] + li * (uint32_t)LINE + l, u32x2{row[j].x, row[j].y}, li < nl[j] ? 1u : 0u);
+                    extra |= li + (uint32_t)LPB < nl[j];
+                    if (l == 0 && li == 0) s_rd_next[b] = rd[j] + nl[j] * (uint32_t)LINE;   // (every bucket has its item li = 0)
+                }
+                if (__ballot(extra) != 0ull) {   // rare: more than half a ring of complete lines (extra stores only make the counted wait stricter)
+#pragma unroll
+                    for (int j = 0; j < FB; ++j) {
+                        const uint32_t b = bucket_of_item(j), li = line_of_item(j);
+                        const uint32_t p1 = rd[j] + (li + (uint32_t)LPB) * (uint32_t)LINE + l;
+                        const uint2 row2 = s_ring[ring_at(b, p1)];
+                        st8_hidden_if(out_rows + slot0 + b * cap + p1, u32x2{row2.x, row2.y}, li + (uint32_t)LPB < nl[j] ? 1u : 0u);
+                    }
+                }
             }
             return;
         }
@@ -425,12 +456,12 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
             uint2* __restrict__ dst = out_rows + slot0 + b * cap;
             if (DIAG != 2)
                 for (uint32_t p = rd + l; p < end; p += LINE) dst[p] = s_ring[ring_at(b, p)];   // 16 lanes x 8 B = one 128-byte line
-            if (l == 0 && end != rd) s_rd[b] = end;
+            if (l == 0) s_rd_next[b] = end;
         }
     };
     auto place = [&](uint32_t key, uint32_t rid, uint32_t b, uint32_t pos) -> bool {   // true when the row stays pending
         if (pos >= cap) return false;                         // slot overflow: dropped, flag raised at the end
-        if (pos - s_rd[b] >= (uint32_t)R) return true;
+        if (pos - s_rd2[cur * F + b] >= (uint32_t)R) return true;
         s_ring[ring_at(b, pos)] = make_uint2(key, rid);
         return false;
     };
@@ -458,9 +489,18 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
                 pos[r] = atomicAdd(&s_wr[bk[r]], 1u);
             }
         }
+        {   // (the cursor reads of all rows first: hipcc cannot tell that the ring writes do not alias them and would order each read
+            //  behind the previous row's write)
+            uint32_t rdv[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r)
-            if (bk[r] != 0xFFFFFFFFu && place(key[r], rid[r], bk[r], pos[r])) pend |= 1u << r;
+            for (int r = 0; r < RPT; ++r) rdv[r] = s_rd2[cur * F + (bk[r] != 0xFFFFFFFFu ? bk[r] : 0u)];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (bk[r] == 0xFFFFFFFFu || pos[r] >= cap) continue;          // no row / slot overflow: dropped, flag raised at the end
+                if (pos[r] - rdv[r] >= (uint32_t)R) pend |= 1u << r;          // ring full: placed after the flush
+                else s_ring[ring_at(bk[r], pos[r])] = make_uint2(key[r], rid[r]);
+            }
+        }
         if (__ballot(pend != 0) != 0ull && lane == 0) s_flag[it & 1] = 1;
         lds_barrier();                       // ring rows + pending flag visible
         load_tile(set, t, k + 2);            // this tile's registers are free: the tile after next streams in behind two flushes
@@ -469,7 +509,8 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
             const bool more = s_flag[it & 1] != 0;
             if (tid == 0) s_flag[(it + 1) & 1] = 0;
             ++it;
-            lds_barrier();                       // rings drained (s_rd advanced), the other flag cleared
+            cur ^= 1u;
+            lds_barrier();                       // rings drained (the other copy of s_rd holds the advanced positions), the other flag cleared
             if (!more) break;                    // work-group-uniform
 #pragma unroll
             for (int r = 0; r < RPT; ++r)

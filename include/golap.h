@@ -404,7 +404,7 @@ typedef struct golap_aggregate_params {             /* aggregate_kernel.rs:47-58
                                     (aggregate_kernel.rs:76-77 "global-memory hash table with open addressing") gives every distinct key a dense
                                     slot, then the dense path runs on the slots.  n_groups = upper bound on the number of distinct keys. */
     int32_t  reserved0;
-    uint64_t out_keys_ptr;       /* HASHED: device int64[n_groups]: the key that owns each slot (slots are numbered in table order: reproducible) */
+    uint64_t out_keys_ptr;       /* HASHED: device int64[n_groups]: the key that owns each slot (one slot per distinct key; which slot is unspecified, like the row order of GROUP BY) */
     uint64_t out_n_groups_ptr;   /* HASHED: device u32: distinct keys found.  A value above n_groups means the bound was too small: the outputs
                                     are then meaningless (memory-safe) and the call must be repeated with a larger n_groups. */
 } golap_aggregate_params;

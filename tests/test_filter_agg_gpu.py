@@ -216,7 +216,7 @@ def _hashed_check(ctx, keys, vals, bound):
     out, counts, skeys = out.cpu().numpy()[:, :nd], counts.cpu().numpy()[:nd], skeys.cpu().numpy()[:nd]
     order = np.argsort(skeys, kind="stable")
     assert np.array_equal(skeys[order], ok)                      # every distinct key owns exactly one slot
-    assert np.array_equal(out[:, order].T, ost)                  # sum, count, min, max, avg per key: bit-exact
+    np.testing.assert_array_equal(out[:, order].T, ost)          # sum, count, min, max, avg per key: bit-exact
     assert np.array_equal(counts[order].astype(np.float64), ost[:, 1])
     return skeys
 
@@ -235,7 +235,9 @@ def test_hashed_group_by_any_keys(ctx, key_dtype, n_distinct):
     vals = rng.integers(-2048, 2048, n).astype(np.float64)
     s1 = _hashed_check(ctx, keys, vals, bound=max(8, 2 * pool.size))
     s2 = _hashed_check(ctx, keys[::-1].copy(), vals[::-1].copy(), bound=max(8, 2 * pool.size))
-    assert np.array_equal(s1, s2)                                # slot numbering is the table order: independent of the row order
+    # (slot numbering is the key table's order: which of two colliding keys gets the earlier entry depends on who inserts first, so
+    #  it is NOT a function of the key set alone -- like SQL, GROUP BY promises no order; the slot_keys column says who is where)
+    assert np.array_equal(np.sort(s1), np.sort(s2))
 
 
 def test_hashed_group_by_reports_a_bound_that_is_too_small(ctx):
@@ -243,7 +245,7 @@ def test_hashed_group_by_reports_a_bound_that_is_too_small(ctx):
     keys = np.arange(n, dtype=np.int64) * 7919 - 12345
     vals = np.ones(n)
     out, skeys, nd = ctx.aggregate([(N.AGG_SUM, 0)], [dev(vals)], group_keys=dev(keys), n_groups=1000, hashed=True)
-    assert int(nd.item()) > 1000                                 # (2^32-1 when even the table overflowed): the caller must retry with a larger bound
+    assert (int(nd.item()) & 0xFFFFFFFF) > 1000                  # (2^32-1 when even the table overflowed): the caller must retry with a larger bound
     _hashed_check(ctx, keys, vals, bound=n)
 
 

@@ -15,7 +15,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gpu_olap_engine_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-KERNELS = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0E", "k_part1_narrowILi16ELi16384ELb1ELb1ELi0E", "k_part2_ringILi4ELi32ELb1ELi0E"]
+KERNELS = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0E", "k_part1_narrowILi16ELi16384ELb1ELb1ELi0E", "k_part2_ringILi4ELi32ELb1ELi0E",
+           "k_part2_ringILi4ELi64ELb1ELi0E", "k_part2_ringILi4ELi128ELb1ELi0E", "k_part2_ringILi4ELi256ELb1ELi0E"]
 
 
 @pytest.fixture(scope="module")

@@ -440,7 +440,10 @@ def _split_api_case(ctx, narrow):
         parts[name] = [ctx.radix_partition(torch.from_numpy(keys[r * h:(r + 1) * h]).cuda(), rid_base=r * h, n_owners=P, extra_bits=e1, narrow=narrow)
                        for r in range(P)]
     torch.cuda.synchronize()
-    assert not narrow or ctx.join_partitioned_narrow_ok(((256 // P) << e1), P, 8 + e1, n // P)
+    # (golap_join_partitioned_narrow_ok is a context-free query: it answers for the production rule -- tuple local passes exist
+    #  from fan-out 32, i.e. from ~25M rows per rank -- and cannot see the per-context knob that forces them in this small case)
+    assert not ctx.join_partitioned_narrow_ok(((256 // P) << e1), P, 8 + e1, n // P)
+    assert ctx.join_partitioned_narrow_ok(((256 // P) << e1), P, 8 + e1, 500_000_000)
     allpairs = []
     for owner in range(P):
         sides = {}
