@@ -2187,8 +2187,8 @@ static int32_t broadcast_hash_join(golap_ctx* ctx, const golap_join_params* p, h
 //                 different composite keys (or a NULL row and a real key) collide with probability 2^-64 per candidate pair,
 //                 i.e. ~0.05 expected false pairs in a 1B x 1B join -- rare, not never.  False pairs are recorded (<= 64);
 //   k_repair_scan / k_repair_fix (no-ops unless a false pair was found): the false pair is removed; in an outer join a row
-//                 that thereby lost its only match gets its unmatched pair.  More than 64 false pairs: status GOLAP_ERR_CAPACITY
-//                 is raised through the count word's companion (never seen in practice; the probability is < 1e-60).
+//                 that thereby lost its only match gets its unmatched pair.  More than 64 false pairs (probability < 1e-60 with
+//                 64-bit surrogates; reachable with the test knob): the count word is set to 2^64-1, an impossible count.
 // ---------------------------------------------------------------------------
 struct KeyCols {
     const long long* col[4];
@@ -2275,6 +2275,7 @@ __global__ __launch_bounds__(256) void k_gj_repair_scan(const uint2* __restrict_
 __global__ void k_gj_repair_fix(uint2* __restrict__ pairs, unsigned long long* __restrict__ count, unsigned long long max_pairs, int join_type,
                                 GjCtl* __restrict__ ctl) {
     if (blockIdx.x || threadIdx.x) return;
+    if (ctl->overflow) { *count = ~0ull; return; }   // more false pairs than can be repaired: an impossible count tells the caller (golap.h)
     const uint32_t nh = ctl->n_holes < GJ_MAX_HOLES ? ctl->n_holes : GJ_MAX_HOLES;
     if (nh == 0) return;
     unsigned long long cnt = *count;

@@ -121,6 +121,9 @@ static int32_t rccl_exchange(void* user, const golap_p2p_op* ops, uint32_t n_ops
 // (One 8 GB ncclSend/ncclRecv pair was observed to deliver wrong data on this stack -- round 1, scripts/dbg_sharded.py
 // CHECK_BIG -- and tests/test_sharded_gpu.py::test_rccl_message_size_boundary pins where that starts; bounded pieces
 // also let a transport pipeline them.)
+// default bound of one message: half of the largest size verified intact (1 GiB; see golap_comm_selftest)
+constexpr uint64_t SHARD_DEFAULT_MAX_MSG = 1ull << 29;
+
 static void split_message(int32_t peer, bool is_send, uint64_t ptr, uint64_t bytes, uint64_t max_msg, std::vector<golap_p2p_op>& ops) {
     for (uint64_t o = 0; o < bytes; o += max_msg) {
         golap_p2p_op op;
@@ -276,7 +279,7 @@ static int32_t ensure_host_words(golap_comm* cm, uint64_t bytes) {
 // ---------------------------------------------------------------------------
 static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, bool* failed) {
     const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2, nsub = sp.nsub;
-    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : (1ull << 30);
+    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : SHARD_DEFAULT_MAX_MSG;
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
     const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
     const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};
@@ -444,7 +447,7 @@ struct SlabHold {   // slabs that must outlive the workspace (the workspace is r
 
 static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st) {
     const uint32_t P = sp.world, me = (uint32_t)cm->rank, e1 = sp.e1, F1 = sp.F1, per = sp.per;
-    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : (1ull << 30);
+    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : SHARD_DEFAULT_MAX_MSG;
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
     const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
     const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};
@@ -647,7 +650,7 @@ int32_t golap_sharded_plan_get(uint32_t world, uint64_t n_build_total, uint64_t 
     out->buckets_per_rank = sp.per;
     out->local_bits = sp.local_bits;
     out->sub_ranges = sp.nsub;
-    const uint64_t mm = max_msg_bytes ? max_msg_bytes : (1ull << 30);
+    const uint64_t mm = max_msg_bytes ? max_msg_bytes : SHARD_DEFAULT_MAX_MSG;
     for (int side = 0; side < 2; ++side)
         for (uint32_t r = 0; r < world; ++r) {
             out->cap_rows[side][r] = sp.cap[side][r];

@@ -211,6 +211,9 @@ typedef struct golap_join_params {
                                       "null handling" is on the reference's roadmap): a row with a NULL in any key column matches nothing,
                                       and on the preserved side of an outer join it survives as an unmatched row */
     uint64_t probe_validity[4];
+    /* (Composite and NULL-aware joins run on 64-bit surrogate keys and verify every pair against the real columns; up to 64
+     * colliding candidate pairs -- expected 0.05 in a 1B x 1B join -- are repaired on the device.  Beyond that the count word is
+     * set to 2^64-1: an impossible count, never observed outside the test hook that narrows the surrogates.) */
 } golap_join_params;
 
 /* Join on int64 keys; row ids are 0-based positions + *_rid_base.  Pair
@@ -339,7 +342,7 @@ typedef struct golap_sharded_join_params {
     uint64_t out_pairs_ptr, out_count_ptr, max_pairs;   /* as golap_join_params; pairs carry global row ids */
     int32_t  join_type;                          /* as golap_join_params */
     int32_t  force_exact;                        /* != 0: skip the fast path */
-    uint64_t max_msg_bytes;                      /* 0 = 1 GiB: larger messages are split (both ends compute the same pieces) */
+    uint64_t max_msg_bytes;                      /* 0 = 512 MiB: larger messages are split (both ends compute the same pieces) */
 } golap_sharded_join_params;
 typedef struct golap_sharded_join_info {          /* what the last golap_sharded_join on this communicator did */
     uint32_t fast_path;          /* 1: the no-histogram tuple path produced the result */

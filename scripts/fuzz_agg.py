@@ -30,6 +30,7 @@ def main():
     rnd = 0
     while time.time() < t_end:
         rnd += 1
+        why = None
         size = rng.random()
         n = int(rng.integers(1, 50_000)) if size < 0.4 else int(rng.integers(50_000, 8_000_000)) if size < 0.9 else int(rng.integers(34_000_000, 45_000_000))
         G = int(rng.choice([1, 7, 300, 1024, 2340, 2341, 5000, 100_000, 1_000_003, 2_097_152, 3_000_000]))
@@ -57,7 +58,32 @@ def main():
         out, counts = out.cpu().numpy(), counts.cpu().numpy()
         present = counts > 0
         good = np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
-        # a filter on the same column
+        why = why or (None if good else "dense")
+        # the same rows through the key table (GOLAP_KEYS_HASHED): arbitrary keys, one slot per distinct key
+        if rng.random() < 0.4 and G <= 3_000_000:
+            hk = keys.astype(np.int64)
+            mode = rng.random()
+            if mode < 0.4:
+                hk = hk * int(rng.integers(1, 1 << 20)) - int(rng.integers(0, 1 << 40))      # sparse, negative
+            elif mode < 0.6 and kd is np.int64:
+                hk = hk ^ np.int64(-9223372036854775808)                                      # around INT64_MIN (the table's empty word)
+            if kd is np.int32:
+                hk = hk.astype(np.int32)
+            hk64 = hk.astype(np.int64)
+            ek, est = oracle.group_aggregate(hk64, vals.astype(np.float64))
+            bound = min(int(ek.size * rng.choice([1, 2, 5])) + int(rng.integers(0, 3)), 1 << 23)   # (the key table's limit)
+            ho, hc, hkeys, hn = ctx.aggregate(SPECS, [torch.from_numpy(vals).cuda()], group_keys=torch.from_numpy(hk).cuda(), n_groups=max(1, bound),
+                                              want_counts=True, hashed=True)
+            nd = int(hn.item()) & 0xFFFFFFFF
+            if bound >= ek.size:
+                sk = hkeys.cpu().numpy()[:nd]
+                order = np.argsort(sk, kind="stable")
+                good = good and nd == ek.size and np.array_equal(sk[order], ek) and np.array_equal(ho.cpu().numpy()[:, :nd][:, order].T, est)
+                why = why or (None if good else "hashed")
+            else:
+                good = good and nd > bound
+                why = why or (None if good else "hashed-bound")
+        # a filter on the same column (sometimes with NULLs)
         op = int(rng.integers(0, 6))
         lit = int(rng.integers(-2100, 2100))
         col = vals.astype(np.int64)
@@ -66,7 +92,22 @@ def main():
         idx, cnt = ctx.filter_compact(torch.from_numpy(col).cuda(), op, lit)
         k = int(cnt.item())
         good = good and np.array_equal(mask, exp_mask) and k == int(exp_mask.sum()) and np.array_equal(idx[:k].cpu().numpy().view(np.uint32), np.nonzero(exp_mask)[0].astype(np.uint32))
-        print(("ok   " if good else "FAIL ") + f"seed={seed} round={rnd} n={n} G={G} key={np.dtype(kd).name} shape={shape} val={'f64' if vf else 'i64'} env={env} op={op} lit={lit}", flush=True)
+        why = why or (None if good else "filter")
+        if rng.random() < 0.4:
+            kv = (rng.random(n) > 0.25).astype(np.uint8)
+            vv = (rng.random(n) > 0.25).astype(np.uint8)
+            em = exp_mask & (kv != 0)
+            tkv, tvv = torch.from_numpy(kv).cuda(), torch.from_numpy(vv).cuda()
+            m2 = ctx.filter_mask(torch.from_numpy(col).cuda(), op, lit, valid=tkv).cpu().numpy().astype(bool)
+            idx2, cnt2 = ctx.filter_compact(torch.from_numpy(col).cuda(), op, lit, valid=tkv)
+            k2 = int(cnt2.item())
+            fs = ctx.filter_sum(torch.from_numpy(col).cuda(), torch.from_numpy(vals).cuda(), op, lit, key_valid=tkv, value_valid=tvv).cpu().numpy()
+            good = good and np.array_equal(m2, em) and k2 == int(em.sum()) and np.array_equal(idx2[:k2].cpu().numpy().view(np.uint32), np.nonzero(em)[0].astype(np.uint32))
+            why = why or (None if good else "filter-null")
+            both = em & (vv != 0)                            # NULL values are skipped by the sum AND the count (SQL aggregates, golap.h)
+            good = good and fs[1] == float(both.sum()) and fs[0] == float(vals[both].astype(np.float64).sum())
+            why = why or (None if good else "filter-sum-null")
+        print(("ok   " if good else "FAIL ") + f"seed={seed} round={rnd} n={n} G={G} key={np.dtype(kd).name} shape={shape} val={'f64' if vf else 'i64'} env={env} op={op} lit={lit}" + (f" FAILED AT {why}" if why else ""), flush=True)
         if not good:
             sys.exit(1)
     print(f"fuzz: {rnd} rounds, all equal to the oracle", flush=True)

@@ -3,7 +3,8 @@ usage (GPU box): python scripts/fuzz_join.py SECONDS [SEED]
 
 Every round draws sizes, a key distribution, a join type, a strategy and (sometimes) experiment hooks that force the
 rarely-taken device paths (pass structures, no-histogram passes and their overflow fallbacks), runs the HIP join through the
-C ABI and compares the canonicalised pairs bit for bit with oracle.hash_join_outer.  Prints one line per round; exits 1 on the
+C ABI and compares the canonicalised pairs bit for bit with oracle.hash_join_outer (a third of the rounds: composite keys and
+NULLs against oracle.hash_join_multi).  Prints one line per round; exits 1 on the
 first mismatch with the recipe that reproduces it."""
 import os
 import sys
@@ -19,7 +20,7 @@ from gpu_olap_engine_amd import _native as N
 from gpu_olap_engine_amd.engine import Context
 from np_twin import canonical
 
-HOOKS = ["GOLAP_PASS_BITS", "GOLAP_RESERVE", "GOLAP_RESERVE_SIGMAS", "GOLAP_SLOT_SIGMAS", "GOLAP_NOHIST", "GOLAP_SCATTER"]
+HOOKS = ["GOLAP_PASS_BITS", "GOLAP_RESERVE", "GOLAP_RESERVE_SIGMAS", "GOLAP_SLOT_SIGMAS", "GOLAP_NOHIST", "GOLAP_SCATTER", "GOLAP_GJ_HASH_BITS"]
 
 
 def draw_keys(rng, n, kind, domain):
@@ -84,13 +85,40 @@ def main():
             _, ib, ip = np.intersect1d(ub, up, assume_unique=True, return_indices=True)
             if int((cb[ib].astype(np.int64) * cp[ip]).sum()) > 30_000_000:
                 continue
-        exp, me = oracle.hash_join_outer(b, p, jt)
-        recipe = f"seed={seed} round={rnd} nb={nb} np={npr} kind={kind} domain={domain} jt={jt} strategy={strategy} env={env}"
-        for k in HOOKS:
-            ctx.debug_set(k, env.get(k))
-        bt = torch.from_numpy(np.ascontiguousarray(b, dtype=np.int64)).cuda() if nb else torch.empty(0, dtype=torch.int64, device="cuda")
-        pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)).cuda() if npr else torch.empty(0, dtype=torch.int64, device="cuda")
-        pairs, cnt = ctx.join(bt, pt, max_pairs=max(1, me + 8), strategy=strategy, join_type=jt)
+        # a third of the rounds: composite keys (the first column split into 2..4) and / or NULLs
+        ncols, with_nulls = 1, False
+        if rng.random() < 0.33:
+            ncols = int(rng.integers(1, 5))
+            with_nulls = rng.random() < 0.6 or ncols == 1
+            if rng.random() < 0.25 and nb and npr:   # narrow surrogates so that a handful of false pairs occur (<= 64 can be repaired)
+                env["GOLAP_GJ_HASH_BITS"] = str(int(min(63, max(8, np.ceil(np.log2(nb * npr / 4.0))))))
+        dt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda() if a.size else torch.empty(0, dtype=torch.from_numpy(a[:0]).dtype, device="cuda")
+        recipe = (f"seed={seed} round={rnd} nb={nb} np={npr} kind={kind} domain={domain} jt={jt} strategy={strategy} ncols={ncols} "
+                  f"nulls={with_nulls} env={env}")
+        if ncols > 1 or with_nulls:
+            def split(k):     # an injective split of one key into ncols columns (so the match structure is the single-column one)
+                k = np.ascontiguousarray(k, dtype=np.int64)
+                if ncols == 1:
+                    return [k]
+                cols = [(k >> (16 * i)) & 0xFFFF for i in range(ncols - 1)]
+                return [c - 300 for c in cols] + [k >> (16 * (ncols - 1))]
+            bc, pc = split(b), split(p)
+            bv = pv = None
+            if with_nulls:
+                mk = lambda n: [None if rng.random() < 0.3 else (rng.random(n) > 0.15).astype(np.uint8) for _ in range(ncols)]
+                bv, pv = mk(nb), mk(npr)
+            exp, me = oracle.hash_join_multi(bc, pc, jt, bv, pv)
+            for k in HOOKS:
+                ctx.debug_set(k, env.get(k))
+            tv = lambda v: None if v is None else [None if x is None else dt(x) for x in v]
+            pairs, cnt = ctx.join([dt(c) for c in bc], [dt(c) for c in pc], max_pairs=max(1, me + 72), strategy=strategy, join_type=jt,
+                                  build_valid=tv(bv), probe_valid=tv(pv))
+        else:
+            exp, me = oracle.hash_join_outer(b, p, jt)
+            for k in HOOKS:
+                ctx.debug_set(k, env.get(k))
+            pairs, cnt = ctx.join(dt(np.ascontiguousarray(b, dtype=np.int64)), dt(np.ascontiguousarray(p, dtype=np.int64)), max_pairs=max(1, me + 8),
+                                  strategy=strategy, join_type=jt)
         torch.cuda.synchronize()
         m = int(cnt.item())
         ok = m == me and np.array_equal(canonical(pairs[:m].cpu().numpy().view(np.uint32)), exp)

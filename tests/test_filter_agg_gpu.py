@@ -98,7 +98,8 @@ def test_filters_with_validity(ctx, op, n):
     c = int(cnt.item())
     assert np.array_equal(idx.cpu().numpy()[:c].view(np.uint32), np.flatnonzero(exp).astype(np.uint32))
     got = ctx.filter_sum(dev(col), dev(val), op, 0, key_valid=dev(kv), value_valid=dev(vv)).cpu().numpy()
-    assert got[1] == float(exp.sum()) and got[0] == float(val[exp & (vv != 0)].sum())
+    both = exp & (vv != 0)                                       # NULL values are skipped by the sum AND the count (SQL aggregates)
+    assert got[1] == float(both.sum()) and got[0] == float(val[both].sum())
     # no validity at all == all valid
     m0 = ctx.filter_mask(dev(col), op, 0).cpu().numpy()
     assert np.array_equal(m0, ctx.filter_mask(dev(col), op, 0, valid=dev(np.ones(n, np.uint8))).cpu().numpy())
