@@ -120,6 +120,8 @@ struct PassCfg {
                            //    owner-major, refined by e1 further hash bits
     uint32_t e1;           // extra bits of the first pass (F = 256 << e1)
     uint32_t owners_log2;  // log2(n_owners)
+    uint32_t pre_hashed;   // k_part1_narrow / k_part2_ring: the tuples' first word is hash_int32(key32 ^ key_hi) instead of key32 -- a
+                           // bijection of the key, so equality, partitions and the join are the same, and later passes need not hash
     const uint32_t* key_hi;   // tuple kernels only, may be null (= 0): the upper 32 bits every key of this join shares.  The tuples carry
                               // the LOWER 32 bits; hash_int64(key) = hash_int32(lo ^ hi) (join_kernels.cuh:37-41), so the partitions stay the
                               // reference's for any common upper half -- not just 0.

@@ -46,11 +46,11 @@ __device__ __forceinline__ void ld8_hidden(u32x2& v, const void* p) { asm volati
 // compiler-visible value ever lives in a register with a load in flight, so no copy, phi or reuse of such a register can exist
 // (the first form of that kernel returned the data as asm outputs: at a loop back edge hipcc copied the "loaded" pair to
 // another register right behind the load, and reused the original one as a store address -- a memory fault on the GPU).
-template <int SLOT> __device__ __forceinline__ void ld8_fixed(const void* p);
+template <int SLOT> __device__ __forceinline__ void ld8_fixed(const void* sbase, uint32_t off);   // sbase: work-group-uniform (SGPR pair), off: bytes
 template <int SLOT> __device__ __forceinline__ u32x2 ld8_take();
 #define GOLAP_FIXED_PAIR(SLOT, LO, HI)                                                                                            \
-    template <> __device__ __forceinline__ void ld8_fixed<SLOT>(const void* p) {                                                   \
-        asm volatile("global_load_dwordx2 v[" #LO ":" #HI "], %0, off" ::"v"(p) : "memory", "v" #LO, "v" #HI);                   \
+    template <> __device__ __forceinline__ void ld8_fixed<SLOT>(const void* sbase, uint32_t off) {                                 \
+        asm volatile("global_load_dwordx2 v[" #LO ":" #HI "], %0, %1" ::"v"(off), "s"(sbase) : "memory", "v" #LO, "v" #HI);      \
     }                                                                                                                              \
     template <> __device__ __forceinline__ u32x2 ld8_take<SLOT>() {                                                               \
         uint32_t x, y;                                                                                                             \
@@ -68,11 +68,11 @@ GOLAP_FIXED_PAIR(7, 118, 119)
 #undef GOLAP_FIXED_PAIR
 constexpr int P2R_FIXED_FIRST = 104, P2R_FIXED_PAIRS = 8;   // (tests/test_isa_audit.py reads these)
 template <int SET, int RPT, int R = 0>
-__device__ __forceinline__ void ld8_fixed_tile(const uint2* src, uint32_t tid, uint32_t tn, uint32_t nt) {
+__device__ __forceinline__ void ld8_fixed_tile(const uint2* sbase, uint32_t tid, uint32_t tn, uint32_t nt) {
     if constexpr (R < RPT) {
         const uint32_t i = (uint32_t)R * nt + tid;
-        ld8_fixed<SET * RPT + R>(src + (i < tn ? i : tn - 1));
-        ld8_fixed_tile<SET, RPT, R + 1>(src, tid, tn, nt);
+        ld8_fixed<SET * RPT + R>(sbase, (i < tn ? i : tn - 1) * 8u);
+        ld8_fixed_tile<SET, RPT, R + 1>(sbase, tid, tn, nt);
     }
 }
 template <int SET, int RPT, int R = 0>
@@ -88,6 +88,14 @@ __device__ __forceinline__ void st8_hidden_if(void* p, u32x2 v, uint32_t ok) {
     asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_store_dwordx2 %1, %2, off\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved)
                  : "v"(p), "v"(v), "v"(ok)
+                 : "memory", "vcc", "scc");
+}
+// the same with a work-group-uniform base (SGPR pair) and a 32-bit byte offset: no 64-bit address arithmetic per lane
+__device__ __forceinline__ void st8_hidden_if_s(void* sbase, uint32_t off, u32x2 v, uint32_t ok) {
+    unsigned long long saved;
+    asm volatile("v_cmp_ne_u32_e32 vcc, 0, %4\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(off), "v"(v), "s"(sbase), "v"(ok)
                  : "memory", "vcc", "scc");
 }
 // returning global atomic add of the active lanes (inactive lanes keep `ret`)
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     const uint32_t F = cfg.F;   // <= NT: one bucket per thread in the scan
     if (tid < F) s_cnt[tid] = 0;
     const uint32_t khi = __builtin_amdgcn_readfirstlane(key_hi_of(cfg));   // the upper key half this attempt stands on (see PassCfg::key_hi)
+    const bool emit_hash = cfg.pre_hashed != 0;
 
     // keys of the tile: kv[h] = (lo, hi) of key 2h, (lo, hi) of key 2h + 1
     u32x4 kv[(RPT + 1) / 2];
@@ -205,8 +214,10 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
             k32[r] = (r & 1) ? kv[r >> 1].z : kv[r >> 1].x;
             hi |= ((r & 1) ? kv[r >> 1].w : kv[r >> 1].y) ^ khi;   // clamped duplicates are real keys too
             br[r] = 0xFFFFFFFFu;
+            const uint32_t h = hash_int32((int32_t)(k32[r] ^ khi));                       // == hash_int64 of the whole key
+            if (emit_hash) k32[r] = h;       // the tuple carries the hash from here on (PassCfg::pre_hashed); work-group-uniform
             if (tile_pos(r) < tn) {
-                const uint32_t b = bucket_of(hash_int32((int32_t)(k32[r] ^ khi)), cfg);   // == hash_int64 of the whole key
+                const uint32_t b = bucket_of(h, cfg);
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);                    // b < 1024, rank < 32768
             }
         }
@@ -298,7 +309,7 @@ constexpr int P2R_THREADS = 1024;
 constexpr int P2R_LINE = 16;     // rows per 128-byte line
 constexpr int P2R_MAX_F = 512;
 
-static inline size_t part2_ring_lds_bytes(uint32_t F, uint32_t R) { return (size_t)F * R * 8 + (size_t)F * 12 + 64 + 3 * 64 * 4; }
+static inline size_t part2_ring_lds_bytes(uint32_t F, uint32_t R) { return (size_t)F * R * 8 + (size_t)F * 16 + 64 + 3 * 64 * 4; }
 // ring length for a fan-out: F * R = 16384 rows of LDS (128 KiB) whatever the fan-out -- a tile brings TILE / F rows per bucket,
 // and a ring must hold that on top of an unfinished line (R = 32 at F = 512 ... 256 at F <= 64)
 static inline uint32_t part2_ring_rows(uint32_t F) { return F >= 512 ? 32u : F >= 256 ? 64u : F >= 128 ? 128u : 256u; }
@@ -324,10 +335,14 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t F = cfg.F;
     uint2* s_ring = reinterpret_cast<uint2*>(s_raw);                          // [F][R]
-    uint32_t* s_wr = reinterpret_cast<uint32_t*>(s_raw + (size_t)F * R * 8);  // [F] rows that have taken a position so far
-    uint32_t* s_rd2 = s_wr + F;                                               // [2][F] rows written out so far (multiple of LINE): a flush reads one
-                                                                              // copy and writes the other (several 16-lane groups serve one bucket)
-    uint32_t* s_flag = s_rd2 + 2 * F;                                         // [2] "rows are pending" (alternating)
+    // [F] per bucket ONE 8-byte word: low = rows that have taken a position so far (wr), high = rows written out so far (rd, a
+    // multiple of LINE).  A row takes its position with one 64-bit returning LDS atomic that also tells it how far the ring
+    // has been drained.
+    unsigned long long* s_wrrd = reinterpret_cast<unsigned long long*>(s_raw + (size_t)F * R * 8);
+    uint32_t* s_snap = reinterpret_cast<uint32_t*>(s_wrrd + F);               // [2][F], rings longer than two lines only: the rd a flush works
+                                                                              // from (several 16-lane groups serve one bucket; one copy is read,
+                                                                              // the other written)
+    uint32_t* s_flag = s_snap + 2 * F;                                        // [2] "rows are pending" (alternating)
     uint32_t* s_poff = s_flag + 2;                                            // [n_pieces] first row of the piece
     uint32_t* s_plen = s_poff + P2R_MAX_SRC;                                  // [n_pieces] rows of the piece
     uint32_t* s_pend = s_plen + P2R_MAX_SRC;                                  // [n_pieces] tiles up to and including the piece
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
             s_poff[s] = o; s_plen[s] = l; s_pend[s] = tiles;
         }
     }
-    if (tid < F) { s_wr[tid] = 0; s_rd2[tid] = 0; s_rd2[F + tid] = 0; }
+    if (tid < F) { s_wrrd[tid] = 0ull; s_snap[tid] = 0; s_snap[F + tid] = 0; }
     if (tid < 2) s_flag[tid] = 0;
     lds_barrier();
     const uint32_t n_tiles = s_pend[n_pieces - 1];
@@ -355,6 +370,8 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
     // also drain the hidden prefetch)
     const uint32_t slot0 = __builtin_amdgcn_readfirstlane(fx.slot_base[g]), cap = __builtin_amdgcn_readfirstlane(fx.slot_cap[g]);
     const uint32_t khi = __builtin_amdgcn_readfirstlane(key_hi_of(cfg));
+    const bool hashed = cfg.pre_hashed != 0;   // the tuples carry hash_int32(key) instead of the key (k_part1_narrow wrote them so)
+    uint2* const out_group = out_rows + slot0;   // work-group-uniform base of every store of this group (byte offsets fit 32 bits)
     if (n_tiles == 0) {
         if (tid < F) { fx.sub_start[(size_t)g * F + tid] = slot0 + tid * cap; fx.sub_len[(size_t)g * F + tid] = 0; }
         return;
@@ -385,8 +402,8 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
         uint32_t row0, tn;
         locate(cur_load, k < n_tiles ? k : n_tiles - 1, row0, tn);
         if (k >= n_tiles) tn = 1;
-        const uint2* __restrict__ src = in_rows + row0;
-        if constexpr (ASM) ld8_fixed_tile<decltype(set)::value, RPT>(src, tid, tn, (uint32_t)NT);
+        const uint2* __restrict__ src = in_rows + __builtin_amdgcn_readfirstlane(row0);   // scalar base, 32-bit lane offsets
+        if constexpr (ASM) ld8_fixed_tile<decltype(set)::value, RPT>(src, tid, __builtin_amdgcn_readfirstlane(tn), (uint32_t)NT);
         else {
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
@@ -399,27 +416,27 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
     // bank rotation of a bucket's ring: neighbouring buckets (flushed by one 32-lane group) start on opposite halves
     auto ring_at = [&](uint32_t b, uint32_t p) -> uint32_t { return b * R + ((p + ((b & 1u) << 4)) & (uint32_t)(R - 1)); };
     uint32_t it = 0;
-    uint32_t cur = 0;                                    // which copy of s_rd2 is current (flips behind every regular flush)
+    uint32_t cur = 0;                                    // LPB > 1: which copy of s_snap is current (flips behind every regular flush)
     const uint32_t lgF = 31u - (uint32_t)__builtin_clz(F);
-    // complete lines of every bucket leave the rings; `fin`: also the unfinished last line (no s_rd update: nothing follows)
+    // complete lines of every bucket leave the rings; `fin`: also the unfinished last line (no cursor update: nothing follows)
     auto flush = [&](bool fin) {
         const uint32_t q = tid >> 4, l = tid & 15;
-        const uint32_t* s_rd = s_rd2 + cur * F;
-        uint32_t* s_rd_next = s_rd2 + (cur ^ 1u) * F;
+        const uint32_t* snap = s_snap + cur * F;
+        uint32_t* snap_next = s_snap + (cur ^ 1u) * F;
         if (ASM && !fin) {
             // FLUSH_ITERS line items per 16-lane group, FB at a time: all their cursor reads are issued together, then all their
-            // ring reads, then the (predicated) stores -- two LDS round trips per batch instead of two per item (the reads of s_rd
-            // and the writes of the other copy cannot alias, so nothing orders them)
+            // ring reads, then the (predicated) stores -- two LDS round trips per batch instead of two per item
 #pragma unroll 1
             for (int j0 = 0; j0 < FLUSH_ITERS; j0 += FB) {
                 uint32_t wr[FB], rd[FB], nl[FB];
                 uint2 row[FB];
                 auto bucket_of_item = [&](int j) -> uint32_t { return (q + (uint32_t)(j0 + j) * (NT / LINE)) & (F - 1u); };   // line li of bucket b's complete lines
-                auto line_of_item = [&](int j) -> uint32_t { return (q + (uint32_t)(j0 + j) * (NT / LINE)) >> lgF; };
+                auto line_of_item = [&](int j) -> uint32_t { return LPB == 1 ? 0u : (q + (uint32_t)(j0 + j) * (NT / LINE)) >> lgF; };
 #pragma unroll
                 for (int j = 0; j < FB; ++j) {
-                    wr[j] = s_wr[bucket_of_item(j)];
-                    rd[j] = s_rd[bucket_of_item(j)];
+                    const unsigned long long w = s_wrrd[bucket_of_item(j)];
+                    wr[j] = (uint32_t)w;
+                    rd[j] = LPB == 1 ? (uint32_t)(w >> 32) : snap[bucket_of_item(j)];
                 }
 #pragma unroll
                 for (int j = 0; j < FB; ++j) {
@@ -432,9 +449,12 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
 #pragma unroll
                 for (int j = 0; j < FB; ++j) {   // one store instruction per item at uniform control flow
                     const uint32_t b = bucket_of_item(j), li = line_of_item(j);
-                    st8_hidden_if(out_rows + slot0 + b * cap + rd[j] + li * (uint32_t)LINE + l, u32x2{row[j].x, row[j].y}, li < nl[j] ? 1u : 0u);
+                    st8_hidden_if_s(out_group, (b * cap + rd[j] + li * (uint32_t)LINE + l) * 8u, u32x2{row[j].x, row[j].y}, li < nl[j] ? 1u : 0u);
                     extra |= li + (uint32_t)LPB < nl[j];
-                    if (l == 0 && li == 0) s_rd_next[b] = rd[j] + nl[j] * (uint32_t)LINE;   // (every bucket has its item li = 0)
+                    if (l == 0 && li == 0) {   // (every bucket has its item li = 0)
+                        reinterpret_cast<uint32_t*>(s_wrrd + b)[1] = rd[j] + nl[j] * (uint32_t)LINE;
+                        if (LPB > 1) snap_next[b] = rd[j] + nl[j] * (uint32_t)LINE;
+                    }
                 }
                 if (__ballot(extra) != 0ull) {   // rare: more than half a ring of complete lines (extra stores only make the counted wait stricter)
 #pragma unroll
@@ -442,28 +462,26 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
                         const uint32_t b = bucket_of_item(j), li = line_of_item(j);
                         const uint32_t p1 = rd[j] + (li + (uint32_t)LPB) * (uint32_t)LINE + l;
                         const uint2 row2 = s_ring[ring_at(b, p1)];
-                        st8_hidden_if(out_rows + slot0 + b * cap + p1, u32x2{row2.x, row2.y}, li + (uint32_t)LPB < nl[j] ? 1u : 0u);
+                        st8_hidden_if_s(out_group, (b * cap + p1) * 8u, u32x2{row2.x, row2.y}, li + (uint32_t)LPB < nl[j] ? 1u : 0u);
                     }
                 }
             }
             return;
         }
-        for (uint32_t b = q; b < F; b += NT / LINE) {
-            const uint32_t wr = s_wr[b], rd = s_rd[b];
+        for (uint32_t b = q; b < F; b += NT / LINE) {   // one 16-lane group per bucket: all its lines
+            const unsigned long long w = s_wrrd[b];
+            const uint32_t wr = (uint32_t)w, rd = (uint32_t)(w >> 32);
             uint32_t end = wr < cap ? wr : cap;                 // rows past the slot were dropped
             if (end > rd + R) end = rd + R;                     // positions beyond the ring are still pending
             if (!fin) end = rd + ((end - rd) & ~(uint32_t)(LINE - 1));
-            uint2* __restrict__ dst = out_rows + slot0 + b * cap;
+            uint2* __restrict__ dst = out_group + b * cap;
             if (DIAG != 2)
                 for (uint32_t p = rd + l; p < end; p += LINE) dst[p] = s_ring[ring_at(b, p)];   // 16 lanes x 8 B = one 128-byte line
-            if (l == 0) s_rd_next[b] = end;
+            if (l == 0 && !fin) {
+                reinterpret_cast<uint32_t*>(s_wrrd + b)[1] = end;
+                if (LPB > 1) snap_next[b] = end;
+            }
         }
-    };
-    auto place = [&](uint32_t key, uint32_t rid, uint32_t b, uint32_t pos) -> bool {   // true when the row stays pending
-        if (pos >= cap) return false;                         // slot overflow: dropped, flag raised at the end
-        if (pos - s_rd2[cur * F + b] >= (uint32_t)R) return true;
-        s_ring[ring_at(b, pos)] = make_uint2(key, rid);
-        return false;
     };
     uint32_t tile_no = 0;
     auto process = [&](auto set, u32x2 (&t)[RPT], uint32_t k) {   // k may be n_tiles (odd tile counts): a tile without rows
@@ -479,25 +497,36 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
         ++tile_no;
         uint32_t key[RPT], rid[RPT], bk[RPT], pos[RPT];
         uint32_t pend = 0;
+        // one returning 64-bit LDS atomic per row: its position in the bucket (low word) and how far the ring is drained (high)
+        auto take = [&](int r, uint32_t& rdv) {
+            const uint32_t h = hashed ? key[r] : hash_int32((int32_t)(key[r] ^ khi));
+            bk[r] = bucket_of(h, cfg);
+            const unsigned long long w = atomicAdd(&s_wrrd[bk[r]], 1ull);
+            pos[r] = (uint32_t)w;
+            rdv = (uint32_t)(w >> 32);
+        };
+        uint32_t rdv[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            key[r] = t[r].x;
-            rid[r] = t[r].y;
-            bk[r] = 0xFFFFFFFFu;
-            if ((uint32_t)r * NT + tid < tn) {
-                bk[r] = bucket_of(hash_int32((int32_t)(key[r] ^ khi)), cfg);
-                pos[r] = atomicAdd(&s_wr[bk[r]], 1u);
-            }
-        }
-        {   // (the cursor reads of all rows first: hipcc cannot tell that the ring writes do not alias them and would order each read
-            //  behind the previous row's write)
-            uint32_t rdv[RPT];
+        for (int r = 0; r < RPT; ++r) { key[r] = t[r].x; rid[r] = t[r].y; }
+        if (tn == (uint32_t)TILE) {   // work-group-uniform: the common tile needs no per-row bounds
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) rdv[r] = s_rd2[cur * F + (bk[r] != 0xFFFFFFFFu ? bk[r] : 0u)];
+            for (int r = 0; r < RPT; ++r) take(r, rdv[r]);
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                if (bk[r] == 0xFFFFFFFFu || pos[r] >= cap) continue;          // no row / slot overflow: dropped, flag raised at the end
+                if (pos[r] >= cap) continue;                                  // slot overflow: dropped, flag raised at the end
                 if (pos[r] - rdv[r] >= (uint32_t)R) pend |= 1u << r;          // ring full: placed after the flush
+                else s_ring[ring_at(bk[r], pos[r])] = make_uint2(key[r], rid[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                bk[r] = 0xFFFFFFFFu;
+                if ((uint32_t)r * NT + tid < tn) take(r, rdv[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (bk[r] == 0xFFFFFFFFu || pos[r] >= cap) continue;
+                if (pos[r] - rdv[r] >= (uint32_t)R) pend |= 1u << r;
                 else s_ring[ring_at(bk[r], pos[r])] = make_uint2(key[r], rid[r]);
             }
         }
@@ -510,12 +539,17 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
             if (tid == 0) s_flag[(it + 1) & 1] = 0;
             ++it;
             cur ^= 1u;
-            lds_barrier();                       // rings drained (the other copy of s_rd holds the advanced positions), the other flag cleared
+            lds_barrier();                       // rings drained (cursors advanced), the other flag cleared
             if (!more) break;                    // work-group-uniform
 #pragma unroll
             for (int r = 0; r < RPT; ++r)
-                if ((pend >> r) & 1u)
-                    if (!place(key[r], rid[r], bk[r], pos[r])) pend &= ~(1u << r);
+                if ((pend >> r) & 1u) {
+                    const uint32_t rd_now = reinterpret_cast<const uint32_t*>(s_wrrd + bk[r])[1];
+                    if (pos[r] - rd_now < (uint32_t)R) {
+                        s_ring[ring_at(bk[r], pos[r])] = make_uint2(key[r], rid[r]);
+                        pend &= ~(1u << r);
+                    }
+                }
             if (__ballot(pend != 0) != 0ull && lane == 0) s_flag[it & 1] = 1;
             lds_barrier();                       // ring rows + pending flag visible
         }
@@ -534,7 +568,7 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
     if (ASM) wait_vmcnt<0>();
     flush(true);   // (the barrier at the end of the last process() ordered every ring write before this)
     if (tid < F) {
-        const uint32_t cnt = s_wr[tid];
+        const uint32_t cnt = (uint32_t)s_wrrd[tid];
         fx.sub_start[(size_t)g * F + tid] = slot0 + tid * cap;
         fx.sub_len[(size_t)g * F + tid] = cnt < cap ? cnt : cap;
         if (cnt > cap) atomicOr(fx.overflow, 1u);

@@ -349,6 +349,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         cfg.mode = 1;
         cfg.e1 = sp.e1;
         cfg.owners_log2 = ilog2(P);
+        cfg.pre_hashed = p1n_variant() != 0 ? 1u : 0u;   // the tuples carry hash_int32(key) from here on (PassCfg::pre_hashed): what travels is (hash, row id)
         {
             KernelTimer t(ctx, side ? "partition_scatter_probe" : "partition_scatter_build", st, 16 * n_local[side]);
             launch_part1_narrow(st, keys_in[side], rid_base[side], nc, c_off, c_len, tuples[side], cfg,
@@ -393,6 +394,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         FixedArgs fx{GroupSrc{}, slot_base, slot_cap, sub_start, sub_len, words, nullptr};
         PassCfg cfg = sp.local.passes[0].cfg;
         cfg.S = 1;
+        cfg.pre_hashed = p1n_variant() != 0 ? 1u : 0u;
         {
             KernelTimer t(ctx, side ? "local_scatter_probe" : "local_scatter_build", st, 16 * cm->info.rows_received[side]);
             launch_part2_ring(st, per, tuples[side], finals[side], cfg, fx, SegSrc{seg_off, seg_len, P * nsub});
