@@ -98,6 +98,18 @@ __device__ __forceinline__ void st8_hidden_if_s(void* sbase, uint32_t off, u32x2
                  : "v"(off), "v"(v), "s"(sbase), "v"(ok)
                  : "memory", "vcc", "scc");
 }
+// 16-byte store of the lanes in `mask` (a wave-wide lane mask in scalar registers, e.g. from __ballot: no vector instruction is
+// spent on the predicate), scalar base + 32-bit byte offset; always one vmcnt event
+__device__ __forceinline__ void st16_hidden_mask_s(void* sbase, uint32_t off, u32x4 v, unsigned long long mask) {
+    unsigned long long saved;
+    // (s_nop: a store of more than 8 bytes reads its data registers for two more cycles on gfx940+; hipcc's hazard recogniser
+    //  does not look inside asm statements, and without the wait states a vector instruction scheduled right behind this
+    //  statement overwrote the first data register in time to be stored -- rows with a garbage first word, i.e. lost matches)
+    asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_nop 1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(off), "v"(v), "s"(sbase), "s"(mask)
+                 : "memory", "scc");
+}
 // returning global atomic add of the active lanes (inactive lanes keep `ret`)
 __device__ __forceinline__ void atomic_add_rtn_hidden(uint32_t& ret, uint32_t* p, uint32_t v) {
     asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(ret) : "v"(p), "v"(v) : "memory");
@@ -327,9 +339,10 @@ template <int RPT, int R, bool ASM, int DIAG = 0>   // DIAG 2: timing-only build
 __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_part2_ring(const uint2* __restrict__ in_rows, uint2* __restrict__ out_rows, PassCfg cfg, FixedArgs fx,
                                                             SegSrc seg) {
     constexpr int NT = P2R_THREADS, TILE = NT * RPT, LINE = P2R_LINE;
-    constexpr int FLUSH_ITERS = P2R_MAX_F / (NT / LINE);   // line items per 16-lane group (ASM: always this many store instructions per flush)
+    constexpr int HL = LINE / 2;                           // lanes per line in the regular flush: 16 bytes (two rows) each
+    constexpr int FLUSH_ITERS = P2R_MAX_F / (NT / HL);     // line items per 8-lane group (ASM: always this many store instructions per flush)
     constexpr int LPB = R / (2 * LINE);                    // lines a bucket gets per regular flush (half a ring); F * LPB <= 512 line items
-    constexpr int FB = 4;                                  // line items whose LDS reads are in flight together (8 would spill at 96 VGPRs)
+    constexpr int FB = LPB == 1 ? FLUSH_ITERS : 2;         // line items whose LDS reads are in flight together (register budget: 96)
     static_assert((R & (R - 1)) == 0 && R >= 2 * LINE && R <= 256, "ring geometry");
     static_assert(!ASM || 2 * RPT <= P2R_FIXED_PAIRS, "two tiles of hidden loads in the fixed registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -424,47 +437,53 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
         const uint32_t* snap = s_snap + cur * F;
         uint32_t* snap_next = s_snap + (cur ^ 1u) * F;
         if (ASM && !fin) {
-            // FLUSH_ITERS line items per 16-lane group, FB at a time: all their cursor reads are issued together, then all their
-            // ring reads, then the (predicated) stores -- two LDS round trips per batch instead of two per item
+            // FLUSH_ITERS line items per 8-lane group (a lane moves two rows = 16 bytes: half as many items per lane as with one
+            // row each, and the per-item cursor arithmetic is what this kernel spends its vector instructions on); all cursor
+            // reads are issued together, then all ring reads, then the stores -- two LDS round trips per flush.
+            // Item q8 + 128 * j = line (item >> lgF) of bucket (item & (F - 1)).
+            const uint32_t q8 = tid >> 3, l2 = (tid & 7u) * 2u;
 #pragma unroll 1
             for (int j0 = 0; j0 < FLUSH_ITERS; j0 += FB) {
-                uint32_t wr[FB], rd[FB], nl[FB];
-                uint2 row[FB];
-                auto bucket_of_item = [&](int j) -> uint32_t { return (q + (uint32_t)(j0 + j) * (NT / LINE)) & (F - 1u); };   // line li of bucket b's complete lines
-                auto line_of_item = [&](int j) -> uint32_t { return LPB == 1 ? 0u : (q + (uint32_t)(j0 + j) * (NT / LINE)) >> lgF; };
+            uint32_t wr[FB], rd[FB], nl[FB];
+            u32x4 row[FB];
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const uint32_t b = (q8 + (uint32_t)(j0 + j) * (NT / HL)) & (F - 1u);
+                const unsigned long long w = s_wrrd[b];
+                wr[j] = (uint32_t)w;
+                rd[j] = LPB == 1 ? (uint32_t)(w >> 32) : snap[b];
+            }
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const uint32_t b = (q8 + (uint32_t)(j0 + j) * (NT / HL)) & (F - 1u);
+                const uint32_t li = LPB == 1 ? 0u : (q8 + (uint32_t)(j0 + j) * (NT / HL)) >> lgF;
+                uint32_t end = wr[j] < cap ? wr[j] : cap;
+                if (end > rd[j] + R) end = rd[j] + R;
+                nl[j] = li < (uint32_t)LPB ? (end - rd[j]) / (uint32_t)LINE : 0u;   // (items beyond F * LPB: no lines)
+                row[j] = *reinterpret_cast<const u32x4*>(&s_ring[ring_at(b, rd[j] + li * (uint32_t)LINE + l2)]);
+            }
+            bool extra = false;
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {   // one store instruction per item at uniform control flow
+                const uint32_t b = (q8 + (uint32_t)(j0 + j) * (NT / HL)) & (F - 1u);
+                const uint32_t li = LPB == 1 ? 0u : (q8 + (uint32_t)(j0 + j) * (NT / HL)) >> lgF;
+                st16_hidden_mask_s(out_group, (b * cap + rd[j] + li * (uint32_t)LINE + l2) * 8u, row[j], __ballot(li < nl[j]));
+                extra |= li + (uint32_t)LPB < nl[j];
+                if (l2 == 0 && li == 0) {   // (every bucket has its item li = 0)
+                    reinterpret_cast<uint32_t*>(s_wrrd + b)[1] = rd[j] + nl[j] * (uint32_t)LINE;
+                    if (LPB > 1) snap_next[b] = rd[j] + nl[j] * (uint32_t)LINE;
+                }
+            }
+            if (__ballot(extra) != 0ull) {   // rare: more than half a ring of complete lines (extra stores only make the counted wait stricter)
 #pragma unroll
                 for (int j = 0; j < FB; ++j) {
-                    const unsigned long long w = s_wrrd[bucket_of_item(j)];
-                    wr[j] = (uint32_t)w;
-                    rd[j] = LPB == 1 ? (uint32_t)(w >> 32) : snap[bucket_of_item(j)];
+                    const uint32_t b = (q8 + (uint32_t)(j0 + j) * (NT / HL)) & (F - 1u);
+                    const uint32_t li = LPB == 1 ? 0u : (q8 + (uint32_t)(j0 + j) * (NT / HL)) >> lgF;
+                    const uint32_t p1 = rd[j] + (li + (uint32_t)LPB) * (uint32_t)LINE + l2;
+                    const u32x4 row2 = *reinterpret_cast<const u32x4*>(&s_ring[ring_at(b, p1)]);
+                    st16_hidden_mask_s(out_group, (b * cap + p1) * 8u, row2, __ballot(li + (uint32_t)LPB < nl[j]));
                 }
-#pragma unroll
-                for (int j = 0; j < FB; ++j) {
-                    uint32_t end = wr[j] < cap ? wr[j] : cap;
-                    if (end > rd[j] + R) end = rd[j] + R;
-                    nl[j] = line_of_item(j) < (uint32_t)LPB ? (end - rd[j]) / (uint32_t)LINE : 0u;   // (items beyond F * LPB: no lines)
-                    row[j] = s_ring[ring_at(bucket_of_item(j), rd[j] + line_of_item(j) * (uint32_t)LINE + l)];
-                }
-                bool extra = false;
-#pragma unroll
-                for (int j = 0; j < FB; ++j) {   // one store instruction per item at uniform control flow
-                    const uint32_t b = bucket_of_item(j), li = line_of_item(j);
-                    st8_hidden_if_s(out_group, (b * cap + rd[j] + li * (uint32_t)LINE + l) * 8u, u32x2{row[j].x, row[j].y}, li < nl[j] ? 1u : 0u);
-                    extra |= li + (uint32_t)LPB < nl[j];
-                    if (l == 0 && li == 0) {   // (every bucket has its item li = 0)
-                        reinterpret_cast<uint32_t*>(s_wrrd + b)[1] = rd[j] + nl[j] * (uint32_t)LINE;
-                        if (LPB > 1) snap_next[b] = rd[j] + nl[j] * (uint32_t)LINE;
-                    }
-                }
-                if (__ballot(extra) != 0ull) {   // rare: more than half a ring of complete lines (extra stores only make the counted wait stricter)
-#pragma unroll
-                    for (int j = 0; j < FB; ++j) {
-                        const uint32_t b = bucket_of_item(j), li = line_of_item(j);
-                        const uint32_t p1 = rd[j] + (li + (uint32_t)LPB) * (uint32_t)LINE + l;
-                        const uint2 row2 = s_ring[ring_at(b, p1)];
-                        st8_hidden_if_s(out_group, (b * cap + p1) * 8u, u32x2{row2.x, row2.y}, li + (uint32_t)LPB < nl[j] ? 1u : 0u);
-                    }
-                }
+            }
             }
             return;
         }

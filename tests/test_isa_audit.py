@@ -87,6 +87,12 @@ def test_hidden_memory_kernels_have_no_scratch_and_no_stray_waits(asm, key):
         assert not touched, (f"{key}: line {ln} `{s}` uses v{sorted(touched)} while a hidden load into them (line "
                              f"{dirty[sorted(touched)[0]]}) may still be in flight")
     assert hidden, f"{key}: no hidden loads found (is this still the ASM form?)"
+    # (4) a hidden store of more than 8 bytes keeps reading its data registers for two more cycles on gfx940+ (hipcc pads compiler-
+    #     visible stores itself but does not look inside asm statements): every such store must carry its own wait states
+    for i, l in enumerate(lines):
+        if "global_store_dwordx4" in l or "global_store_dwordx3" in l:
+            nxt = [x.strip() for x in lines[i + 1:i + 3]]
+            assert nxt and nxt[0].startswith("s_nop"), f"{key}: line {i} `{l.strip()}` is not followed by s_nop (store-data hazard)"
     if "k_part2_ring" in key:
         # the ring pass loads into fixed registers outside hipcc's budget (golap_part_narrow.h, ld8_fixed): hipcc itself must
         # never name them, and the kernel descriptor must cover them
