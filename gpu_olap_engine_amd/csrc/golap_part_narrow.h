@@ -151,6 +151,9 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     uint32_t* s_w = s_delta + cfg.F;                                       // [NW] wave totals, [NW] abandon flag
 
     if (rs.run_if && *rs.run_if == 0) return;
+    // the attempt may be over before it starts (k_key_hi's sample found two upper key halves): ~2000 work-groups that each load and
+    // rank one tile before they notice cost 0.45 ms per side; asking first costs the good case one L2 round trip per work-group
+    if (__hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
     if (len == 0) return;
