@@ -108,6 +108,7 @@ pub struct golap_aggregate_params {
     pub reserved0: i32,
     pub out_keys_ptr: u64,
     pub out_n_groups_ptr: u64,
+    pub value_validity_ptrs: *const u64,
 }
 
 #[repr(C)]

@@ -119,6 +119,7 @@ impl AggregateKernel {
             reserved0: 0,
             out_keys_ptr: 0,
             out_n_groups_ptr: 0,
+            value_validity_ptrs: std::ptr::null(),
         };
         check(self.ctx, unsafe { golap_aggregate(self.ctx, s.as_ptr(), s.len() as u32, &p, null_mut()) })
     }

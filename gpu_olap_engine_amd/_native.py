@@ -140,7 +140,7 @@ class AggregateParams(C.Structure):
     _fields_ = [("group_key_ptr", C.c_uint64), ("value_ptrs", C.POINTER(C.c_uint64)), ("n_value_cols", C.c_uint32),
                 ("n_rows", C.c_uint64), ("n_groups", C.c_uint32), ("out_ptr", C.c_uint64), ("key_dtype", C.c_int32),
                 ("value_dtypes", C.POINTER(C.c_int32)), ("out_count_ptr", C.c_uint64), ("key_mode", C.c_int32), ("reserved0", C.c_int32),
-                ("out_keys_ptr", C.c_uint64), ("out_n_groups_ptr", C.c_uint64)]
+                ("out_keys_ptr", C.c_uint64), ("out_n_groups_ptr", C.c_uint64), ("value_validity_ptrs", C.POINTER(C.c_uint64))]
 
 
 class KernelStat(C.Structure):

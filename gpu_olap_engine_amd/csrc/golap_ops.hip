@@ -271,7 +271,8 @@ __device__ __forceinline__ uint32_t slot_of(KeyT key, uint32_t n_groups) {
 // ---------------------------------------------------------------------------
 template <typename KeyT, bool VAL_F64, bool NEED_MM>
 __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n, uint32_t n_groups,
-                                                    unsigned long long rows_per_block, double* __restrict__ slab /*[grid][4][n_groups]*/) {
+                                                    unsigned long long rows_per_block, double* __restrict__ slab /*[grid][4][n_groups]*/,
+                                                    const uint8_t* __restrict__ vv = nullptr /*validity of the value column, 0 = NULL: skipped*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_sum = reinterpret_cast<double*>(s_raw);
     double* s_mn = s_sum + n_groups;
@@ -290,17 +291,19 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
     for (unsigned long long base = lo; base < hi; base += (unsigned long long)blockDim.x * GR) {
         KeyT k[GR];
         double x[GR];
+        uint8_t ok[GR];
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
             unsigned long long i = base + (unsigned long long)r * blockDim.x + threadIdx.x;
             if (i >= hi) i = hi - 1;
             k[r] = keys[i];
             x[r] = VAL_F64 ? vf[i] : (double)vi[i];
+            ok[r] = vv ? vv[i] : (uint8_t)1;
         }
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
             const unsigned long long i = base + (unsigned long long)r * blockDim.x + threadIdx.x;
-            if (i < hi) {
+            if (i < hi && ok[r]) {   // SQL aggregates skip NULL values (COUNT counts the non-NULL ones)
                 const uint32_t g = slot_of(k[r], n_groups);
                 atomicAdd(&s_sum[g], x[r]);
                 atomicAdd(&s_cnt[g], 1u);
@@ -370,6 +373,7 @@ constexpr int AG_RPT = 8;
 constexpr int AG_TILE = AG_THREADS * AG_RPT;   // 4096 rows staged in LDS
 constexpr int AG_GB = 2048;                    // slots per bucket (one 56 KiB LDS table)
 constexpr int AG_MAX_B = 1024;                 // buckets (fan-out of the single partition pass)
+constexpr uint32_t AG_NULL_MARK = 0x80000000u;   // partition path: top bit of the slot word = the row's VALUE is NULL (it travels, but is not aggregated)
 
 template <typename KeyT>
 __global__ __launch_bounds__(AG_THREADS) void k_agg_hist(const KeyT* __restrict__ keys, unsigned long long n, uint32_t n_groups, uint32_t chunk_rows,
@@ -401,7 +405,7 @@ template <typename KeyT, bool VAL_F64>
 __global__ __launch_bounds__(AG_THREADS) void k_agg_scatter(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
                                                             uint32_t n_groups, uint32_t chunk_rows, uint32_t S, uint32_t B,
                                                             const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
-                                                            double* __restrict__ out_val) {
+                                                            double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr) {
     __shared__ double s_val[AG_TILE];
     __shared__ uint32_t s_slot[AG_TILE];
     __shared__ uint32_t s_cnt[AG_MAX_B], s_start[AG_MAX_B], s_gpos[AG_MAX_B], s_w[AG_WAVES];
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_scatter(const KeyT* __restri
         for (int r = 0; r < AG_RPT; ++r) {   // unconditional loads on clamped indices: all in flight together
             const uint32_t i = r * AG_THREADS + tid;
             const unsigned long long gi = t0 + (i < tn ? i : tn - 1);
-            slot[r] = slot_of(keys[gi], n_groups);
+            slot[r] = slot_of(keys[gi], n_groups) | ((vv && !vv[gi]) ? AG_NULL_MARK : 0u);
             x[r] = VAL_F64 ? vf[gi] : (double)vi[gi];   // executor.rs:521 `as f64`
         }
         __syncthreads();
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_scatter(const KeyT* __restri
         for (int r = 0; r < AG_RPT; ++r) {
             const uint32_t i = r * AG_THREADS + tid;
             if (i < tn) {
-                const uint32_t b = slot[r] / AG_GB;
+                const uint32_t b = (slot[r] & ~AG_NULL_MARK) / AG_GB;
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);
             }
         }
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_scatter(const KeyT* __restri
         for (int r = 0; r < AG_RPT; ++r) {
             const uint32_t i = r * AG_THREADS + tid;
             if (i < tn) {
-                const uint32_t sl = s_slot[i], b = sl / AG_GB;
+                const uint32_t sl = s_slot[i], b = (sl & ~AG_NULL_MARK) / AG_GB;
                 const uint32_t gp = s_gpos[b] + (i - s_start[b]);
                 out_slot[gp] = sl;
                 out_val[gp] = s_val[i];
@@ -486,7 +490,7 @@ template <typename KeyT, bool VAL_F64>
 __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
                                                                  uint32_t n_groups, uint32_t chunk_rows, uint32_t S, uint32_t B,
                                                                  const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
-                                                                 double* __restrict__ out_val) {
+                                                                 double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_val = reinterpret_cast<double*>(s_raw);                          // [AGB_WIN]
     uint32_t* s_slot = reinterpret_cast<uint32_t*>(s_raw + AGB_WIN * 8);       // [AGB_WIN]
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
         for (int r = 0; r < AGB_RPT; ++r) {   // unconditional loads on clamped indices: all in flight together
             const uint32_t i = r * AGB_THREADS + tid;
             const unsigned long long gi = t0 + (i < tn ? i : tn - 1);
-            slot[r] = slot_of(keys[gi], n_groups);
+            slot[r] = slot_of(keys[gi], n_groups) | ((vv && !vv[gi]) ? AG_NULL_MARK : 0u);
             x[r] = VAL_F64 ? vf[gi] : (double)vi[gi];   // executor.rs:521 `as f64`
         }
         lds_barrier();
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
             const uint32_t i = r * AGB_THREADS + tid;
             br[r] = 0xFFFFFFFFu;
             if (i < tn) {
-                const uint32_t b = slot[r] / AG_GB;
+                const uint32_t b = (slot[r] & ~AG_NULL_MARK) / AG_GB;
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 1024, rank < 16384
             }
         }
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
             for (int j = 0; j < AGB_WIN / AGB_THREADS; ++j) {
                 const uint32_t i = j * AGB_THREADS + tid;
                 if (i < wn) {
-                    const uint32_t sl = s_slot[i], b = sl / AG_GB;
+                    const uint32_t sl = s_slot[i], b = (sl & ~AG_NULL_MARK) / AG_GB;
                     const uint32_t gp = s_gpos[b] + (w0 + i - s_start[b]);
                     out_slot[gp] = sl;
                     out_val[gp] = s_val[i];
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_bucket(const uint32_t* __res
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const uint32_t i = base + r * AG_THREADS + threadIdx.x;
-            if (i < hi) {
+            if (i < hi && !(k[r] & AG_NULL_MARK)) {
                 const uint32_t g = k[r] - kbase;
                 atomicAdd(&s_sum[g], x[r]);
                 atomicAdd(&s_cnt[g], 1u);
@@ -643,10 +647,12 @@ __global__ void k_group_init(double* __restrict__ stats4, uint32_t n_groups) {
 
 template <typename KeyT, bool VAL_F64>
 __global__ __launch_bounds__(OP_THREADS) void k_group_global(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
-                                                             uint32_t n_groups, double* __restrict__ stats4, int need_minmax, int need_cnt) {
+                                                             uint32_t n_groups, double* __restrict__ stats4, int need_minmax, int need_cnt,
+                                                             const uint8_t* __restrict__ vv = nullptr) {
     const long long* vi = (const long long*)val;
     const double* vf = (const double*)val;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        if (vv && !vv[i]) continue;
         const uint32_t g = slot_of(keys[i], n_groups);
         const double x = VAL_F64 ? vf[i] : (double)vi[i];
         unsafeAtomicAdd(&stats4[g * 4 + 0], x);
@@ -964,14 +970,15 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
         if (vdt != GOLAP_DT_INT64 && vdt != GOLAP_DT_FLOAT64) return fail(ctx, GOLAP_ERR_INVALID_ARG, "value column %u: dtype must be INT64 or FLOAT64", col);
         const bool vf = vdt == GOLAP_DT_FLOAT64;
         const void* val = p->n_rows ? (const void*)p->value_ptrs[col] : nullptr;
+        const uint8_t* vv = (p->value_validity_ptrs && p->n_rows) ? (const uint8_t*)p->value_validity_ptrs[col] : nullptr;   // 0 = NULL row
         if (p->n_rows && !val) return fail(ctx, GOLAP_ERR_INVALID_ARG, "value column %u is null", col);
         const uint64_t key_bytes = grouped ? (p->key_dtype == GOLAP_DT_INT32 ? 4 : 8) : 0;
         if (!grouped) {
             KernelTimer t(ctx, "aggregate_ungrouped", st, 8 * p->n_rows);
             if (vf) hipLaunchKernelGGL((k_reduce_partials<true, false>), dim3(red_grid), dim3(OP_THREADS), 0, st, (const long long*)nullptr, val,
-                                       (unsigned long long)p->n_rows, 0, 0ll, partials);
+                                       (unsigned long long)p->n_rows, 0, 0ll, partials, (const uint8_t*)nullptr, vv);
             else hipLaunchKernelGGL((k_reduce_partials<false, false>), dim3(red_grid), dim3(OP_THREADS), 0, st, (const long long*)nullptr, val,
-                                    (unsigned long long)p->n_rows, 0, 0ll, partials);
+                                    (unsigned long long)p->n_rows, 0, 0ll, partials, (const uint8_t*)nullptr, vv);
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, red_grid, stats4);
         } else if (lds_path) {
             const size_t lds = (size_t)G * 28 + 16;
@@ -979,7 +986,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                 KernelTimer t(ctx, "hash_aggregate_lds", st, (key_bytes + 8) * p->n_rows + 12ull * G);
 #define GOLAP_LAUNCH_LDS(KT, VF, MM)                                                                                              \
     hipLaunchKernelGGL((k_group_lds<KT, VF, MM>), dim3(lds_grid), dim3(512), lds, st, (const KT*)p->group_key_ptr, val,          \
-                       (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab)
+                       (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab, vv)
                 if (p->key_dtype == GOLAP_DT_INT32) {
                     if (vf) { if (need_minmax) GOLAP_LAUNCH_LDS(int, true, true); else GOLAP_LAUNCH_LDS(int, true, false); }
                     else { if (need_minmax) GOLAP_LAUNCH_LDS(int, false, true); else GOLAP_LAUNCH_LDS(int, false, false); }
@@ -1010,10 +1017,10 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                 KernelTimer t(ctx, "agg_partition_scatter", st, (key_bytes + 8 + 12) * p->n_rows);
 #define GOLAP_AGG_SC(KT, VF)                                                                                                          \
     hipLaunchKernelGGL((k_agg_scatter<KT, VF>), dim3(pS2), dim3(AG_THREADS), 0, st, (const KT*)p->group_key_ptr, val,                 \
-                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val)
+                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
 #define GOLAP_AGG_SCB(KT, VF)                                                                                                         \
     hipLaunchKernelGGL((k_agg_scatter_big<KT, VF>), dim3(pS2), dim3(AGB_THREADS), AGB_LDS, st, (const KT*)p->group_key_ptr, val,      \
-                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val)
+                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
                 if (p_big) {
                     if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_SCB(int, true); else GOLAP_AGG_SCB(int, false); }
                     else { if (vf) GOLAP_AGG_SCB(long long, true); else GOLAP_AGG_SCB(long long, false); }
@@ -1038,14 +1045,14 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             const uint32_t grid = stream_grid(ctx, p->n_rows, OP_THREADS * 4);
             if (p->key_dtype == GOLAP_DT_INT32) {
                 if (vf) hipLaunchKernelGGL((k_group_global<int, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, val,
-                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
+                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt, vv);
                 else hipLaunchKernelGGL((k_group_global<int, false>), dim3(grid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, val,
-                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
+                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt, vv);
             } else {
                 if (vf) hipLaunchKernelGGL((k_group_global<long long, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, val,
-                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
+                                           (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt, vv);
                 else hipLaunchKernelGGL((k_group_global<long long, false>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, val,
-                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt);
+                                        (unsigned long long)p->n_rows, G, stats4, (int)need_minmax, (int)need_cnt, vv);
             }
         }
         const uint32_t fg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS)));
@@ -1181,7 +1188,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict
 
 static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st) {
     if (!p->group_key_ptr && p->n_rows) return fail(ctx, GOLAP_ERR_INVALID_ARG, "GOLAP_KEYS_HASHED needs a group key column");
-    if (p->n_groups > (1u << 23)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^23 groups (key table of 2^24 entries)");
+    if (p->n_groups > (1u << 22)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^22 groups (key table of 2^23 entries + 1: the two-level scan covers 2^24)");
     if (p->n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^32-16 rows");
     uint32_t cap = 1024;
     while (cap < 2 * p->n_groups) cap <<= 1;   // load factor <= 0.5 while the bound holds

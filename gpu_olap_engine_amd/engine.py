@@ -329,7 +329,7 @@ class Context:
         return c
 
     # ---- GpuAggregate -----------------------------------------------------------
-    def aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False, hashed=False):
+    def aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False, hashed=False, value_valid=None):
         """AggregateKernel::aggregate.
 
         specs  : list of (func, value_col_index) -- output plane i belongs to specs[i]
@@ -337,6 +337,7 @@ class Context:
         -> f64[n_specs, n_groups] (and u64 counts as int64[n_groups] when want_counts)
         hashed : GOLAP_KEYS_HASHED -- any keys; n_groups bounds the number of distinct keys;
                  -> (out, [counts,] slot_keys int64[n_groups], n_distinct int32[1] device)
+        value_valid : None or a list (one entry per value column) of None | uint8 device tensors, 0 = NULL: SQL aggregates skip them
         """
         dev = values[0].device
         n_rows = values[0].numel()
@@ -361,8 +362,16 @@ class Context:
                 raise ValueError("group key column differs in length")
         okeys = torch.zeros(n_groups, dtype=torch.int64, device=dev) if hashed else None
         ong = torch.zeros(1, dtype=torch.int32, device=dev) if hashed else None
+        vvp = None
+        if value_valid is not None:
+            if len(value_valid) != nv:
+                raise ValueError("value_valid needs one entry per value column")
+            for v in value_valid:
+                if v is not None and (v.dtype != torch.uint8 or v.numel() != n_rows):
+                    raise TypeError("validity columns are uint8 with one byte per row")
+            vvp = (C.c_uint64 * nv)(*[_ptr(v) for v in value_valid])
         prm = N.AggregateParams(_ptr(group_keys), vptrs, nv, n_rows, n_groups, _ptr(out), kd, vdt, _ptr(counts),
-                                N.KEYS_HASHED if hashed else N.KEYS_DENSE, 0, _ptr(okeys), _ptr(ong))
+                                N.KEYS_HASHED if hashed else N.KEYS_DENSE, 0, _ptr(okeys), _ptr(ong), vvp)
         self._ck(self._lib.golap_aggregate(self._h, sp, len(specs), C.byref(prm), _stream()))
         if hashed:
             return (out, counts, okeys, ong) if want_counts else (out, okeys, ong)

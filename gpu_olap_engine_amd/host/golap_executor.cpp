@@ -574,13 +574,40 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
     uint64_t n = 0;
     for (const RecordBatch& b : in) n += b.num_rows;
     const uint32_t nv = (uint32_t)val_names.size();
-    std::vector<DevBuf> dvals(nv);
-    std::vector<uint64_t> vptrs(nv);
+    std::vector<DevBuf> dvals(nv), dvalid(nv);
+    std::vector<uint64_t> vptrs(nv), vvptrs(nv, 0);   // vvptrs: validity of the value columns (0 = that column has no NULLs)
     std::vector<int32_t> vdt(nv, GOLAP_DT_INT64);
+    bool any_value_nulls = false;
     for (uint32_t v = 0; v < nv; ++v) {
         H_TRY(dvals[v].alloc(ctx, n * 8));
         vptrs[v] = dvals[v].ptr;
         uint64_t o = 0;
+        std::vector<uint8_t> valid;   // byte per row over all batches, only when some batch carries NULLs in this column
+        {
+            bool nulls = false;
+            for (const RecordBatch& b : in) {
+                golap_expr e; e.kind = golap_expr::Column; e.name = val_names[v];
+                for (uint32_t i = 0; i < na; ++i) if (p.aggr_inputs[i]->name == val_names[v]) { e.index = p.aggr_inputs[i]->index; break; }
+                const int ci = resolve_column(e, b);
+                if (ci >= 0 && !b.cols[ci].in_valid.empty()) nulls = true;
+            }
+            if (nulls && n) {
+                valid.assign(n, 1);
+                uint64_t ro = 0;
+                for (const RecordBatch& b : in) {
+                    golap_expr e; e.kind = golap_expr::Column; e.name = val_names[v];
+                    for (uint32_t i = 0; i < na; ++i) if (p.aggr_inputs[i]->name == val_names[v]) { e.index = p.aggr_inputs[i]->index; break; }
+                    const int ci = resolve_column(e, b);
+                    if (ci >= 0 && !b.cols[ci].in_valid.empty() && b.num_rows) memcpy(valid.data() + ro, b.cols[ci].in_valid.data(), b.num_rows);
+                    ro += b.num_rows;
+                }
+                H_TRY(dvalid[v].alloc(ctx, n));
+                H_TRY(h2d(valid.data(), dvalid[v].ptr, n));
+                H_TRY(xsync());   // (the host vector goes out of scope below)
+                vvptrs[v] = dvalid[v].ptr;
+                any_value_nulls = true;
+            }
+        }
         for (const RecordBatch& b : in) {
             golap_expr e; e.kind = golap_expr::Column; e.name = val_names[v];
             for (uint32_t i = 0; i < na; ++i) if (p.aggr_inputs[i]->name == val_names[v]) { e.index = p.aggr_inputs[i]->index; break; }
@@ -605,6 +632,7 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
         golap_aggregate_params ap;
         memset(&ap, 0, sizeof ap);
         ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = 1; ap.out_ptr = dout.ptr;
+        ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;   // SQL aggregates skip NULL values
         ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data();
         H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
         H_TRY(ksync());
@@ -663,7 +691,7 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
         // (GOLAP_KEYS_HASHED, aggregate_kernel.rs:76-77)
         const bool dense_keys = mmv[0] >= 0 && mmv[1] <= 9e15 && (mmv[1] - mmv[0]) < (double)(64ull << 20) && (mmv[1] - mmv[0]) <= 4.0 * (double)n + 1024.0;
         if (!dense_keys) {
-            const uint64_t bound = std::min<uint64_t>(n, 1ull << 23);   // distinct keys <= rows
+            const uint64_t bound = std::min<uint64_t>(n, 1ull << 22);   // distinct keys <= rows; the key table holds at most 2^22 groups
             DevBuf dout, dcnt, dkeys, dn;
             H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * bound * 8));
             H_TRY(dcnt.alloc(ctx, bound * 8));
@@ -671,11 +699,12 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
             H_TRY(dn.alloc(ctx, 8));
             memset(&ap, 0, sizeof ap);
             ap.group_key_ptr = dk.ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)bound;
+            ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;
             ap.out_ptr = dout.ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt.ptr;
             ap.key_mode = GOLAP_KEYS_HASHED; ap.out_keys_ptr = dkeys.ptr; ap.out_n_groups_ptr = dn.ptr;
             if (na == 0) {
                 golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
-                ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd;
+                ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd; ap.value_validity_ptrs = nullptr;
                 H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
             } else {
                 H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
@@ -684,7 +713,7 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
             uint32_t nd = 0;
             H_TRY(d2h(dn.ptr, &nd, 4));
             H_TRY(xsync());
-            if (nd > bound) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^23 distinct group keys");
+            if (nd > bound) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^22 distinct group keys");
             std::vector<int64_t> gk(nd);
             std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * bound);
             if (nd) H_TRY(d2h(dkeys.ptr, gk.data(), (uint64_t)nd * 8));
@@ -714,13 +743,25 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
         H_TRY(dcnt.alloc(ctx, G * 8));
         memset(&ap, 0, sizeof ap);
         ap.group_key_ptr = dk.ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)G;
+        ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;
         ap.out_ptr = dout.ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt.ptr;
         if (na == 0) {   // GROUP BY without aggregates: count only, to find the present groups
             golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
-            ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd;
+            ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd; ap.value_validity_ptrs = nullptr;
             H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
         } else {
             H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
+            if (any_value_nulls) {
+                // out_count counted the non-NULL values of the last column; which groups EXIST is a question about rows: count the
+                // key column (no NULLs) once more into dcnt (a group whose values are all NULL is still a group)
+                DevBuf dtmp;
+                H_TRY(dtmp.alloc(ctx, G * 8));
+                golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
+                golap_aggregate_params cp = ap;
+                cp.value_ptrs = &kp; cp.n_value_cols = 1; cp.value_dtypes = &kd; cp.value_validity_ptrs = nullptr; cp.out_ptr = dtmp.ptr;
+                H_TRY(golap_aggregate(ctx, &cs, 1, &cp, nullptr));
+                H_TRY(ksync());
+            }
         }
         H_TRY(ksync());
         std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * G);

@@ -410,6 +410,10 @@ typedef struct golap_aggregate_params {             /* aggregate_kernel.rs:47-58
     uint64_t out_keys_ptr;       /* HASHED: device int64[n_groups]: the key that owns each slot (one slot per distinct key; which slot is unspecified, like the row order of GROUP BY) */
     uint64_t out_n_groups_ptr;   /* HASHED: device u32: distinct keys found.  A value above n_groups means the bound was too small: the outputs
                                     are then meaningless (memory-safe) and the call must be repeated with a larger n_groups. */
+    const uint64_t* value_validity_ptrs;   /* host array (n_value_cols) of device u8[n_rows], 0 = NULL (column_buffer.rs:59-60); a null array or a
+                                    0 entry = that column has no NULLs.  SQL aggregates: SUM / MIN / MAX / AVG skip NULL values, COUNT counts
+                                    the non-NULL ones; a group whose values are all NULL reports COUNT 0 and the reference's identities
+                                    (executor.rs:308-311, :339-345).  out_count_ptr then counts the non-NULL rows of the LAST aggregated column. */
 } golap_aggregate_params;
 enum { GOLAP_KEYS_DENSE = 0, GOLAP_KEYS_HASHED = 1 };
 

@@ -53,8 +53,11 @@ def main():
             env["GOLAP_AGG_PART"] = "0"
         ctx.debug_set("GOLAP_AGG_PART", env.get("GOLAP_AGG_PART"))
         slots = (keys.astype(np.int64) % G)
-        ok, ost = oracle.group_aggregate(slots, vals.astype(np.float64))
-        out, counts = ctx.aggregate(SPECS, [torch.from_numpy(vals).cuda()], group_keys=torch.from_numpy(keys).cuda(), n_groups=G, want_counts=True)
+        vvalid = (rng.random(n) > 0.2).astype(np.uint8) if rng.random() < 0.3 else None      # NULL values: skipped by every aggregate
+        live = np.ones(n, bool) if vvalid is None else vvalid != 0
+        ok, ost = oracle.group_aggregate(slots[live], vals.astype(np.float64)[live])
+        out, counts = ctx.aggregate(SPECS, [torch.from_numpy(vals).cuda()], group_keys=torch.from_numpy(keys).cuda(), n_groups=G, want_counts=True,
+                                    value_valid=None if vvalid is None else [torch.from_numpy(vvalid).cuda()])
         out, counts = out.cpu().numpy(), counts.cpu().numpy()
         present = counts > 0
         good = np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
@@ -71,7 +74,7 @@ def main():
                 hk = hk.astype(np.int32)
             hk64 = hk.astype(np.int64)
             ek, est = oracle.group_aggregate(hk64, vals.astype(np.float64))
-            bound = min(int(ek.size * rng.choice([1, 2, 5])) + int(rng.integers(0, 3)), 1 << 23)   # (the key table's limit)
+            bound = min(int(ek.size * rng.choice([1, 2, 5])) + int(rng.integers(0, 3)), 1 << 22)   # (the key table limit)
             ho, hc, hkeys, hn = ctx.aggregate(SPECS, [torch.from_numpy(vals).cuda()], group_keys=torch.from_numpy(hk).cuda(), n_groups=max(1, bound),
                                               want_counts=True, hashed=True)
             nd = int(hn.item()) & 0xFFFFFFFF
@@ -107,7 +110,7 @@ def main():
             both = em & (vv != 0)                            # NULL values are skipped by the sum AND the count (SQL aggregates, golap.h)
             good = good and fs[1] == float(both.sum()) and fs[0] == float(vals[both].astype(np.float64).sum())
             why = why or (None if good else "filter-sum-null")
-        print(("ok   " if good else "FAIL ") + f"seed={seed} round={rnd} n={n} G={G} key={np.dtype(kd).name} shape={shape} val={'f64' if vf else 'i64'} env={env} op={op} lit={lit}" + (f" FAILED AT {why}" if why else ""), flush=True)
+        print(("ok   " if good else "FAIL ") + f"seed={seed} round={rnd} n={n} G={G} key={np.dtype(kd).name} shape={shape} val={'f64' if vf else 'i64'} nulls={vvalid is not None} env={env} op={op} lit={lit}" + (f" FAILED AT {why}" if why else ""), flush=True)
         if not good:
             sys.exit(1)
     print(f"fuzz: {rnd} rounds, all equal to the oracle", flush=True)

@@ -308,3 +308,52 @@ def test_sum_of_general_doubles_is_within_the_stated_bound(ctx):
         seq = 0.0
         seq = float(np.add.reduce(xs))   # (pairwise in numpy; the sequential sum lies within the same bound)
         assert abs(gs[g] - seq) <= xs.size * eps * float(np.abs(xs).sum())
+
+
+@pytest.mark.parametrize("shape", ["ungrouped", "lds", "partition", "global", "hashed"])
+def test_aggregates_skip_null_values(ctx, shape):
+    """SURVEY 8(f) rank 2 for aggregates: a NULL value (validity byte 0, column_buffer.rs:59-60) takes no part in SUM / MIN / MAX /
+    AVG and is not counted by COUNT -- on every grouped path (LDS pre-aggregation, partition-then-aggregate, global atomics, hashed
+    keys) and ungrouped.  Expected = the oracle on the non-NULL rows; a group whose values are all NULL keeps the identities."""
+    n, G = {"ungrouped": (300_007, 1), "lds": (400_003, 100), "partition": (4_300_000, 150_000), "global": (200_000, 150_000),
+            "hashed": (500_000, 3000)}[shape]
+    rng = np.random.default_rng(len(shape))
+    vals = rng.integers(-2048, 2048, n).astype(np.float64)
+    ivals = rng.integers(-2048, 2048, n).astype(np.int64)
+    vv = (rng.random(n) > 0.3).astype(np.uint8)
+    iv = (rng.random(n) > 0.1).astype(np.uint8)
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0), (N.AGG_SUM, 1), (N.AGG_COUNT, 1)]
+    if shape == "ungrouped":
+        got = ctx.aggregate(specs, [dev(vals), dev(ivals)], value_valid=[dev(vv), dev(iv)]).cpu().numpy()[:, 0]
+        e0, e1 = oracle.execute_aggregate(vals[vv != 0]), oracle.execute_aggregate(ivals[iv != 0].astype(np.float64))
+        assert got.tolist() == [e0["sum"], e0["count"], e0["min"], e0["max"], e0["avg"], e1["sum"], e1["count"]]
+        allnull = ctx.aggregate(specs[:5], [dev(vals)], value_valid=[dev(np.zeros(n, np.uint8))]).cpu().numpy()[:, 0]
+        e = oracle.execute_aggregate(np.empty(0))
+        assert allnull.tolist() == [e["sum"], e["count"], e["min"], e["max"], e["avg"]]
+        return
+    keys = rng.integers(0, G, n).astype(np.int64)
+    if shape == "hashed":
+        keys = keys * 7919 - 5_000_000
+    vv[keys == keys[0]] = 0                                       # one group whose first value column is NULL in every row
+    if shape == "hashed":
+        out, skeys, nd = ctx.aggregate(specs, [dev(vals), dev(ivals)], group_keys=dev(keys), n_groups=2 * G, hashed=True, value_valid=[dev(vv), dev(iv)])
+        nd = int(nd.item())
+        sk = skeys.cpu().numpy()[:nd]
+        order = np.argsort(sk)
+        out = out.cpu().numpy()[:, :nd][:, order]
+        present = sk[order]
+    else:
+        out = ctx.aggregate(specs, [dev(vals), dev(ivals)], group_keys=dev(keys), n_groups=G, value_valid=[dev(vv), dev(iv)]).cpu().numpy()
+        present = np.arange(G)
+    for col, (x, valid, planes) in enumerate([(vals, vv, [0, 1, 2, 3, 4]), (ivals.astype(np.float64), iv, [5, 6])]):
+        ek, est = oracle.group_aggregate(keys[valid != 0], x[valid != 0])
+        pos = np.searchsorted(present, ek)
+        assert np.array_equal(present[pos], ek)
+        exp = np.zeros((present.size, 5))
+        exp[:, 2], exp[:, 3] = np.finfo(np.float64).max, -np.finfo(np.float64).max      # identities of groups without a non-NULL value
+        exp[pos] = est
+        names = ["sum", "count", "min", "max", "avg"]
+        for pl, st in zip(planes, [0, 1, 2, 3, 4] if col == 0 else [0, 1]):
+            np.testing.assert_array_equal(out[pl], exp[:, st], err_msg=f"{shape}: column {col} {names[st]}")
+    g0 = int(np.searchsorted(present, keys[0]))
+    assert out[1, g0] == 0.0 and out[0, g0] == 0.0                 # the all-NULL group: COUNT 0, SUM 0

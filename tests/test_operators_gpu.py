@@ -244,6 +244,38 @@ def test_aggregate_group_by_sparse_and_negative_keys(ctx):
     assert np.array_equal(out[0].column(3).to_numpy(), st[:, 2]) and np.array_equal(out[0].column(4).to_numpy(), st[:, 4])
 
 
+def test_aggregates_skip_null_values(ctx):
+    """NULLs in an aggregated column (Arrow validity): SUM / MIN / AVG skip them, COUNT counts the others -- ungrouped, with dense
+    group keys and with sparse ones; a group whose values are all NULL is still a group (COUNT 0).  The reference zero-fills
+    NULLs on ingest (record_batch_convert.rs:102-110) and so counts them and sums zeros; SQL semantics are what its roadmap
+    (README.md:411) asks for."""
+    n = 50_000
+    rng = np.random.default_rng(21)
+    v = rng.integers(-500, 500, n).astype(np.float64)
+    mask = rng.random(n) < 0.25
+    g_dense = rng.integers(0, 40, n).astype(np.int64)
+    mask[g_dense == 7] = True                                                  # group 7: every value NULL
+    varr = pa.array([None if m else float(x) for x, m in zip(v, mask)], pa.float64())
+    for keys in (g_dense, g_dense * (1 << 35) - 9):
+        b1 = pa.RecordBatch.from_arrays([pa.array(keys[:20_000]), varr[:20_000]], names=["g", "v"])
+        b2 = pa.RecordBatch.from_arrays([pa.array(keys[20_000:]), varr[20_000:]], names=["g", "v"])
+        out = O.execute(O.GpuAggregate(O.Batches([b1, b2]), [O.Column(0, "g")],
+                                       [O.Sum(O.Column(1, "v")), O.Count(O.Column(1, "v")), O.Min(O.Column(1, "v")), O.Avg(O.Column(1, "v"))]), ctx)
+        groups = np.unique(keys)
+        assert np.array_equal(out[0].column(0).to_numpy(), groups)              # all 40 groups, also the all-NULL one
+        ks, st = oracle.group_aggregate(keys[~mask], v[~mask])
+        pos = np.searchsorted(groups, ks)
+        exp = np.zeros((groups.size, 5))
+        exp[:, 2] = np.finfo(np.float64).max
+        exp[pos] = st
+        assert np.array_equal(out[0].column(1).to_numpy(), exp[:, 0]) and np.array_equal(out[0].column(2).to_numpy(), exp[:, 1])
+        assert np.array_equal(out[0].column(3).to_numpy(), exp[:, 2]) and np.array_equal(out[0].column(4).to_numpy(), exp[:, 4])
+    b = pa.RecordBatch.from_arrays([varr], names=["v"])
+    out = O.execute(O.GpuAggregate(O.Batches([b]), [], [O.Sum(O.Column(0, "v")), O.Count(O.Column(0, "v")), O.Max(O.Column(0, "v"))]), ctx)
+    e = oracle.execute_aggregate(v[~mask])
+    assert [out[0].column(i)[0].as_py() for i in range(3)] == [e["sum"], e["count"], e["max"]]
+
+
 def test_group_by_many_aggregates_on_a_fresh_context():
     """A fresh context, a small table, six aggregates over six distinct columns: more than eight same-class slabs are alive at once
     (one per column + keys + outputs); the slab pool's per-class limit is a config field (slab_allocator.rs:25-28), not 8."""
