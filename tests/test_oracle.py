@@ -146,3 +146,32 @@ def test_fnv1a_and_widen():
     h = oracle.lib().orc_fnv1a_hash((C.c_uint8 * len(s))(*s), len(s))
     assert h == 0xA430D84680AABD0B                           # FNV-1a 64 of "hello" (published test vector)
     assert oracle.lib().orc_fnv1a_hash(None, 0) == 14695981039346656037   # offset basis, record_batch_convert.rs:124
+
+
+@pytest.mark.parametrize("jt", [0, 1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_multi_column_null_aware_join_vs_brute_force(seed, jt):
+    """orc_hash_join_multi (composite keys, SQL NULLs, outer joins) has no counterpart in the reference: pinned here by a pure-Python
+    nested loop on small tables -- rows match when EVERY key column is equal and none is NULL; Left / Right / Full keep unmatched
+    rows of the preserved side with the other id = 0xFFFFFFFF."""
+    rng = np.random.default_rng(seed)
+    nb, npr, nc = 57, 83, int(rng.integers(1, 4))
+    bc = [rng.integers(-3, 4, nb).astype(np.int64) for _ in range(nc)]
+    pc = [rng.integers(-3, 4, npr).astype(np.int64) for _ in range(nc)]
+    bv = [None if rng.random() < 0.3 else (rng.random(nb) > 0.2).astype(np.uint8) for _ in range(nc)]
+    pv = [None if rng.random() < 0.3 else (rng.random(npr) > 0.2).astype(np.uint8) for _ in range(nc)]
+    ok_b = [all(bv[c] is None or bv[c][i] for c in range(nc)) for i in range(nb)]
+    ok_p = [all(pv[c] is None or pv[c][j] for c in range(nc)) for j in range(npr)]
+    pairs, hit_b, hit_p = [], [False] * nb, [False] * npr
+    for j in range(npr):
+        for i in range(nb):
+            if ok_b[i] and ok_p[j] and all(bc[c][i] == pc[c][j] for c in range(nc)):
+                pairs.append((i, j)); hit_b[i] = True; hit_p[j] = True
+    NULL = 0xFFFFFFFF
+    if jt & 1:
+        pairs += [(i, NULL) for i in range(nb) if not hit_b[i]]
+    if jt & 2:
+        pairs += [(NULL, j) for j in range(npr) if not hit_p[j]]
+    exp = T.canonical(np.array(pairs, np.uint32).reshape(-1, 2))
+    got, m = oracle.hash_join_multi(bc, pc, jt, bv, pv)
+    assert m == exp.shape[0] and np.array_equal(got, exp)
