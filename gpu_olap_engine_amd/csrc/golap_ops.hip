@@ -257,6 +257,7 @@ __global__ void k_counts_from_stats(const double* __restrict__ stats4, uint32_t 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t slot_of(KeyT key, uint32_t n_groups) {
     const unsigned long long u = (unsigned long long)key;
+    if ((n_groups & (n_groups - 1u)) == 0) return (uint32_t)u & (n_groups - 1u);   // work-group-uniform: a power of two is a mask
     if ((u >> 32) == 0) return (uint32_t)u % n_groups;
     return (uint32_t)(u % n_groups);
 }
@@ -505,18 +506,31 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
     const long long* vi = (const long long*)val;
     const double* vf = (const double*)val;
     for (uint32_t b = tid; b < B; b += AGB_THREADS) s_gpos[b] = scanned[(size_t)b * S + blockIdx.x];
-    for (unsigned long long t0 = lo; t0 < hi; t0 += AGB_TILE) {
+    // The tile's raw rows live in registers from their load to their staging; the NEXT tile's rows are requested as soon as the
+    // last window has been staged (the registers are dead from then on), so its HBM reads run under this tile's write-out instead
+    // of after it (the SQ counters had this kernel parked at waits 77 % of the time: one work-group per CU, nothing else to overlap).
+    KeyT kraw[AGB_RPT];
+    double x[AGB_RPT];
+    uint32_t nullbits = 0;   // bit r: the value of row r is NULL
+    auto load_tile = [&](unsigned long long t0) {
         const uint32_t tn = hi - t0 < (unsigned long long)AGB_TILE ? (uint32_t)(hi - t0) : (uint32_t)AGB_TILE;
-        for (uint32_t b = tid; b < B; b += AGB_THREADS) s_cnt[b] = 0;
-        uint32_t slot[AGB_RPT], br[AGB_RPT];
-        double x[AGB_RPT];
+        nullbits = 0;
 #pragma unroll
         for (int r = 0; r < AGB_RPT; ++r) {   // unconditional loads on clamped indices: all in flight together
             const uint32_t i = r * AGB_THREADS + tid;
             const unsigned long long gi = t0 + (i < tn ? i : tn - 1);
-            slot[r] = slot_of(keys[gi], n_groups) | ((vv && !vv[gi]) ? AG_NULL_MARK : 0u);
+            kraw[r] = keys[gi];
             x[r] = VAL_F64 ? vf[gi] : (double)vi[gi];   // executor.rs:521 `as f64`
+            if (vv) nullbits |= (vv[gi] ? 0u : 1u) << r;
         }
+    };
+    load_tile(lo);
+    for (unsigned long long t0 = lo; t0 < hi; t0 += AGB_TILE) {
+        const uint32_t tn = hi - t0 < (unsigned long long)AGB_TILE ? (uint32_t)(hi - t0) : (uint32_t)AGB_TILE;
+        for (uint32_t b = tid; b < B; b += AGB_THREADS) s_cnt[b] = 0;
+        uint32_t slot[AGB_RPT], br[AGB_RPT];
+#pragma unroll
+        for (int r = 0; r < AGB_RPT; ++r) slot[r] = slot_of(kraw[r], n_groups) | (((nullbits >> r) & 1u) ? AG_NULL_MARK : 0u);
         lds_barrier();
 #pragma unroll
         for (int r = 0; r < AGB_RPT; ++r) {
@@ -542,7 +556,9 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
 #pragma unroll
         for (int r = 0; r < AGB_RPT; ++r)
             if (br[r] != 0xFFFFFFFFu) br[r] = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
-        for (uint32_t w0 = 0; w0 < tn; w0 += AGB_WIN) {
+        // windows: stage, (last window: request the next tile -- slot / br / x are dead from here on, which hipcc only sees when the
+        // last window is not an iteration of the loop), write out
+        auto window = [&](uint32_t w0, auto last) {
 #pragma unroll
             for (int r = 0; r < AGB_RPT; ++r) {
                 const uint32_t pos = br[r] - w0;   // invalid rows and rows of the other window fall outside
@@ -552,6 +568,9 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
                 }
             }
             lds_barrier();
+            if constexpr (decltype(last)::value) {
+                if (t0 + AGB_TILE < hi) load_tile(t0 + AGB_TILE);   // work-group-uniform
+            }
             const uint32_t wn = tn - w0 < (uint32_t)AGB_WIN ? tn - w0 : (uint32_t)AGB_WIN;
 #pragma unroll 4
             for (int j = 0; j < AGB_WIN / AGB_THREADS; ++j) {
@@ -564,7 +583,10 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
                 }
             }
             lds_barrier();
-        }
+        };
+        uint32_t w0 = 0;
+        for (; w0 + AGB_WIN < tn; w0 += AGB_WIN) window(w0, std::false_type{});
+        window(w0, std::true_type{});
         for (uint32_t b = tid; b < B; b += AGB_THREADS) s_gpos[b] += s_cnt[b];
     }
 }
