@@ -107,6 +107,63 @@ def test_sharded_join_ranks_share_one_gpu(world, variant, mode):
         assert info["host_syncs"] == (1 if mode == "fast" else 3)
 
 
+def _worker_big(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpu_olap_engine_amd import _native as N
+        from gpu_olap_engine_amd.distributed import NativeShardedJoin
+        from gpu_olap_engine_amd.engine import Context, shard_range
+        torch.cuda.set_device(0)
+        c = Context(max_gpu_memory=0)
+        lo, hi = shard_range(n, rank, world)
+        b = c.generate(N.GEN_BUILD_KEYS, hi - lo, modulus=n, first=lo)            # a permutation of 0..n-1 over all ranks
+        p = c.generate(N.GEN_SM64_MOD_I64, hi - lo, modulus=n, seed=43, first=lo)
+        sj = NativeShardedJoin(c, transport="staged")
+        cap = int((hi - lo) * 1.3) + 65536
+        out = torch.empty((cap, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt, info = sj.join(b, p, lo, lo, n, out_pairs=out, max_pairs=cap)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        pr = pairs[:m].to(torch.int64) & 0xFFFFFFFF
+        # every probe row id at most once on this rank; the pair's keys are equal: recompute both from the generators' formulas
+        bk = (2654435761 * pr[:, 0] + 12345) % n
+        pk = c.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)[pr[:, 1]]     # (the whole probe column: n is small enough)
+        ok = bool((bk == pk).all())
+        q.put((rank, m, int(pr[:, 1].sum().item()), ok, info))
+        dist.barrier()
+        sj.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 64_000_000), (4, 120_000_000)])
+def test_sharded_fast_path_at_its_natural_size(world, n):
+    """No knobs: >= 25M rows per rank, so the plan is the production one (extra bits, 8 sub-ranges per bucket, world x 8 pieces per
+    group in the ring pass, 512 MiB message pieces); the ranks share the one GPU and the bytes travel through gloo.  Checked without
+    the oracle: unique build keys, so every probe row matches exactly once over all ranks (count and id sum) and every pair's keys
+    are equal."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_big, args=(r, world, port, n, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert sum(r[1] for r in res) == n
+    assert sum(r[2] for r in res) == n * (n - 1) // 2
+    assert all(r[3] for r in res)
+    for r in res:
+        assert r[4]["fast_path"] and r[4]["host_syncs"] == 1 and not r[4]["fast_path_abandoned"]
+
+
 def test_sharded_join_one_wide_key_sends_every_rank_to_the_exact_path():
     """The fast path's status word is gathered: ONE key outside [0, 2^32) on ONE rank and all ranks redo the join exactly."""
     from np_twin import canonical
