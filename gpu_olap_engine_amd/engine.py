@@ -452,8 +452,11 @@ class Comm:
             pass
 
     def sharded_join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, n_probe_total=None, out_pairs=None,
-                     max_pairs=None, out_count=None, join_type=0, force_exact=False, max_msg_bytes=0):
-        """golap_sharded_join (collective).  -> (pairs int32[max_pairs,2] with GLOBAL u32 row ids, count int64[1] device)."""
+                     max_pairs=None, out_count=None, join_type=0, force_exact=False, max_msg_bytes=0, build_rows_per_rank=None,
+                     probe_rows_per_rank=None):
+        """golap_sharded_join (collective).  -> (pairs int32[max_pairs,2] with GLOBAL u32 row ids, count int64[1] device).
+        *_rows_per_rank: the row count of every rank's shard (sequences of world ints) when the split is not shard_range's even one --
+        every rank must pass the same lists (the fast path sizes its messages from them without asking anybody)."""
         _chk_tensor(build_keys, torch.int64, "build_keys")
         _chk_tensor(probe_keys, torch.int64, "probe_keys")
         if n_probe_total is None:
@@ -465,8 +468,15 @@ class Comm:
             max_pairs = out_pairs.numel() // 2
         if out_count is None:
             out_count = torch.zeros(1, dtype=torch.int64, device=build_keys.device)
+        def rows(v, mine):
+            if v is None:
+                return None
+            if len(v) != self.world or int(v[self.rank]) != mine:
+                raise ValueError("rows_per_rank needs one entry per rank, and this rank's entry must be its shard's row count")
+            return (C.c_uint64 * self.world)(*[int(x) for x in v])
+        brows, prows = rows(build_rows_per_rank, build_keys.numel()), rows(probe_rows_per_rank, probe_keys.numel())
         prm = N.ShardedJoinParams(_ptr(build_keys), _ptr(probe_keys), build_keys.numel(), probe_keys.numel(), build_rid_base, probe_rid_base,
-                                  n_build_total, n_probe_total, None, None, _ptr(out_pairs), _ptr(out_count), max_pairs, join_type,
+                                  n_build_total, n_probe_total, brows, prows, _ptr(out_pairs), _ptr(out_count), max_pairs, join_type,
                                   1 if force_exact else 0, max_msg_bytes)
         self.ctx._ck(self.ctx._lib.golap_sharded_join(self.ctx._h, self._h, C.byref(prm), _stream()))
         return out_pairs, out_count

@@ -186,6 +186,66 @@ def test_sharded_outer_joins(mode, join_type):
     assert got.shape[0] == me and np.array_equal(got, exp)
 
 
+def _worker_uneven(rank, world, port, n, cuts, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if mode == "fast":
+        os.environ["GOLAP_DEBUG_ENV"] = "1"
+        os.environ["GOLAP_SHARD_FAST"] = "1"
+        os.environ["GOLAP_LOCAL_BITS"] = "6"
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from gpu_olap_engine_amd.distributed import NativeShardedJoin
+        from gpu_olap_engine_amd.engine import Context
+        torch.cuda.set_device(0)
+        c = Context(max_gpu_memory=0)
+        lo_b, hi_b = cuts[0][rank], cuts[0][rank + 1]
+        lo_p, hi_p = cuts[1][rank], cuts[1][rank + 1]
+        b = oracle.gen_sm64_mod(11, lo_b, hi_b - lo_b, n // 2)
+        p = oracle.gen_sm64_mod(12, lo_p, hi_p - lo_p, n // 2)
+        sj = NativeShardedJoin(c, transport="staged")
+        out = torch.empty((4 * n + 16, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt, info = sj.join(torch.from_numpy(b).cuda(), torch.from_numpy(p).cuda(), lo_b, lo_p, n, n, out_pairs=out,
+                                   force_exact=(mode == "exact"),
+                                   build_rows_per_rank=[cuts[0][r + 1] - cuts[0][r] for r in range(world)],
+                                   probe_rows_per_rank=[cuts[1][r + 1] - cuts[1][r] for r in range(world)])
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        q.put((rank, pairs[:m].cpu().numpy().view(np.uint32).copy(), info))
+        dist.barrier()
+        sj.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_sharded_join_uneven_shards(mode):
+    """Shards of different sizes (and different splits of the two tables): the fast path sizes every message from the SOURCE rank's row
+    count, which every rank takes from the rows-per-rank lists -- the receiving side must provision exactly what the sender sends."""
+    import oracle
+    import torch.multiprocessing as mp
+    from np_twin import canonical
+    n, world = 2_400_000, 4
+    cuts = ([0, 300_000, 1_900_000, 1_900_000, n], [0, 1_100_000, 1_150_000, 2_000_000, n])       # (one build shard is empty)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_uneven, args=(r, world, port, n, cuts, mode, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    exp, me = oracle.hash_join(oracle.gen_sm64_mod(11, 0, n, n // 2), oracle.gen_sm64_mod(12, 0, n, n // 2))
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+    assert all(r[2]["fast_path"] == (mode == "fast") for r in res)
+
+
 def test_sharded_join_small_messages_are_split():
     """max_msg_bytes far below a message: every (source, destination) message travels in many pieces, both ends agree on them."""
     from np_twin import canonical
