@@ -284,6 +284,8 @@ def bench_join(args, n_total, label):
         line["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if sharded:
+        comm.close()       # (the communicator before the context it was made on)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -85,6 +85,10 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for ref in getattr(self, "_comms", []):      # communicators go first: golap_comm_destroy uses the context's device
+                c = ref()
+                if c is not None:
+                    c.close()
             self._lib.golap_ctx_destroy(self._h)
             self._h = None
 
@@ -438,7 +442,11 @@ class Comm:
     """golap_comm: a context bound to a communicator (one process per GPU)."""
 
     def __init__(self, ctx, handle, world, rank):
+        import weakref
         self.ctx, self._h, self.world, self.rank = ctx, handle, world, rank
+        if not hasattr(ctx, "_comms"):
+            ctx._comms = []
+        ctx._comms.append(weakref.ref(self))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -330,7 +330,7 @@ typedef struct golap_transport {
 int32_t golap_comm_unique_id(uint8_t out_id[GOLAP_COMM_ID_BYTES]);                     /* ncclGetUniqueId (rank 0, then broadcast by the host) */
 int32_t golap_comm_create_rccl(golap_ctx* ctx, const uint8_t id[GOLAP_COMM_ID_BYTES], int32_t world, int32_t rank, golap_comm** out);
 int32_t golap_comm_create_custom(golap_ctx* ctx, const golap_transport* transport, int32_t world, int32_t rank, golap_comm** out);
-void    golap_comm_destroy(golap_comm* comm);
+void    golap_comm_destroy(golap_comm* comm);   /* before golap_ctx_destroy of the context it was created on */
 
 typedef struct golap_sharded_join_params {
     uint64_t build_key_ptr, probe_key_ptr;       /* device int64: this rank's rows */
