@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rows of the bounded CPU-baseline sample (-1 = the config's default, 0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-wide", action="store_true", help="C5: skip the second timed leg with 64-bit keys")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="developer: run the N > 1 code path on ONE GPU (all ranks on device 0, gloo + host-staged transport instead of RCCL); "
+                         "the numbers mean nothing, the line is marked")
     ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (golap_sharded_join) even with 1 rank")
     return ap.parse_args()
 
@@ -139,14 +142,19 @@ def bench_join(args, n_total, label):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.sharded
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # barrier / max-over-ranks only; the join's own
-                                                                                       # exchange is the library's RCCL communicator
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # barrier / max-over-ranks only; the join's own
+                                                                                           # exchange is the library's RCCL communicator
     ctx = Context(profiling=True, max_gpu_memory=0)
     info = ctx.device_info()
 
@@ -168,7 +176,7 @@ def bench_join(args, n_total, label):
     else:
         if world > 1:
             from gpu_olap_engine_amd.distributed import NativeShardedJoin
-            sj = NativeShardedJoin(ctx, transport="rccl")
+            sj = NativeShardedJoin(ctx, transport="staged" if args.rehearse else "rccl")
             comm = sj.comm
         else:
             from gpu_olap_engine_amd.engine import comm_unique_id
@@ -234,7 +242,7 @@ def bench_join(args, n_total, label):
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "int64",
-        "data": "synthetic",
+        "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, host-staged transport -- not a measurement)" if args.rehearse else ""),
         "config": {"workload": f"{label} radix hash join {n_total} x {n_total} int64 keys (all below 2^32: the 8-byte tuple pipeline), 256 radix "
                                f"partitions, unique build keys, M = N_probe",
                    "n_build": n_total, "n_probe": n_total, "rows_per_gpu_per_side": n_local, "narrow_keys": True,
