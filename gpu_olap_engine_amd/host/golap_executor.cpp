@@ -37,7 +37,7 @@ struct Column {
     std::vector<uint8_t> valid;  // Arrow validity bitmap of an exported column (empty = all valid)
     std::vector<uint8_t> in_valid;   // byte per row, 0 = NULL (ColumnBuffer.validity, column_buffer.rs:59-60); empty = no NULLs.  Travels with
                                      // the column through the operators; GpuFilter and GpuHashJoin hand it to the kernels (NULL keys
-                                     // match nothing), aggregates read the zero the ingest leaves in a NULL slot (record_batch_convert.rs:102-110)
+                                     // match nothing), GpuAggregate skips NULL values and puts NULL group keys into a group of their own
     uint64_t null_count = 0;
     uint64_t rows = 0;
     size_t width() const { return dtype == DType::Int32 ? 4 : 8; }
@@ -559,8 +559,77 @@ static const char* agg_name(int32_t f) {
 // ---------------------------------------------------------------------------
 // execute_aggregate, executor.rs:297-355 (+ eval_agg_input :509-527)
 // ---------------------------------------------------------------------------
+// rows `idx` of a batch (host side; values, widths and validity bytes travel together)
+static RecordBatch take_rows(const RecordBatch& b, const std::vector<uint64_t>& idx) {
+    RecordBatch o;
+    o.num_rows = idx.size();
+    for (const Column& c : b.cols) {
+        Column oc;
+        oc.name = c.name; oc.dtype = c.dtype; oc.rows = idx.size();
+        const size_t w = c.width();
+        oc.data.resize(idx.size() * w);
+        for (size_t i = 0; i < idx.size(); ++i) memcpy(oc.data.data() + i * w, c.data.data() + idx[i] * w, w);
+        if (!c.in_valid.empty()) {
+            oc.in_valid.resize(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) oc.in_valid[i] = c.in_valid[idx[i]];
+        }
+        o.cols.push_back(std::move(oc));
+    }
+    return o;
+}
+
 int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out) {
     const uint32_t na = (uint32_t)p.aggr_inputs.size();
+    // NULL group keys: SQL puts them into ONE group of their own.  Only when the key column really carries NULLs: the rows are
+    // split on the host, the rows with a key take the ordinary path below, the others an ungrouped aggregate, and the result
+    // gets one more row whose key is NULL (last, like NULLS LAST).
+    if (p.group_by.size() == 1 && p.group_by[0]->kind == golap_expr::Column) {
+        bool key_nulls = false;
+        for (const RecordBatch& b : in) {
+            const int ci = resolve_column(*p.group_by[0], b);
+            if (ci >= 0 && !b.cols[ci].in_valid.empty())
+                for (uint8_t v : b.cols[ci].in_valid) if (!v) { key_nulls = true; break; }
+            if (key_nulls) break;
+        }
+        if (key_nulls) {
+            std::vector<RecordBatch> with_key, without_key;
+            for (const RecordBatch& b : in) {
+                const int ci = resolve_column(*p.group_by[0], b);
+                if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + p.group_by[0]->name + "' not found in batch");
+                std::vector<uint64_t> yes, no;
+                const std::vector<uint8_t>& kv = b.cols[ci].in_valid;
+                for (uint64_t i = 0; i < b.num_rows; ++i) (kv.empty() || kv[i] ? yes : no).push_back(i);
+                RecordBatch y = take_rows(b, yes), n = take_rows(b, no);
+                y.cols[ci].in_valid.clear();              // no NULL keys left on this side
+                with_key.push_back(std::move(y));
+                without_key.push_back(std::move(n));
+            }
+            std::vector<RecordBatch> g, u;
+            H_TRY(aggregate(with_key, p, g));
+            auto gb = std::move(p.group_by);
+            p.group_by.clear();
+            const int32_t rc = aggregate(without_key, p, u);   // one row: the aggregates over the rows whose key is NULL
+            p.group_by = std::move(gb);
+            H_TRY(rc);
+            RecordBatch ob = g.empty() ? RecordBatch() : std::move(g[0]);
+            if (ob.cols.empty()) return herr(GOLAP_ERR_INVALID_ARG, "GpuAggregate: empty grouped result");
+            Column& kc = ob.cols[0];
+            kc.in_valid.assign(ob.num_rows, 1);
+            kc.in_valid.push_back(0);
+            kc.data.resize(kc.data.size() + 8, 0);
+            for (uint32_t i = 0; i < na; ++i) {
+                Column& ac = ob.cols[1 + i];
+                const Column& uc = u[0].cols[i];
+                ac.data.insert(ac.data.end(), uc.data.begin(), uc.data.begin() + 8);
+                if (!ac.in_valid.empty()) ac.in_valid.push_back(1);
+                ac.rows = ob.num_rows + 1;
+            }
+            ob.num_rows += 1;
+            kc.rows = ob.num_rows;
+            out.push_back(std::move(ob));
+            return GOLAP_OK;
+        }
+    }
     // gather the distinct value columns the aggregates read
     std::vector<std::string> val_names;
     std::vector<uint64_t> spec_col(na);

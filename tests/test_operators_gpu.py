@@ -276,6 +276,30 @@ def test_aggregates_skip_null_values(ctx):
     assert [out[0].column(i)[0].as_py() for i in range(3)] == [e["sum"], e["count"], e["max"]]
 
 
+def test_group_by_null_keys_form_one_group(ctx):
+    """NULL group keys: one group of their own (SQL), reported last with a NULL key; the other groups are what they would be without
+    those rows -- in particular key 0 does not absorb them (the reference's ingest turns a NULL key into 0)."""
+    n = 30_000
+    rng = np.random.default_rng(33)
+    g = rng.integers(0, 12, n).astype(np.int64)
+    v = rng.integers(-100, 100, n).astype(np.float64)
+    knull = rng.random(n) < 0.2
+    vnull = rng.random(n) < 0.1
+    garr = pa.array([None if m else int(x) for x, m in zip(g, knull)], pa.int64())
+    varr = pa.array([None if m else float(x) for x, m in zip(v, vnull)], pa.float64())
+    b1 = pa.RecordBatch.from_arrays([garr[:10_000], varr[:10_000]], names=["g", "v"])
+    b2 = pa.RecordBatch.from_arrays([garr[10_000:], varr[10_000:]], names=["g", "v"])
+    out = O.execute(O.GpuAggregate(O.Batches([b1, b2]), [O.Column(0, "g")], [O.Sum(O.Column(1, "v")), O.Count(O.Column(1, "v"))]), ctx)
+    keys = out[0].column(0).to_pylist()
+    assert keys[:-1] == sorted(set(g[~knull].tolist())) and keys[-1] is None
+    live = ~knull & ~vnull
+    ks, st = oracle.group_aggregate(g[live], v[live])
+    assert np.array_equal(np.array(keys[:-1]), ks)
+    assert np.array_equal(out[0].column(1).to_numpy()[:-1], st[:, 0]) and np.array_equal(out[0].column(2).to_numpy()[:-1], st[:, 1])
+    e = oracle.execute_aggregate(v[knull & ~vnull])
+    assert out[0].column(1)[-1].as_py() == e["sum"] and out[0].column(2)[-1].as_py() == e["count"]
+
+
 def test_group_by_many_aggregates_on_a_fresh_context():
     """A fresh context, a small table, six aggregates over six distinct columns: more than eight same-class slabs are alive at once
     (one per column + keys + outputs); the slab pool's per-class limit is a config field (slab_allocator.rs:25-28), not 8."""
