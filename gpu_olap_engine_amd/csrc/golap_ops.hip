@@ -217,7 +217,8 @@ __global__ __launch_bounds__(OP_THREADS) void k_reduce_partials(const long long*
 }
 
 // folds partials[0..n_part) in index order (strided per thread, then a fixed tree)
-__global__ __launch_bounds__(OP_THREADS) void k_reduce_final(const double* __restrict__ partials, uint32_t n_part, double* __restrict__ out4) {
+__global__ __launch_bounds__(OP_THREADS) void k_reduce_final(const double* __restrict__ partials, uint32_t n_part, double* __restrict__ out4,
+                                                             uint32_t n_out = 4 /*how many of sum, count, min, max the caller's buffer takes*/) {
     __shared__ double s[4 * OP_WAVES];
     Acc4 a{0.0, 0.0, GOLAP_F64_MAX, -GOLAP_F64_MAX};
     for (uint32_t i = threadIdx.x; i < n_part; i += OP_THREADS) {
@@ -226,7 +227,11 @@ __global__ __launch_bounds__(OP_THREADS) void k_reduce_final(const double* __res
         a.mx = partials[i * 4 + 3] > a.mx ? partials[i * 4 + 3] : a.mx;
     }
     block_reduce_acc(a, s);
-    if (threadIdx.x == 0) { out4[0] = a.sum; out4[1] = a.cnt; out4[2] = a.mn; out4[3] = a.mx; }
+    if (threadIdx.x == 0) {
+        out4[0] = a.sum;
+        if (n_out > 1) out4[1] = a.cnt;
+        if (n_out > 2) { out4[2] = a.mn; out4[3] = a.mx; }
+    }
 }
 
 // out[spec plane * n_groups + g] from stats4[g] = sum,count,min,max (executor.rs:334-346)
@@ -863,8 +868,7 @@ int32_t golap_filter_sum_nullable(golap_ctx* ctx, const golap_filter_predicate* 
     const uint32_t grid = stream_grid(ctx, n_rows, OP_THREADS * 8);
     GOLAP_TRY(ws_begin(ctx, (uint64_t)grid * 32 + 4096, st));
     double* partials = (double*)ws_take(ctx, (uint64_t)grid * 32);
-    double* out4 = (double*)ws_take(ctx, 32);
-    if (!partials || !out4) return fail(ctx, GOLAP_ERR_OOM, "workspace exhausted");
+    if (!partials) return fail(ctx, GOLAP_ERR_OOM, "workspace exhausted");
     {
         KernelTimer t(ctx, "filter_sum", st, 16 * n_rows);
         if (value_is_f64)
@@ -875,9 +879,8 @@ int32_t golap_filter_sum_nullable(golap_ctx* ctx, const golap_filter_predicate* 
             hipLaunchKernelGGL((k_reduce_partials<false, true>), dim3(grid), dim3(OP_THREADS), 0, st, (const long long*)key_column_ptr,
                                (const void*)value_column_ptr, (unsigned long long)n_rows, pred->op, (long long)pred->literal, partials,
                                (const uint8_t*)key_validity_ptr, (const uint8_t*)value_validity_ptr);
-        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, grid, out4);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, grid, (double*)out_ptr, 2u);   // sum, kept-count: straight into the caller's buffer
     }
-    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)out_ptr, out4, 16, hipMemcpyDeviceToDevice, st));   // sum, kept-count
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     ws_end(ctx, st);
     return GOLAP_OK;
