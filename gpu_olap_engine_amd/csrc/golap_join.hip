@@ -1416,10 +1416,19 @@ static uint32_t slots_for(uint32_t G, uint64_t n_rows) {
 // uniform chunks of the global first pass: <= 2048 work-groups; once the input is large enough, chunks of at least four
 // 24576-row tiles so that the 1024-thread big-tile scatter applies (launch_hist_scatter)
 // `tile`: chunks are whole tiles of the kernel that will read them (only a side's very last chunk then ends in a partial tile)
-static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out, uint32_t tile = PT_TILE) {
+// tiles (of 24576 rows) every work-group of the big-tile first pass gets at least: the size from which that form -- and with it the
+// no-histogram tuple pipeline -- is used.  2 since round 2 (13M rows per side; 4 = 25M before): the rewritten passes win from there
+// (scripts/size_sweep.py: 16M x 16M 0.75 -> 0.63 ms, 24M x 24M 0.97 -> 0.74 ms).  GOLAP_MIN_TILES: A/B hook.
+static uint32_t big_tile_min_tiles() {
+    const char* e = knob("GOLAP_MIN_TILES");
+    const int v = e ? atoi(e) : 2;
+    return (uint32_t)(v >= 1 && v <= 16 ? v : 2);
+}
+
+static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out, uint32_t tile = PT_TILE, uint32_t min_tiles = 4) {
     const uint64_t n = std::max<uint64_t>(1, n_rows);
     uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n, PT_TILE)));
-    const uint64_t big = n / (4 * 24576);
+    const uint64_t big = n / ((uint64_t)min_tiles * 24576);
     if (big >= 256) c1 = std::min<uint64_t>(2048, big / 256 * 256);   // whole rounds of one 1024-thread work-group per CU (256 CUs)
     const uint32_t chunk_rows = (uint32_t)round_up(round_up(ceil_div(n, c1), PT_TILE), big >= 256 ? tile : PT_TILE);
     if (chunk_rows_out) *chunk_rows_out = chunk_rows;
@@ -1513,25 +1522,32 @@ static uint64_t reserve_cap_sub(uint64_t n_rows, uint32_t F, uint32_t nsub, uint
 
 // No-histogram FIRST pass: single-source global pass of a two-pass plan whose second pass is the no-histogram one,
 // large enough for the 1024-thread big-tile kernel.
+static bool narrow_size_ok(uint64_t n_rows);
 static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool has_segs, bool has_rids) {
     const char* env = knob("GOLAP_RESERVE");   // "0" disables (A/B hook), "1" drops the size condition (test hook)
     if (env && !strcmp(env, "0")) return false;
     if (!use_fast_last_pass(plan, has_segs) || has_rids) return false;
     const uint32_t F = plan.passes[0].cfg.F;
     if (!use_big_scatter(F, false, false) || F > (uint32_t)WC_MAX_F) return false;   // the stand-by pass uses the write-combining scatter
-    uint32_t chunk_rows = 0;
-    const uint32_t chunks = first_pass_chunks(n_rows, &chunk_rows);
-    if (!(env && !strcmp(env, "1")) && (chunks < 224 || n_rows / chunks < 4 * 24576)) return false;   // (rounding chunk rows up to whole 4096-row tiles can leave a few fewer than 256)
+    if (!(env && !strcmp(env, "1")) && !narrow_size_ok(n_rows)) return false;
     return reserve_cap(n_rows, F) * F < 0xFFFFFFF0ull;
 }
 
 static uint32_t part1_narrow_tile();
+// chunking of the tuple pipeline's first pass (k_part1_narrow: one 1024-thread work-group per chunk, whole tiles per chunk) and the
+// size rule for using it: (almost) every CU gets a chunk of at least big_tile_min_tiles() tiles
+static uint32_t narrow_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) { return first_pass_chunks(n_rows, chunk_rows_out, part1_narrow_tile(), big_tile_min_tiles()); }
+static bool narrow_size_ok(uint64_t n_rows) {
+    uint32_t chunk_rows = 0;
+    const uint32_t chunks = narrow_chunks(n_rows, &chunk_rows);
+    return chunks >= 192 && n_rows / chunks >= (uint64_t)big_tile_min_tiles() * part1_narrow_tile();
+}
 // rows the first-pass output buffer must hold
 static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
     if (!use_reserve_first_pass(plan, n, has_segs, false)) return n;
     const uint32_t F = plan.passes[0].cfg.F, nsub = narrow_nsub();
     uint32_t chunk_rows = 0;
-    const uint32_t nc = first_pass_chunks(n, &chunk_rows, part1_narrow_tile());
+    const uint32_t nc = narrow_chunks(n, &chunk_rows);
     return std::max<uint64_t>(std::max<uint64_t>(n, reserve_cap(n, F) * F), reserve_cap_sub(n, F, nsub, nc, chunk_rows) * F * nsub);   // (narrow tuples: 8 B per row as well)
 }
 
@@ -2008,7 +2024,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     const PassPlan& p2 = plan.passes[1];
     const uint32_t F1 = p1.cfg.F, G = p2.G, F2 = p2.cfg.F;
     uint32_t chunk_rows = 0;
-    const uint32_t nc = first_pass_chunks(n_rows, &chunk_rows, part1_narrow_tile());
+    const uint32_t nc = narrow_chunks(n_rows, &chunk_rows);
     const uint32_t nsub = (p2r_variant() == 0 || F2 > (uint32_t)P2R_MAX_F) ? 1u : narrow_nsub();   // (the write-combining second pass reads one extent per group)
     // k_part1_narrow + k_part2_ring hand the HASH of the key on instead of the key (a bijection of the 32 key bits): the ring pass
     // and the join need not hash again, equality is the same.  (The A/B knobs that pair an old kernel with a new one keep keys.)

@@ -188,7 +188,7 @@ static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_p
         sp.cap[side].resize(world);
         for (uint32_t r = 0; r < world; ++r) {
             uint32_t chunk_rows = 0;
-            const uint32_t chunks = first_pass_chunks(sp.rows[side][r], &chunk_rows, part1_narrow_tile());
+            const uint32_t chunks = narrow_chunks(sp.rows[side][r], &chunk_rows);
             sp.cap[side][r] = reserve_cap_sub(sp.rows[side][r], sp.F1, sp.nsub, chunks, chunk_rows);
         }
     }
@@ -197,9 +197,7 @@ static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_p
     bool ok = world <= (uint32_t)P2R_MAX_SRC && sp.local.passes.size() == 1 && sp.F2 >= 32 && sp.F2 <= (uint32_t)P2R_MAX_F && sp.per <= 1024;
     for (int side = 0; side < 2 && ok; ++side)
         for (uint32_t r = 0; r < world && ok; ++r) {
-            uint32_t chunk_rows = 0;
-            const uint32_t chunks = first_pass_chunks(sp.rows[side][r], &chunk_rows, part1_narrow_tile());
-            if (chunks < 224 || sp.rows[side][r] / chunks < 4 * 24576) ok = false;
+            if (!narrow_size_ok(sp.rows[side][r])) ok = false;
             if (sp.cap[side][r] * sp.F1 * sp.nsub >= 0xFFFFFFF0ull) ok = false;
         }
     const char* env = knob("GOLAP_SHARD_FAST");   // test hook: "1" drops the size condition, "0" disables the fast path
@@ -336,7 +334,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         hdr[side] = (uint32_t*)ws_take(ctx, (uint64_t)hdr_stride * 4);          // [F1] reservation cursors, [F1] this rank's failure word
         hdr_all[side] = (uint32_t*)ws_take(ctx, (uint64_t)P * hdr_stride * 4);
         uint32_t chunk_rows = 0;
-        const uint32_t nc = first_pass_chunks(n_local[side], &chunk_rows, part1_narrow_tile());
+        const uint32_t nc = narrow_chunks(n_local[side], &chunk_rows);
         uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
         uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
         if (!hdr[side] || !hdr_all[side] || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");

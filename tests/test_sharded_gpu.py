@@ -142,7 +142,7 @@ def _worker_big(rank, world, port, n, q):
 
 @pytest.mark.parametrize("world,n", [(2, 64_000_000), (4, 120_000_000)])
 def test_sharded_fast_path_at_its_natural_size(world, n):
-    """No knobs: >= 25M rows per rank, so the plan is the production one (extra bits, 8 sub-ranges per bucket, world x 8 pieces per
+    """No knobs: well above the fast path's size rule (>= 16M rows per rank), so the plan is the production one (extra bits, 8 sub-ranges per bucket, world x 8 pieces per
     group in the ring pass, 512 MiB message pieces); the ranks share the one GPU and the bytes travel through gloo.  Checked without
     the oracle: unique build keys, so every probe row matches exactly once over all ranks (count and id sum) and every pair's keys
     are equal."""
