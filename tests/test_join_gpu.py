@@ -709,3 +709,28 @@ def test_composite_key_join_large_radix(ctx):
     pi = rng.integers(0, n, m)
     p = [b[0][pi], b[1][pi]]
     _multi_check(ctx, b, p, N.JT_INNER, N.JOIN_RADIX_HASH)
+
+
+def test_key_columns_that_are_only_8_byte_aligned(ctx):
+    """The first pass reads its keys in 16-byte words when the column allows it; a column that starts 8 bytes into an allocation (a
+    sliced Arrow buffer) takes the 8-byte form of the same kernel -- both sides independently, at a size that runs the tuple
+    pipeline (checked on the device: count, key equality of every pair, probe ids a permutation)."""
+    n = 20_000_003
+    bfull = ctx.generate(N.GEN_BUILD_KEYS, n + 1, modulus=n)
+    pfull = ctx.generate(N.GEN_SM64_MOD_I64, n + 3, modulus=n, seed=43)
+    for b, p in ((bfull[1:], pfull[:n]), (bfull[:n], pfull[3:]), (bfull[1:], pfull[1:n + 1])):
+        assert b.data_ptr() % 16 in (0, 8) and p.numel() == n
+        bk = b.clone()                                   # (the generator's key of row i is a function of i: re-derive the expected pairs from the actual columns)
+        out = torch.empty((2 * n, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt = ctx.join(b, p, out_pairs=out, max_pairs=2 * n, strategy=N.JOIN_RADIX_HASH)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        # expected match count: build keys are distinct except possibly the one row that wrapped; count via sort
+        ub, cb = torch.unique(bk, return_counts=True)
+        pos = torch.searchsorted(ub, p)
+        pos = pos.clamp(max=ub.numel() - 1)
+        hit = ub[pos] == p
+        want = int(cb[pos][hit].sum().item())
+        assert m == want
+        v = ctx.verify_pairs(pairs, m, b, p).cpu()
+        assert int(v[0]) == m
