@@ -123,8 +123,16 @@ __global__ void k_setup_from_scan(GroupSrc gs, uint32_t n_groups, uint32_t S, ui
     if (i >= n_groups * S) return;
     uint32_t g = i / S, s = i % S;
     uint32_t start, len;
-    group_extent(gs, g, start, len);
-    uint32_t cr = (len + S - 1) / S;
+    uint32_t per = S;            // chunks per extent
+    const uint32_t np = group_pieces(gs);
+    if (np > 1) {                // a group in per-XCD sub-ranges (the host made S a multiple of their number): chunks per piece
+        per = S / np;
+        group_piece(gs, g, s / per, start, len);
+        s %= per;
+    } else {
+        group_extent(gs, g, start, len);
+    }
+    uint32_t cr = (len + per - 1) / per;
     cr = (cr + PT_TILE - 1) / PT_TILE * PT_TILE;
     unsigned long long o = (unsigned long long)s * cr;
     uint32_t off = o < len ? (uint32_t)o : len;
@@ -710,8 +718,15 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
     const uint32_t chunk = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t len, off, slot0 = 0, cap = 0;
+    uint32_t piece = 0, n_pieces = 1;   // FIXED: the group may come as several pieces (per-XCD sub-ranges of the first pass); they are
+                                        // consumed one after the other, the carried lines do not care where rows come from
     if (FIXED) {   // one work-group = one whole group; buckets go to their pre-provisioned slots
-        group_extent(fx.groups, chunk, off, len);
+        n_pieces = group_pieces(fx.groups);
+        len = 0; off = 0;
+        for (; piece < n_pieces; ++piece) {   // the first piece with rows
+            group_piece(fx.groups, chunk, piece, off, len);
+            if (len) break;
+        }
         slot0 = fx.slot_base[chunk];
         cap = fx.slot_cap[chunk];
         if (len == 0) {
@@ -758,7 +773,15 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
     }
     for (;;) {
         consumed += t_eff;
-        const bool last = consumed >= len;
+        uint32_t n_off = off, n_len = len, n_piece = piece;   // where the NEXT tile comes from
+        if (FIXED && consumed >= len) {
+            n_len = 0;
+            for (++n_piece; n_piece < n_pieces; ++n_piece) {   // work-group-uniform
+                group_piece(fx.groups, chunk, n_piece, n_off, n_len);
+                if (n_len) break;
+            }
+        }
+        const bool last = consumed >= len && (!FIXED || n_len == 0);
         if (tid < F) s_cnt[tid] = s_carry[tid];
         if (tid == 0) s_misc[0] = 0;
         lds_barrier();
@@ -834,6 +857,7 @@ __global__ __launch_bounds__(WC_THREADS) void k_scatter_wc(const long long* __re
         const uint32_t room = (uint32_t)CAP - s_misc[0];
         uint32_t t_next = 0;
         if (!last) {
+            if (FIXED && consumed >= len) { off = n_off; len = n_len; piece = n_piece; consumed = 0; }   // step into the next piece
             t_next = len - consumed;
             if (t_next > (uint32_t)(RPT * WC_THREADS)) t_next = RPT * WC_THREADS;
             if (t_next > room) t_next = room;
@@ -1513,6 +1537,12 @@ static uint32_t narrow_nsub() {
     const uint32_t v = e ? (uint32_t)atoi(e) : 8u;
     return v >= 1 && v <= 8 ? v : 8u;
 }
+// the same for the 64-bit pipeline's reserving first pass (its second pass and the stand-by setup read pieces since round 2)
+static uint32_t wide_nsub() {
+    const char* e = knob("GOLAP_NSUB_WIDE");
+    const uint32_t v = e ? (uint32_t)atoi(e) : 8u;
+    return v >= 1 && v <= 8 ? v : 8u;
+}
 // rows provisioned per (bucket, sub-range): the sub-range of work-groups b = s (mod nsub) receives at most ceil(chunks / nsub) chunks
 static uint64_t reserve_cap_sub(uint64_t n_rows, uint32_t F, uint32_t nsub, uint32_t n_chunks, uint32_t chunk_rows) {
     if (nsub <= 1) return reserve_cap(n_rows, F);
@@ -1548,7 +1578,11 @@ static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
     const uint32_t F = plan.passes[0].cfg.F, nsub = narrow_nsub();
     uint32_t chunk_rows = 0;
     const uint32_t nc = narrow_chunks(n, &chunk_rows);
-    return std::max<uint64_t>(std::max<uint64_t>(n, reserve_cap(n, F) * F), reserve_cap_sub(n, F, nsub, nc, chunk_rows) * F * nsub);   // (narrow tuples: 8 B per row as well)
+    uint32_t wchunk = 0;
+    const uint32_t wnc = first_pass_chunks(n, &wchunk);
+    const uint64_t wide_rows = reserve_cap_sub(n, F, wide_nsub(), wnc, wchunk) * F * wide_nsub();   // the 64-bit pipeline's own chunking
+    return std::max<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(n, reserve_cap(n, F) * F), wide_rows),
+                              reserve_cap_sub(n, F, nsub, nc, chunk_rows) * F * nsub);   // (narrow tuples: 8 B per row as well)
 }
 
 // rows the final buffers of one side must hold: slots are avg + 6 sqrt(avg) + 48, 16-row aligned (k_slots_setup)
@@ -1667,11 +1701,11 @@ static uint64_t side_small_bytes(const JoinPlan& plan, uint64_t n_rows, uint32_t
         uint64_t S;
         if (k == 0 && !has_segs) S = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(std::max<uint64_t>(1, n_rows), PT_TILE)));
         else if (k == 0) S = (uint64_t)n_src * std::max<uint32_t>(1, slots_for(pp.G * n_src, n_rows));
-        else S = slots_for(pp.G, n_rows);
+        else S = round_up(std::max<uint64_t>(slots_for(pp.G, n_rows), 8), 8);   // (a group in up to 8 per-XCD pieces: chunks per piece)
         uint64_t L = (uint64_t)pp.G * pp.cfg.F * S + 1;
         total += round_up(L * 4, 256) + round_up(ceil_div(L, SC_ELEMS) * 4 + 4, 256) + 2 * round_up((uint64_t)pp.G * S * 4, 256) + 1024;
     }
-    return total;
+    return total + 64 * 1024;   // reservation cursors (fan-out x 8 sub-ranges) and flags of both pipelines
 }
 
 // Runs all passes for one side.  `in_keys`/`in_rids` describe pass 0's input; when
@@ -1704,14 +1738,15 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         if (reserve_first && k == 0) {
             // ---- no-histogram first pass: tiles reserve their bucket runs by atomics (k_scatter_big<.., RESERVE>) ----
             const uint32_t F = pp.cfg.F;
-            const uint32_t cap = (uint32_t)reserve_cap(n_rows, F);
-            uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F * 4);
-            uint32_t* flag1 = (uint32_t*)ws_take(ctx, 4);
             const uint32_t nc = first_pass_chunks(n_rows, &chunk_rows);
+            const uint32_t nsub = wide_nsub();   // per-XCD sub-ranges (ReserveArgs::nsub), as in the tuple pipeline
+            const uint32_t cap = (uint32_t)reserve_cap_sub(n_rows, F, nsub, nc, chunk_rows);
+            uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F * nsub * 4);
+            uint32_t* flag1 = (uint32_t*)ws_take(ctx, 4);
             uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
             uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
             if (!cursor || !flag1 || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (reservation arrays)");
-            GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F * 4));
+            GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F * nsub * 4));
             GOLAP_TRY(zero_async(ctx, st, (void*)flag1, 4));
             hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_rows, chunk_rows, nc, c_off, c_len);
             PassCfg cfg = pp.cfg;
@@ -1722,7 +1757,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
 #define GOLAP_RSV(RPT, WIN, WU)                                                                                                            \
     hipLaunchKernelGGL((k_scatter_big<1, RPT, 1024, WIN, 4, false, WU, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F, WIN, 1024), st,      \
                        (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,         \
-                       (long long*)buf.tmp_keys[0], (uint32_t*)buf.tmp_rids[0], cfg, ReserveArgs{cursor, cap, flag1, nullptr, gate})
+                       (long long*)buf.tmp_keys[0], (uint32_t*)buf.tmp_rids[0], cfg, ReserveArgs{cursor, cap, flag1, nullptr, gate, nsub})
                 GOLAP_RSV(24, 12288, 3);
 #undef GOLAP_RSV
             }
@@ -1730,6 +1765,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             groups.cursor = cursor;
             groups.cap = cap;
             groups.flag = flag1;
+            groups.nsub = nsub;
             run_if = flag1;   // the histogram path below stands by
         }
         if (fast_last && k == 1) {
@@ -1769,6 +1805,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             S = segs->n_src * cps;
         } else {
             S = slots_for(pp.G, n_rows);
+            if (groups.nsub > 1) S = (uint32_t)round_up(std::max<uint32_t>(S, groups.nsub), groups.nsub);   // chunks per piece (k_setup_from_scan)
         }
         pp.cfg.S = S;
         n_chunks = pp.G * S;
