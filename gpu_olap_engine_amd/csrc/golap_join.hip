@@ -1390,6 +1390,14 @@ static uint32_t bits_needed(uint64_t n_build) {
         double avg = (double)n_build / (double)(1ull << b);
         if (avg + 4.5 * std::sqrt(avg) <= (double)JN_CAP) break;
     }
+    // 18 bits are two passes of 9, 19 would be three: just above 1.0003B rows the whole join would fall off a cliff (2B x 2B:
+    // 91 ms with three passes of 64-bit rows).  The LDS join loops over table chunks when a sub-partition's build side exceeds one
+    // table (it does so for skew anyway), so up to two tables' worth per sub-partition stays with two passes: the join kernel
+    // reads the probe rows of such a sub-partition twice, everything else is unchanged.
+    if (b > 18) {
+        const double avg18 = (double)n_build / (double)(1ull << 18);
+        if (avg18 + 4.5 * std::sqrt(avg18) <= 2.0 * (double)JN_CAP) b = 18;
+    }
     return b;
 }
 

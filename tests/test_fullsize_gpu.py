@@ -68,6 +68,20 @@ def test_c5_1b_join_every_pair():
         torch.cuda.empty_cache()
 
 
+def test_join_above_one_lds_table_per_subpartition():
+    """1.1B x 1.1B: 18 hash bits no longer fit one 4096-row LDS table per sub-partition (mean 4196 rows).  The plan stays at two
+    passes -- a third one would more than double the time -- and the join loops over two table chunks where needed; every pair
+    is checked like in the 1B case."""
+    from gpu_olap_engine_amd.engine import Context
+    c = Context(max_gpu_memory=0)
+    try:
+        plan = _check_join(c, 1_100_000_000)
+        assert plan["bits1"] == 9 and plan["bits2"] == 9
+    finally:
+        c.close()
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n_groups", [1024, 1_048_576])
 def test_c4_1b_group_by_sum_and_count(n_groups):
     """BASELINE config 4: 1B rows, int32 group key, SUM(f64) (+ COUNT): LDS pre-aggregation at G = 1024, partition-then-aggregate
