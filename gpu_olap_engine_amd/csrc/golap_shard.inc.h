@@ -123,6 +123,13 @@ static int32_t rccl_exchange(void* user, const golap_p2p_op* ops, uint32_t n_ops
 // also let a transport pipeline them.)
 // default bound of one message: half of the largest size verified intact (1 GiB; see golap_comm_selftest)
 constexpr uint64_t SHARD_DEFAULT_MAX_MSG = 1ull << 29;
+constexpr uint64_t SHARD_RCCL_MAX_MSG = 1ull << 30;   // the built-in transport never sends more in one message, whatever the caller asks for:
+                                                      // beyond it this RCCL build delivers only the first half (golap_comm_selftest)
+static uint64_t shard_max_msg(const golap_comm* cm, uint64_t asked) {
+    uint64_t m = asked ? asked : SHARD_DEFAULT_MAX_MSG;
+    if (cm->builtin && m > SHARD_RCCL_MAX_MSG) m = SHARD_RCCL_MAX_MSG;
+    return m;
+}
 
 static void split_message(int32_t peer, bool is_send, uint64_t ptr, uint64_t bytes, uint64_t max_msg, std::vector<golap_p2p_op>& ops) {
     for (uint64_t o = 0; o < bytes; o += max_msg) {
@@ -277,7 +284,7 @@ static int32_t ensure_host_words(golap_comm* cm, uint64_t bytes) {
 // ---------------------------------------------------------------------------
 static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, bool* failed) {
     const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2, nsub = sp.nsub;
-    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : SHARD_DEFAULT_MAX_MSG;
+    const uint64_t max_msg = shard_max_msg(cm, p->max_msg_bytes);
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
     const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
     const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};
@@ -447,7 +454,7 @@ struct SlabHold {   // slabs that must outlive the workspace (the workspace is r
 
 static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st) {
     const uint32_t P = sp.world, me = (uint32_t)cm->rank, e1 = sp.e1, F1 = sp.F1, per = sp.per;
-    const uint64_t max_msg = p->max_msg_bytes ? p->max_msg_bytes : SHARD_DEFAULT_MAX_MSG;
+    const uint64_t max_msg = shard_max_msg(cm, p->max_msg_bytes);
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
     const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
     const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};

@@ -342,7 +342,7 @@ typedef struct golap_sharded_join_params {
     uint64_t out_pairs_ptr, out_count_ptr, max_pairs;   /* as golap_join_params; pairs carry global row ids */
     int32_t  join_type;                          /* as golap_join_params */
     int32_t  force_exact;                        /* != 0: skip the fast path */
-    uint64_t max_msg_bytes;                      /* 0 = 512 MiB: larger messages are split (both ends compute the same pieces) */
+    uint64_t max_msg_bytes;                      /* 0 = 512 MiB: larger messages are split (both ends compute the same pieces); the built-in RCCL transport caps it at 1 GiB */
 } golap_sharded_join_params;
 typedef struct golap_sharded_join_info {          /* what the last golap_sharded_join on this communicator did */
     uint32_t fast_path;          /* 1: the no-histogram tuple path produced the result */
