@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--rehearse", action="store_true",
                     help="developer: run the N > 1 code path on ONE GPU (all ranks on device 0, gloo + host-staged transport instead of RCCL); "
                          "the numbers mean nothing, the line is marked")
+    ap.add_argument("--no-others", action="store_true", help="C5 default run: skip the other_configs block (C3, C4, C4L, C1)")
     ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (golap_sharded_join) even with 1 rank")
     return ap.parse_args()
 
@@ -285,18 +286,17 @@ def bench_join(args, n_total, label):
         pkeys += (pkeys & 1) << 41
         wk["two_upper_halves"] = leg("two_upper_halves", "as above, odd keys moved by another 2^41: two upper halves -> the 64-bit-row pipeline")
         line["wide_keys"] = wk
-    # C3 is timed at its full size on the CPU too (the reference's own CPU-runnable scale); C5 on a bounded 32M x 32M sample
-    sample = args.cpu_sample if args.cpu_sample >= 0 else (n_total if label == "C3" else 32_000_000)
+    # C3 is timed at its full size on the CPU too (the reference's own CPU-runnable scale); C5 on a bounded 16M x 16M sample
+    sample = args.cpu_sample if args.cpu_sample >= 0 else (n_total if label == "C3" else 16_000_000)
     cb = cpu_join_baseline(min(sample, n_total), rank) if world == 1 else None
     if cb:
         line["cpu_baseline"] = cb
-    if rank == 0:
-        print(json.dumps(line), flush=True)
     if sharded:
         comm.close()       # (the communicator before the context it was made on)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    return line if rank == 0 else None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -347,8 +347,8 @@ def bench_group_by(args, n, groups, label):
         line["cpu_baseline"] = {"value": s / (t1 - t0), "unit": "rows/s", "cores": 1, "kind": "port",
                                 "sample": f"{s} rows of the same generators, single-thread sequential f64 accumulation per group "
                                           f"(executor.rs:313-327 extended by the group key); {t1 - t0:.2f} s"}
-    print(json.dumps(line), flush=True)
     ctx.close()
+    return line
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -396,22 +396,52 @@ def bench_filter_sum(args, n):
         t1 = time.perf_counter()
         line["cpu_baseline"] = {"value": s * reps / (t1 - t0), "unit": "rows/s", "cores": 1, "kind": "port",
                                 "sample": f"{reps} x {s} rows, the reference's 4-pass CPU path (executor.rs:161-178 + :297-355) restated; {t1 - t0:.2f} s"}
-    print(json.dumps(line), flush=True)
     ctx.close()
+    return line
+
+
+def run_config(args, config):
+    if config == "C5":
+        return bench_join(args, args.rows or 1_000_000_000, "C5")
+    if config == "C3":
+        return bench_join(args, args.rows or 100_000_000, "C3")
+    if config == "C4":
+        return bench_group_by(args, args.rows or 1_000_000_000, 1024, "C4")
+    if config == "C4L":
+        return bench_group_by(args, args.rows or 1_000_000_000, 1_048_576, "C4L")
+    return bench_filter_sum(args, args.rows or 1_000_000)
+
+
+def other_configs(args):
+    """The other BASELINE configurations at their full sizes, a few steps each, GPU only (their CPU baselines are printed by
+    `--config X`): every entry is verified like its stand-alone run."""
+    import copy
+    import gc
+
+    import torch
+    out = {}
+    for cfg in ("C3", "C4", "C4L", "C1"):
+        a = copy.copy(args)
+        a.config, a.rows, a.cpu_sample, a.no_wide, a.sharded = cfg, 0, 0, True, False
+        a.steps, a.warmup = (50, 5) if cfg == "C1" else (5, 2)
+        gc.collect()
+        torch.cuda.empty_cache()
+        ln = run_config(a, cfg)
+        r = ln.get("roofline") or {}
+        out[cfg] = {"workload": ln["config"]["workload"], "ms_per_step": ln["ms_per_step"], "value": ln["value"], "unit": ln["unit"], "steps": a.steps,
+                    "roofline": {"kernel": r.get("kernel"), "achieved": r.get("achieved"), "frac": r.get("frac"), "unit": r.get("unit")},
+                    "kernels_ms_per_step": ln["kernels_ms_per_step"], "verify": ln["verify"]}
+    return out
 
 
 def main():
     args = parse_args()
-    if args.config == "C5":
-        bench_join(args, args.rows or 1_000_000_000, "C5")
-    elif args.config == "C3":
-        bench_join(args, args.rows or 100_000_000, "C3")
-    elif args.config == "C4":
-        bench_group_by(args, args.rows or 1_000_000_000, 1024, "C4")
-    elif args.config == "C4L":
-        bench_group_by(args, args.rows or 1_000_000_000, 1_048_576, "C4L")
-    else:
-        bench_filter_sum(args, args.rows or 1_000_000)
+    line = run_config(args, args.config)
+    # the driver runs the default line only: it carries the other BASELINE configurations too (one GPU, < 2 s of GPU time)
+    if line is not None and args.config == "C5" and args.gpus == 1 and not args.sharded and not args.rehearse and not args.rows and not args.no_others:
+        line["other_configs"] = other_configs(args)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

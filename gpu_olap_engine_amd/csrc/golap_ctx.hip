@@ -46,21 +46,46 @@ hipEvent_t Profiler::get_event() {
     return e;
 }
 
+uint32_t* Profiler::take_gate_slot() {
+    const uint32_t blk = gate_used / GATE_BLOCK, idx = gate_used % GATE_BLOCK;
+    if (blk >= gate_blocks.size()) {
+        uint32_t* b = nullptr;
+        if (hipHostMalloc((void**)&b, GATE_BLOCK * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        gate_blocks.push_back(b);
+    }
+    ++gate_used;
+    uint32_t* s = gate_blocks[blk] + idx;
+    *s = 0;
+    return s;
+}
+
 void Profiler::resolve() {
     for (auto& p : pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess)
             stats[p.stat].total_ms += (double)ms;
+        // (the stop event of a call's last kernel precedes the copy of its gate word on the stream: wait for the stream's
+        // tail through the LAST pending event of the list -- events are recorded in order -- before reading any slot)
         pool.push_back(p.start);
         pool.push_back(p.stop);
     }
+    if (!pending.empty()) {
+        bool any = false;
+        for (auto& p : pending) any = any || p.gate_host;
+        if (any) (void)hipDeviceSynchronize();   // the slot copies sit behind the events just waited for; profiling runs only
+        for (auto& p : pending)
+            if (p.gate_host && ((*p.gate_host != 0u) == p.credit_when_set)) stats[p.stat].bytes += p.cond_bytes;
+    }
     pending.clear();
+    gate_used = 0;
 }
 
 void Profiler::destroy() {
     resolve();
     for (auto e : pool) (void)hipEventDestroy(e);
     pool.clear();
+    for (auto b : gate_blocks) (void)hipHostFree(b);
+    gate_blocks.clear();
 }
 
 // ---------------------------------------------------------------------------

@@ -84,6 +84,12 @@ struct TransferQueue {
 struct PendingEvent {
     uint32_t stat;
     hipEvent_t start, stop;
+    // bytes credited only once the call's gate word is known (the optimistic tuple pipeline and the 64-bit pipeline standing by
+    // behind it are both enqueued; exactly one of them does the work): `gate_host` is a pinned copy of the device word, written
+    // by an async copy behind the call's last kernel; credited when (*gate_host != 0) == credit_when_set
+    uint64_t cond_bytes = 0;
+    const uint32_t* gate_host = nullptr;
+    bool credit_when_set = true;
 };
 
 struct Profiler {
@@ -91,6 +97,11 @@ struct Profiler {
     std::vector<golap_kernel_stat> stats;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> pool;
+    std::vector<uint32_t*> gate_blocks;      // pinned blocks of GATE_BLOCK words
+    uint32_t gate_used = 0;                  // words handed out since the last resolve()
+    const uint32_t* cur_gate_host = nullptr; // the running call's slot (nullptr: no conditional credits, e.g. during stream capture)
+    static constexpr uint32_t GATE_BLOCK = 256;
+    uint32_t* take_gate_slot();
     uint32_t stat_index(const char* name);
     hipEvent_t get_event();
     void resolve();
@@ -158,7 +169,9 @@ struct KernelTimer {
     hipStream_t st;
     PendingEvent ev;
     bool on;
-    KernelTimer(golap_ctx* c, const char* name, hipStream_t s, uint64_t bytes = 0) : ctx(c), st(s), on(c->prof.enabled) {
+    // cond_bytes: credited at resolve time if the call's gate word turned out (credit_when_set ? non-zero : zero)
+    KernelTimer(golap_ctx* c, const char* name, hipStream_t s, uint64_t bytes = 0, uint64_t cond_bytes = 0, bool credit_when_set = true)
+        : ctx(c), st(s), on(c->prof.enabled) {
         if (on) {   // timing events have no meaning inside a stream capture (and must not become graph nodes)
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
@@ -168,6 +181,13 @@ struct KernelTimer {
         ev.stat = c->prof.stat_index(name);
         c->prof.stats[ev.stat].launches += 1;
         c->prof.stats[ev.stat].bytes += bytes;
+        if (cond_bytes && c->prof.cur_gate_host) {
+            ev.cond_bytes = cond_bytes;
+            ev.gate_host = c->prof.cur_gate_host;
+            ev.credit_when_set = credit_when_set;
+        } else if (cond_bytes && !credit_when_set) {
+            c->prof.stats[ev.stat].bytes += cond_bytes;   // no read-back in this call: the optimistic pipeline is credited as launched
+        }
         ev.start = c->prof.get_event();
         ev.stop = c->prof.get_event();
         (void)hipEventRecord(ev.start, st);
@@ -195,11 +215,13 @@ struct KnobScope {
 
 // head-room of the provisioned (no-histogram) layouts: standard deviations + pad rows (golap_engine_config::provision_sigmas;
 // the per-pass test knobs GOLAP_RESERVE_SIGMAS / GOLAP_SLOT_SIGMAS override it)
+constexpr uint32_t PROVISION_MAX_SIGMAS = 12;
 inline void provision_of(const char* knob_name, uint32_t& sigmas, uint32_t& pad) {
     sigmas = 6;
     pad = 48;
     if (g_scope_cfg && g_scope_cfg->provision_sigmas) { sigmas = g_scope_cfg->provision_sigmas == GOLAP_PROVISION_NONE ? 0u : g_scope_cfg->provision_sigmas; pad = sigmas ? 48 : 0; }
     if (const char* v = knob(knob_name)) { sigmas = (uint32_t)atoi(v); pad = sigmas ? 48 : 0; }
+    if (sigmas > PROVISION_MAX_SIGMAS) sigmas = PROVISION_MAX_SIGMAS;   // (6 sigmas already mean < 1e-8 per slot; more only buys buffer)
 }
 
 // NULL is the HIP null (legacy default) stream, exactly as in every HIP API -- it is also what

@@ -633,8 +633,12 @@ __device__ __forceinline__ uint32_t isqrt_u32(uint32_t x) {
     return r;
 }
 
+// limit_rows / overflow: rows the output buffer holds; a layout that would not fit raises *overflow instead of being used (the
+// pass behind returns at once through its skip_if, the exact path redoes it) -- the host sizes the buffer from the same
+// (sigmas, pad), so this is a guard, not a path that is expected to run.
 __global__ __launch_bounds__(1024) void k_slots_setup(GroupSrc gs, uint32_t G, uint32_t F, uint32_t sigmas,
-                                                      uint32_t pad, uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap) {
+                                                      uint32_t pad, uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap,
+                                                      unsigned long long limit_rows, uint32_t* __restrict__ overflow) {
     __shared__ uint32_t s_w[16];
     const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
     uint32_t total = 0;
@@ -656,7 +660,10 @@ __global__ __launch_bounds__(1024) void k_slots_setup(GroupSrc gs, uint32_t G, u
     uint32_t base = 0;
     for (uint32_t i = 0; i < wv; ++i) base += s_w[i];
     if (g < G) slot_base[g] = base + inc - total;
-    if (g == G - 1) slot_base[G] = base + inc;
+    if (g == G - 1) {
+        slot_base[G] = base + inc;
+        if (overflow && (unsigned long long)(base + inc) > limit_rows) atomicOr(overflow, 1u);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1593,11 +1600,18 @@ static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
                               reserve_cap_sub(n, F, nsub, nc, chunk_rows) * F * nsub);   // (narrow tuples: 8 B per row as well)
 }
 
-// rows the final buffers of one side must hold: slots are avg + 6 sqrt(avg) + 48, 16-row aligned (k_slots_setup)
+// rows the final buffers of one side must hold when the last pass writes into provisioned slots (k_slots_setup: every slot is
+// avg_g + sigmas * sqrt(avg_g) + pad rows, 16-row aligned, avg_g = ceil(n_g / F)).  Upper bound over any split of n rows into
+// the G groups (sqrt is concave): n + sigmas * (sqrt(FG * n) + FG) + (pad + 24) * FG.  The SAME (sigmas, pad) the device layout
+// uses -- golap_engine_config::provision_sigmas / GOLAP_SLOT_SIGMAS -- so a larger head-room setting grows the buffer with it.
+static uint64_t slot_rows_bound(uint64_t n, double FG) {
+    uint32_t sigmas, pad;
+    provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);
+    return n + (uint64_t)((double)sigmas * (std::sqrt(FG * (double)std::max<uint64_t>(n, 1)) + FG)) + (uint64_t)(((double)pad + 24.0) * FG) + 4096;
+}
 static uint64_t final_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
     if (!use_fast_last_pass(plan, has_segs)) return n;
-    const double FG = (double)plan.passes[1].G * (double)plan.passes[1].cfg.F;
-    return n + (uint64_t)(6.0 * (std::sqrt(FG * (double)std::max<uint64_t>(n, 1)) + FG)) + (uint64_t)(72.0 * FG) + 4096;
+    return slot_rows_bound(n, (double)plan.passes[1].G * (double)plan.passes[1].cfg.F);
 }
 
 struct SegTable {
@@ -1761,7 +1775,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             cfg.S = nc;
             {
                 snprintf(name, sizeof name, "radix_scatter_p1%s", sfx);
-                KernelTimer t(ctx, name, st, gate ? 0 : 20 * n_rows);
+                KernelTimer t(ctx, name, st, gate ? 0 : 20 * n_rows, gate ? 20 * n_rows : 0, true);
 #define GOLAP_RSV(RPT, WIN, WU)                                                                                                            \
     hipLaunchKernelGGL((k_scatter_big<1, RPT, 1024, WIN, 4, false, WU, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F, WIN, 1024), st,      \
                        (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,         \
@@ -1788,13 +1802,14 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             GOLAP_TRY(zero_async(ctx, st, (void*)(flag), 4));
             uint32_t sigmas, pad;
             provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
-            hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F, sigmas, pad, slot_base, slot_cap);
-            FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, flag, nullptr};
+            hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F, sigmas, pad, slot_base, slot_cap,
+                               (unsigned long long)final_rows(plan, n_rows, false), flag);
+            FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, flag, flag};   // (skip_if = its own overflow word: set before the launch only by the guard above)
             PassCfg cfg = pp.cfg;
             cfg.S = 1;
             {
                 snprintf(name, sizeof name, "%s_scatter_p%zu%s", pfx, k + 1, sfx);
-                KernelTimer t(ctx, name, st, gate ? 0 : 24 * n_rows);
+                KernelTimer t(ctx, name, st, gate ? 0 : 24 * n_rows, gate ? 24 * n_rows : 0, true);
                 hipLaunchKernelGGL((k_scatter_wc<2, true>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F), st, (const long long*)cur_keys,
                                    (const uint32_t*)cur_rids, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                                    (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, gate);
@@ -1906,12 +1921,20 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
             const void* p1[] = {(const void*)k_part1_narrow<18, 18432, true, true>, (const void*)k_part1_narrow<18, 18432, true, false>,
                                 (const void*)k_part1_narrow<18, 18432, false, false>, (const void*)k_part1_narrow<16, 16384, true, true>,
                                 (const void*)k_part1_narrow<16, 16384, true, false>, (const void*)k_part1_narrow<16, 16384, false, false>,
-                                (const void*)k_part1_narrow<24, 12288, false, false>, (const void*)k_part1_narrow<18, 18432, true, false, 1>,
-                                (const void*)k_part1_narrow<18, 18432, true, false, 2>, (const void*)k_part1_narrow<18, 18432, true, false, 3>};
+                                (const void*)k_part1_narrow<24, 12288, false, false>,
+#ifdef GOLAP_DIAG   // timing-only diagnostic builds (WRONG results): developer builds only, never in the shipped library
+                                (const void*)k_part1_narrow<18, 18432, true, false, 1>, (const void*)k_part1_narrow<18, 18432, true, false, 2>,
+                                (const void*)k_part1_narrow<18, 18432, true, false, 3>,
+#endif
+            };
             for (const void* f : p1) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part1_narrow_lds_bytes(PT_MAX_F, 18432)));
             const void* p2[] = {(const void*)k_part2_ring<4, 32, true>, (const void*)k_part2_ring<4, 64, true>, (const void*)k_part2_ring<4, 128, true>,
                                 (const void*)k_part2_ring<4, 256, true>, (const void*)k_part2_ring<4, 32, false>, (const void*)k_part2_ring<4, 64, false>,
-                                (const void*)k_part2_ring<4, 128, false>, (const void*)k_part2_ring<4, 256, false>, (const void*)k_part2_ring<4, 32, false, 2>};
+                                (const void*)k_part2_ring<4, 128, false>, (const void*)k_part2_ring<4, 256, false>,
+#ifdef GOLAP_DIAG
+                                (const void*)k_part2_ring<4, 32, false, 2>,
+#endif
+            };
             for (const void* f : p2) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_ring_lds_bytes(P2R_MAX_F, 32)));
         }
         const void* wcn[] = {(const void*)k_scatter_wc<1, false, 16, true>, (const void*)k_scatter_wc<2, false, 16, true>,
@@ -1958,7 +1981,10 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
         GOLAP_TRY(zero_async(ctx, st, (void*)(probe_hit), words * 4));
     }
     const uint64_t row_bytes = narrow ? 8 : 12;
-    KernelTimer t(ctx, run_if ? "join_build_probe_lds_wide" : "join_build_probe_lds", st, run_if ? 0 : row_bytes * (n_build + n_probe));
+    // (gated launches -- the 64-bit pipeline standing by, or the tuple join in front of it -- are credited once the gate is known)
+    const uint64_t jbytes = row_bytes * (n_build + n_probe);
+    KernelTimer t(ctx, run_if ? "join_build_probe_lds_wide" : "join_build_probe_lds", st, run_if || skip_if ? 0 : jbytes, run_if || skip_if ? jbytes : 0,
+                  run_if != nullptr);
     const uint32_t n_sub = (uint32_t)plan.n_sub;
     uint32_t stride_grid = 4096u;
     if (const char* e = knob("GOLAP_JOIN_STRIDE_GRID")) stride_grid = (uint32_t)std::max(1, atoi(e));   // debug hook
@@ -2025,10 +2051,12 @@ static void launch_part1_narrow(hipStream_t st, uint64_t in_keys, uint32_t rid_b
 #define GOLAP_P1N(RPT, WIN, VEC, ASM, ...)                                                                                                            \
     hipLaunchKernelGGL((k_part1_narrow<RPT, WIN, VEC, ASM, ##__VA_ARGS__>), dim3(nc), dim3(P1N_THREADS), part1_narrow_lds_bytes(F1, WIN), st, (const long long*)in_keys, \
                        rid_base, c_off, c_len, (uint2*)tmp_rows, cfg, rsa)
-    if (v1 == 901) GOLAP_P1N(18, 18432, true, false, 1);          // 9xx: timing-only diagnostic builds (scripts/ab_p12.py)
-    else if (v1 == 902) GOLAP_P1N(18, 18432, true, false, 2);
-    else if (v1 == 903) GOLAP_P1N(18, 18432, true, false, 3);
-    else if (v1 == 118 && al16) GOLAP_P1N(18, 18432, true, true);
+#ifdef GOLAP_DIAG
+    if (v1 == 901) { GOLAP_P1N(18, 18432, true, false, 1); return; }   // 9xx: timing-only diagnostic builds (scripts/ab_p12.py; make DIAG=1)
+    if (v1 == 902) { GOLAP_P1N(18, 18432, true, false, 2); return; }
+    if (v1 == 903) { GOLAP_P1N(18, 18432, true, false, 3); return; }
+#endif
+    if (v1 == 118 && al16) GOLAP_P1N(18, 18432, true, true);
     else if (v1 == 116 && al16) GOLAP_P1N(16, 16384, true, true);
     else if (v1 == 24 || v1 == 124) GOLAP_P1N(24, 12288, false, false);
     else if ((v1 == 18 || v1 == 118) && al16) GOLAP_P1N(18, 18432, true, false);
@@ -2055,8 +2083,10 @@ static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint
         else if (R == 128) GOLAP_P2R(128, ASM, ##__VA_ARGS__);                                                                            \
         else GOLAP_P2R(256, ASM, ##__VA_ARGS__);                                                                                          \
     } while (0)
-    if (v2 == 902) GOLAP_P2R(32, false, 2);       // timing-only diagnostic (scripts/ab_p12.py)
-    else if (v2 == 4) GOLAP_P2R_BY_R(false);      // plain loads and stores, hipcc's own waits (A/B reference)
+#ifdef GOLAP_DIAG
+    if (v2 == 902) { GOLAP_P2R(32, false, 2); return; }   // timing-only diagnostic (scripts/ab_p12.py; make DIAG=1)
+#endif
+    if (v2 == 4) GOLAP_P2R_BY_R(false);      // plain loads and stores, hipcc's own waits (A/B reference)
     else GOLAP_P2R_BY_R(true);
 #undef GOLAP_P2R_BY_R
 #undef GOLAP_P2R
@@ -2092,7 +2122,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
         cfg.S = nc;
         cfg.key_hi = key_hi;
         cfg.pre_hashed = hashed_tuples ? 1u : 0u;
-        KernelTimer t(ctx, "radix_scatter_p1", st, 16 * n_rows);
+        KernelTimer t(ctx, "radix_scatter_p1", st, 0, 16 * n_rows, false);   // credited unless the attempt was abandoned
         const ReserveArgs rsa{cursor, cap1, wide, wide, nullptr, nsub};
         launch_part1_narrow(st, in_keys, rid_base, nc, c_off, c_len, tmp_rows, cfg, rsa);
     }
@@ -2100,14 +2130,15 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     GroupSrc groups{nullptr, 0, cursor, cap1, zero_word, nsub};
     uint32_t sigmas, pad;
     provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
-    hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F2, sigmas, pad, slot_base, slot_cap);
+    hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F2, sigmas, pad, slot_base, slot_cap,
+                       (unsigned long long)final_rows(plan, n_rows, false), wide);
     {
         FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, wide, wide};
         PassCfg cfg = p2.cfg;
         cfg.S = 1;
         cfg.key_hi = key_hi;
         cfg.pre_hashed = hashed_tuples ? 1u : 0u;
-        KernelTimer t(ctx, "radix_scatter_p2", st, 16 * n_rows);
+        KernelTimer t(ctx, "radix_scatter_p2", st, 0, 16 * n_rows, false);
         if (p2r_variant() != 0 && F2 <= (uint32_t)P2R_MAX_F)
             launch_part2_ring(st, G, tmp_rows, final_rows_ptr, cfg, fx, SegSrc{nullptr, nullptr, 0});
         else
@@ -2147,6 +2178,7 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     if ((uint64_t)p->build_rid_base + p->n_build > 0xFFFFFFFFull || (uint64_t)p->probe_rid_base + p->n_probe > 0xFFFFFFFFull)
         return fail(ctx, GOLAP_ERR_UNSUPPORTED, "rid_base + rows exceeds the u32 row-id range (0xFFFFFFFF is the NULL row id)");
     GOLAP_TRY(ensure_scatter_lds(ctx));
+    ctx->prof.cur_gate_host = nullptr;
     JoinPlan plan;
     make_plan(p->n_build, 0, true, plan);
     // positions inside the slot-padded layouts are u32 as well: near 2^32 rows fall back to the dense (histogram) layouts
@@ -2178,6 +2210,11 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
         uint32_t* words = (uint32_t*)ws_take(ctx, 16);   // [0] wide flag, [1] constant 0, [2] the upper key half the attempt stands on
         if (!words) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
         GOLAP_TRY(zero_async(ctx, st, (void*)words, 16));
+        if (ctx->prof.enabled) {   // profiling: which of the two pipelines did the work is read back (asynchronously) for the byte credits
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+            ctx->prof.cur_gate_host = cs == hipStreamCaptureStatusNone ? ctx->prof.take_gate_slot() : nullptr;
+        }
         // Frame of reference: the tuples carry the lower 32 key bits, valid while every key of BOTH sides shares its upper 32 bits
         // with the first build key (0 for the usual small non-negative ids, 0xFFFFFFFF for small negative ones, anything for keys
         // offset into a common 4 Gi window).  Only the new tuple kernels know about it (knobs that select the old ones keep 0).
@@ -2204,6 +2241,10 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe_key_ptr, 0, p->probe_rid_base, p->n_probe, nullptr, pb, rp, gate));
     GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type, false, gate,
                               nullptr, probe_hit));
+    if (gate && ctx->prof.cur_gate_host) {
+        (void)hipMemcpyAsync((void*)ctx->prof.cur_gate_host, gate, 4, hipMemcpyDeviceToHost, st);
+        ctx->prof.cur_gate_host = nullptr;
+    }
     ws_end(ctx, st);
     return GOLAP_OK;
 }

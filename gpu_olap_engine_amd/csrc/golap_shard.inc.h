@@ -229,7 +229,7 @@ struct ShardSrcTable {
 __global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restrict__ hdr, uint32_t hdr_stride, uint32_t F1, uint32_t world, uint32_t me,
                                                         uint32_t per, uint32_t nsub, ShardSrcTable src, uint32_t F2, uint32_t sigmas, uint32_t pad,
                                                         uint32_t* __restrict__ seg_off, uint32_t* __restrict__ seg_len, uint32_t* __restrict__ slot_base,
-                                                        uint32_t* __restrict__ slot_cap, uint32_t* __restrict__ status) {
+                                                        uint32_t* __restrict__ slot_cap, uint32_t* __restrict__ status, unsigned long long limit_rows) {
     __shared__ uint32_t s_w[16];
     const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
     uint32_t total = 0;
@@ -255,7 +255,10 @@ __global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restr
     uint32_t base = 0;
     for (uint32_t i = 0; i < wv; ++i) base += s_w[i];
     if (g < per) slot_base[g] = base + inc - total;
-    if (g == per - 1) slot_base[per] = base + inc;
+    if (g == per - 1) {
+        slot_base[per] = base + inc;
+        if ((unsigned long long)(base + inc) > limit_rows) atomicOr(status, 1u);   // guard: the slot layout must fit the final buffer
+    }
 }
 
 static int32_t comm_all_gather(golap_comm* cm, uint64_t send, uint64_t recv, uint64_t bytes, hipStream_t s) {
@@ -304,7 +307,9 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         }
         recv_rows[side] = ro - send_rows[side];
         const uint64_t avg = ceil_div(n_g_max, F2);
-        final_rows_[side] = (uint64_t)per * F2 * round_up(avg + 6ull * isqrt_host(avg) + 48 + 15, 16);
+        uint32_t sg, pd;
+        provision_of("GOLAP_SLOT_SIGMAS", sg, pd);   // the same head-room k_shard_segments lays the slots out with
+        final_rows_[side] = (uint64_t)per * F2 * round_up(avg + (uint64_t)sg * isqrt_host(avg) + pd + 15, 16);
         if (send_rows[side] + recv_rows[side] >= 0xFFFFFFF0ull || final_rows_[side] >= 0xFFFFFFF0ull)
             return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: positions exceed u32");
     }
@@ -395,7 +400,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         uint32_t sigmas, pad;
         provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
         hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)hdr_all[side], hdr_stride, F1, P, me, per, nsub, tab, F2, sigmas, pad,
-                           seg_off, seg_len, slot_base, slot_cap, words);
+                           seg_off, seg_len, slot_base, slot_cap, words, (unsigned long long)final_rows_[side]);
         FixedArgs fx{GroupSrc{}, slot_base, slot_cap, sub_start, sub_len, words, nullptr};
         PassCfg cfg = sp.local.passes[0].cfg;
         cfg.S = 1;

@@ -734,3 +734,66 @@ def test_key_columns_that_are_only_8_byte_aligned(ctx):
         assert m == want
         v = ctx.verify_pairs(pairs, m, b, p).cpu()
         assert int(v[0]) == m
+
+
+def _pairs_by_probe(ctx, bt, pt, n, **knobs):
+    """build row id of every probe row (unique build keys: exactly one partner each), -1 where missing, -2 where seen twice"""
+    out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    with ctx.knobs(**knobs):
+        pairs, cnt = ctx.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
+        torch.cuda.synchronize()
+    m = int(cnt.item())
+    got = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+    seen = torch.zeros(n, dtype=torch.int32, device="cuda")
+    pr = pairs[:min(m, n), 1].to(torch.int64) & 0xFFFFFFFF
+    seen.index_add_(0, pr, torch.ones_like(pr, dtype=torch.int32))
+    got[pr] = pairs[:min(m, n), 0].to(torch.int64) & 0xFFFFFFFF
+    got[seen > 1] = -2
+    return m, got
+
+
+@pytest.mark.parametrize("bits,ring", [("9,9", 32), ("9,8", 64), ("9,7", 128), ("9,6", 256)])
+def test_hidden_forms_match_plain_forms(ctx, bits, ring):
+    """The partition kernels that hide their loads and stores from hipcc (hand-counted vmcnt waits, fixed registers: the ASM forms of
+    k_part1_narrow and k_part2_ring) against their plain forms, row by row, at every ring length (the second fan-out picks it:
+    512 -> 32 ... 64 -> 256 rows) and with a partial last tile in every chunk and group (n is not a multiple of any tile).  With
+    unique build keys the partner of every probe row is known in closed form, so a row that either form loses, duplicates, garbles
+    or files under the wrong sub-partition shows up as a probe row without exactly its partner."""
+    n = 24_000_011
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    inv = torch.empty(n, dtype=torch.int64, device="cuda")
+    inv[bt] = torch.arange(n, dtype=torch.int64, device="cuda")
+    exp = inv[pt]
+    del inv
+    base = {"GOLAP_PASS_BITS": bits, "GOLAP_RESERVE": "1"}
+    forms = {"hidden p1 + hidden ring": {"GOLAP_P1N": "118", "GOLAP_P2R": "104"}, "plain p1 + hidden ring": {"GOLAP_P1N": "18", "GOLAP_P2R": "104"},
+             "hidden p1 + plain ring": {"GOLAP_P1N": "118", "GOLAP_P2R": "4"}, "plain p1 + plain ring": {"GOLAP_P1N": "18", "GOLAP_P2R": "4"}}
+    for name, kn in forms.items():
+        ctx.stats_reset()
+        m, got = _pairs_by_probe(ctx, bt, pt, n, **base, **kn)
+        st = ctx.stats()
+        assert st["join_build_probe_lds"]["total_ms"] > st["join_build_probe_lds_wide"]["total_ms"], f"{name}: the tuple pipeline did not run"
+        bad = torch.nonzero(got != exp).flatten()
+        assert m == n and bad.numel() == 0, (f"{name} (ring {ring}): {m} pairs for {n} probe rows; {bad.numel()} probe rows without exactly their partner, "
+                                             f"first {bad[:8].tolist()} -> {got[bad[:8]].tolist()}")
+
+
+@pytest.mark.parametrize("sigmas", [8, 12, 40])
+def test_large_provision_sigmas_size_the_buffers_too(sigmas):
+    """golap_engine_config.provision_sigmas widens the slots of the no-histogram layouts; the buffers behind them must grow with it
+    (round 2 sized them for 6 sigmas whatever the setting: with >= 7 the last pass wrote past the final buffers).  Values above
+    the library's cap (12) are clamped.  Both pipelines: the tuple one and, with two upper key halves, the 64-bit one."""
+    from gpu_olap_engine_amd.engine import Context
+    n = 40_000_000
+    with Context(max_gpu_memory=0, provision_sigmas=sigmas) as c:
+        bt = c.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+        pt = c.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+        for wide in (False, True):
+            if wide:
+                bt += (bt & 1) << 40
+                pt += (pt & 1) << 40
+            out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+            pairs, cnt = c.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
+            v = c.verify_pairs(pairs, n, bt, pt).cpu().numpy().view(np.uint64)
+            assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2
