@@ -258,6 +258,11 @@ def bench_join(args, n_total, label):
         "device": device_block(info),
     }
     if join_info:
+        # where the time went on every rank (device timestamps of the fast path's stages, ms since that rank's first kernel)
+        if world > 1:
+            infos = [None] * world
+            dist.all_gather_object(infos, {"stage_ms": join_info["stage_ms"], "total_ms": join_info["total_ms"], "bytes_sent": join_info["bytes_sent"]})
+            join_info["per_rank"] = infos
         line["sharded_join"] = join_info
 
     # ---- further legs: the same join with keys outside [0, 2^32) -------------------------------

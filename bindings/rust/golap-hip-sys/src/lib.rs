@@ -1,12 +1,13 @@
-//! Raw FFI of `include/golap.h` (ABI version 2), one declaration per C declaration, same names and field order.
+//! Raw FFI of `include/golap.h` (ABI version 3), one declaration per C declaration, same names and field order.
 //!
-//! Not compiled in the authoring environment (no Rust toolchain); `tests/test_rust_binding.py` keeps it in step with the
-//! header.  Reference interfaces each item replaces are cited as in the header (paths relative to the reference root).
+//! NOT COMPILED in the authoring environment (no Rust toolchain): layout-checked only.  `tests/test_rust_binding.py` parses this
+//! file and the header and compares EVERY `#[repr(C)]` struct field by field and every bound function's arity; the `unsafe`
+//! wrapper bodies and `build.rs` are unverified until a maintainer builds the crate.  Reference interfaces each item replaces are cited as in the header (paths relative to the reference root).
 #![allow(non_camel_case_types)]
 
 use std::os::raw::{c_char, c_void};
 
-pub const GOLAP_ABI_VERSION: u32 = 2;
+pub const GOLAP_ABI_VERSION: u32 = 3;
 pub const GOLAP_OK: i32 = 0;
 pub const GOLAP_ERR_INVALID_ARG: i32 = 1;
 pub const GOLAP_ERR_NO_DEVICE: i32 = 2;
@@ -14,6 +15,9 @@ pub const GOLAP_ERR_HIP: i32 = 3;
 pub const GOLAP_ERR_OOM: i32 = 4;
 pub const GOLAP_ERR_UNSUPPORTED: i32 = 5;
 pub const GOLAP_ERR_CAPACITY: i32 = 6;
+/// collective call: ANOTHER rank failed before the exchange; every rank has left the call together
+pub const GOLAP_ERR_PEER: i32 = 7;
+pub const GOLAP_SHARD_STAGES: usize = 8;
 
 #[repr(C)]
 pub struct golap_ctx {
@@ -149,6 +153,100 @@ pub struct golap_sharded_join_params {
     pub max_msg_bytes: u64,
 }
 
+/// what the last `golap_sharded_join` on a communicator did; `stage_ms[stage][begin, end]` in ms since the call's first kernel
+/// (stages: partition build/probe, exchange build/probe, ring build/probe, join, status)
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct golap_sharded_join_info {
+    pub fast_path: u32,
+    pub fast_path_abandoned: u32,
+    pub extra_bits: u32,
+    pub n_groups: u32,
+    pub local_bits: u32,
+    pub host_syncs: u32,
+    pub rows_received: [u64; 2],
+    pub bytes_sent: [u64; 2],
+    pub chunks: u32,
+    pub sub_ranges: u32,
+    pub stage_ms: [[f32; 2]; 8],
+    pub total_ms: f32,
+    pub reserved0: u32,
+}
+
+/// host-only description of the fast path's messages (every rank computes the same numbers)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct golap_sharded_plan {
+    pub eligible: u32,
+    pub extra_bits: u32,
+    pub n_buckets: u32,
+    pub buckets_per_rank: u32,
+    pub local_bits: u32,
+    pub sub_ranges: u32,
+    pub chunks: u32,
+    pub cap_rows: [[u64; 64]; 2],
+    pub cap_rows_last: [[u64; 64]; 2],
+    pub msg_bytes: [[u64; 64]; 2],
+    pub msg_pieces: [[u32; 64]; 2],
+}
+
+/// stand-alone radix partition (join_kernels.cuh:45-76), owner-major for the partition exchange
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct golap_partition_params {
+    pub key_ptr: u64,
+    pub row_id_ptr: u64,
+    pub n_rows: u64,
+    pub rid_base: u32,
+    pub n_owners: u32,
+    pub extra_bits: u32,
+    pub out_key_ptr: u64,
+    pub out_row_id_ptr: u64,
+    pub out_offsets_ptr: u64,
+    pub narrow: u32,
+    pub reserved0: u32,
+    pub wide_flag_ptr: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct golap_partitioned_side {
+    pub key_ptr: u64,
+    pub row_id_ptr: u64,
+    pub n_rows: u64,
+    pub seg_off: *const u64,
+    pub seg_len: *const u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct golap_join_partitioned_plan {
+    pub n_groups: u32,
+    pub n_sources: u32,
+    pub pre_bits: u32,
+    pub total_build_rows_hint: u64,
+    pub build_rows: u64,
+    pub probe_rows: u64,
+    pub narrow: u32,
+    pub reserved0: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct golap_join_plan {
+    pub bits1: u32,
+    pub bits2: u32,
+    pub tile_rows: u32,
+    pub chunks1: u32,
+    pub slots2: u32,
+    pub table_capacity: u32,
+    pub n_subpartitions: u64,
+    pub no_histogram_last_pass: u32,
+    pub no_histogram_first_pass: u32,
+    pub optimistic_narrow_keys: u32,
+    pub reserved0: u32,
+}
+
 extern "C" {
     // ---- context (EngineConfig, lib.rs:20-43) ----
     pub fn golap_abi_version() -> u32;
@@ -191,6 +289,16 @@ extern "C" {
     pub fn golap_comm_create_custom(ctx: *mut golap_ctx, transport: *const golap_transport, world: i32, rank: i32, out: *mut *mut golap_comm) -> i32;
     pub fn golap_comm_destroy(comm: *mut golap_comm);
     pub fn golap_sharded_join(ctx: *mut golap_ctx, comm: *mut golap_comm, params: *const golap_sharded_join_params, stream: *mut c_void) -> i32;
+    pub fn golap_sharded_join_info_get(comm: *mut golap_comm, out: *mut golap_sharded_join_info) -> i32;
+    pub fn golap_sharded_plan_get(world: u32, n_build_total: u64, n_probe_total: u64, build_rows_per_rank: *const u64, probe_rows_per_rank: *const u64,
+                                  max_msg_bytes: u64, out: *mut golap_sharded_plan) -> i32;
+    pub fn golap_shard_range(n_total: u64, rank: u32, world: u32, lo: *mut u64, hi: *mut u64);
+    pub fn golap_radix_partition(ctx: *mut golap_ctx, params: *const golap_partition_params, stream: *mut c_void) -> i32;
+    pub fn golap_join_partitioned_begin(ctx: *mut golap_ctx, plan: *const golap_join_partitioned_plan, stream: *mut c_void) -> i32;
+    pub fn golap_join_partitioned_side(ctx: *mut golap_ctx, which: i32, side: *const golap_partitioned_side, stream: *mut c_void) -> i32;
+    pub fn golap_join_partitioned_finish(ctx: *mut golap_ctx, out_pairs_ptr: u64, out_count_ptr: u64, max_pairs: u64, stream: *mut c_void) -> i32;
+    pub fn golap_join_partitioned_abort(ctx: *mut golap_ctx) -> i32;
+    pub fn golap_join_plan_get(ctx: *mut golap_ctx, n_build: u64, n_owners: u32, out: *mut golap_join_plan) -> i32;
 }
 
 /// Maps a status code to the `anyhow::Result` the reference uses everywhere (nothing unwinds across the boundary).

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgolap_hip.so")
 
 GOLAP_OK = 0
-ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY = 1, 2, 3, 4, 5, 6
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_PEER = 1, 2, 3, 4, 5, 6, 7
 
 JOIN_RADIX_HASH, JOIN_SORT_MERGE, JOIN_BROADCAST_HASH = 0, 1, 2
 JT_INNER, JT_LEFT, JT_RIGHT, JT_FULL = 0, 1, 2, 3
@@ -121,13 +121,17 @@ class ShardedJoinParams(C.Structure):
 
 class ShardedJoinInfo(C.Structure):
     _fields_ = [("fast_path", C.c_uint32), ("fast_path_abandoned", C.c_uint32), ("extra_bits", C.c_uint32), ("n_groups", C.c_uint32),
-                ("local_bits", C.c_uint32), ("host_syncs", C.c_uint32), ("rows_received", C.c_uint64 * 2), ("bytes_sent", C.c_uint64 * 2)]
+                ("local_bits", C.c_uint32), ("host_syncs", C.c_uint32), ("rows_received", C.c_uint64 * 2), ("bytes_sent", C.c_uint64 * 2),
+                ("chunks", C.c_uint32), ("sub_ranges", C.c_uint32), ("stage_ms", (C.c_float * 2) * 8), ("total_ms", C.c_float), ("reserved0", C.c_uint32)]
+
+
+SHARD_STAGES = ["partition_build", "partition_probe", "exchange_build", "exchange_probe", "ring_build", "ring_probe", "join", "status"]
 
 
 class ShardedPlan(C.Structure):
     _fields_ = [("eligible", C.c_uint32), ("extra_bits", C.c_uint32), ("n_buckets", C.c_uint32), ("buckets_per_rank", C.c_uint32),
-                ("local_bits", C.c_uint32), ("sub_ranges", C.c_uint32), ("reserved0", C.c_uint32), ("cap_rows", (C.c_uint64 * 64) * 2), ("msg_bytes", (C.c_uint64 * 64) * 2),
-                ("msg_pieces", (C.c_uint32 * 64) * 2)]
+                ("local_bits", C.c_uint32), ("sub_ranges", C.c_uint32), ("chunks", C.c_uint32), ("cap_rows", (C.c_uint64 * 64) * 2),
+                ("cap_rows_last", (C.c_uint64 * 64) * 2), ("msg_bytes", (C.c_uint64 * 64) * 2), ("msg_pieces", (C.c_uint32 * 64) * 2)]
 
 
 class AggregateSpec(C.Structure):

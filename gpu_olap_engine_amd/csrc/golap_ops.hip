@@ -378,12 +378,13 @@ constexpr int AG_WAVES = AG_THREADS / 64;
 constexpr int AG_RPT = 8;
 constexpr int AG_TILE = AG_THREADS * AG_RPT;   // 4096 rows staged in LDS
 constexpr int AG_GB = 2048;                    // slots per bucket (one 56 KiB LDS table)
+constexpr int AG_GB_SUM = 8192;                // slots per bucket when only sums and counts are kept (12 bytes per slot: one 96 KiB table)
 constexpr int AG_MAX_B = 1024;                 // buckets (fan-out of the single partition pass)
 constexpr uint32_t AG_NULL_MARK = 0x80000000u;   // partition path: top bit of the slot word = the row's VALUE is NULL (it travels, but is not aggregated)
 
 template <typename KeyT>
 __global__ __launch_bounds__(AG_THREADS) void k_agg_hist(const KeyT* __restrict__ keys, unsigned long long n, uint32_t n_groups, uint32_t chunk_rows,
-                                                         uint32_t S, uint32_t B, uint32_t* __restrict__ hist /*[B][S]*/) {
+                                                         uint32_t S, uint32_t B, uint32_t* __restrict__ hist /*[B][S]*/, uint32_t gb_shift) {
     __shared__ uint32_t s_cnt[AG_MAX_B];
     const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
     if (lo >= n) return;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_hist(const KeyT* __restrict_
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const unsigned long long i = base + (unsigned long long)r * AG_THREADS + threadIdx.x;
-            if (i < hi) atomicAdd(&s_cnt[slot_of(k[r], n_groups) / AG_GB], 1u);
+            if (i < hi) atomicAdd(&s_cnt[slot_of(k[r], n_groups) >> gb_shift], 1u);
         }
     }
     __syncthreads();
@@ -596,37 +597,200 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
     }
 }
 
-// bucket b = slots [b*AG_GB, (b+1)*AG_GB); work-group (b, w) folds its share of the bucket's rows into an LDS table
-template <bool NEED_MM>
-__global__ __launch_bounds__(AG_THREADS) void k_agg_bucket(const uint32_t* __restrict__ slot, const double* __restrict__ val,
-                                                           const uint32_t* __restrict__ scanned, uint32_t S, uint32_t W,
-                                                           double* __restrict__ slab /*[B*W][4][AG_GB]*/) {
+// ---------------------------------------------------------------------------
+// Partition scatter with line-aligned write combining (fan-outs <= 128: SUM / COUNT / AVG over up to 2^20 groups, whose 12-byte
+// LDS table entries allow 8192 slots per bucket).  Round 2's profile of k_agg_scatter_big: 3.1 TB/s, 77 % of the wave cycles
+// parked at waits, 1.14 x write amplification -- every (tile, bucket) run ends inside a 128-byte line that the same work-group
+// completes one tile later, after the L2 has evicted it.  The histogram gives every chunk (= work-group) a PRIVATE contiguous range
+// in every bucket, so here a bucket's unfinished line stays in LDS: per tile a bucket emits rows only up to the last 16-row boundary
+// of its cursor (a whole 128-byte value line, a 64-byte half line of slot words) and carries the < 16 remaining rows into the next
+// tile, where they are staged in front of the bucket's new rows -- each line leaves the chip once, whole.  Only the first and the
+// last line of a (chunk, bucket) range can be partial.  Same register-resident 16384-row tile as k_agg_scatter_big; the window
+// (9216 rows) holds the carried rows too, so a tile still takes two rounds.
+// ---------------------------------------------------------------------------
+constexpr int AGW_THREADS = 1024;
+constexpr int AGW_RPT = 16;
+constexpr int AGW_TILE = AGW_THREADS * AGW_RPT;
+constexpr int AGW_MAX_B = 128;
+constexpr int AGW_CL = 16;       // rows per carried line
+constexpr int AGW_WIN = 9216;    // 2 * WIN >= TILE + MAX_B * (CL - 1)
+constexpr size_t AGW_LDS = (size_t)AGW_WIN * 12 + (size_t)AGW_MAX_B * AGW_CL * 12 + (size_t)AGW_MAX_B * 5 * 4 + 20 * 4 + 16;
+static_assert(2 * AGW_WIN >= AGW_TILE + AGW_MAX_B * (AGW_CL - 1), "a tile and its carried rows pass the window in two rounds");
+static_assert(AGW_WIN % AGW_THREADS == 0, "window rows per thread");
+
+template <typename KeyT, bool VAL_F64>
+__global__ __launch_bounds__(AGW_THREADS) void k_agg_scatter_wc(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
+                                                                uint32_t n_groups, uint32_t gb_shift, uint32_t chunk_rows, uint32_t S, uint32_t B,
+                                                                const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
+                                                                double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    double* s_val = reinterpret_cast<double*>(s_raw);                     // [WIN]      window: values
+    double* c_val = s_val + AGW_WIN;                                      // [B][CL]    carried rows: values
+    uint32_t* s_slot = reinterpret_cast<uint32_t*>(c_val + AGW_MAX_B * AGW_CL);   // [WIN] window: slot words
+    uint32_t* c_slot = s_slot + AGW_WIN;                                  // [B][CL]
+    uint32_t* s_cnt = c_slot + AGW_MAX_B * AGW_CL;                        // [B] new rows of the bucket in this tile
+    uint32_t* s_start = s_cnt + AGW_MAX_B;                                // [B] tile-local position of the bucket's first (carried) row
+    uint32_t* s_gpos = s_start + AGW_MAX_B;                               // [B] output row of the bucket's first staged row
+    uint32_t* s_carry = s_gpos + AGW_MAX_B;                               // [B] rows carried into this tile
+    uint32_t* s_emit = s_carry + AGW_MAX_B;                               // [B] rows that leave in this tile (the rest is carried on)
+    uint32_t* s_w = s_emit + AGW_MAX_B;                                   // [16] wave totals, [16] rows staged in this tile
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
+    if (lo >= n) return;
+    const unsigned long long hi = lo + chunk_rows < n ? lo + chunk_rows : n;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long* vi = (const long long*)val;
+    const double* vf = (const double*)val;
+    if (tid < B) { s_gpos[tid] = scanned[(size_t)tid * S + blockIdx.x]; s_carry[tid] = 0; s_cnt[tid] = 0; }
+    KeyT kraw[AGW_RPT];
+    double x[AGW_RPT];
+    uint32_t nullbits = 0;   // bit r: the value of row r is NULL
+    auto load_tile = [&](unsigned long long t0) {
+        const uint32_t tn = hi - t0 < (unsigned long long)AGW_TILE ? (uint32_t)(hi - t0) : (uint32_t)AGW_TILE;
+        nullbits = 0;
+#pragma unroll
+        for (int r = 0; r < AGW_RPT; ++r) {   // unconditional loads on clamped indices: all in flight together
+            const uint32_t i = r * AGW_THREADS + tid;
+            const unsigned long long gi = t0 + (i < tn ? i : tn - 1);
+            kraw[r] = keys[gi];
+            x[r] = VAL_F64 ? vf[gi] : (double)vi[gi];   // executor.rs:521 `as f64`
+            if (vv) nullbits |= (vv[gi] ? 0u : 1u) << r;
+        }
+    };
+    load_tile(lo);
+    for (unsigned long long t0 = lo; t0 < hi; t0 += AGW_TILE) {
+        const uint32_t tn = hi - t0 < (unsigned long long)AGW_TILE ? (uint32_t)(hi - t0) : (uint32_t)AGW_TILE;
+        const bool last_tile = t0 + AGW_TILE >= hi;
+        uint32_t slot[AGW_RPT], br[AGW_RPT];
+#pragma unroll
+        for (int r = 0; r < AGW_RPT; ++r) slot[r] = slot_of(kraw[r], n_groups) | (((nullbits >> r) & 1u) ? AG_NULL_MARK : 0u);
+        lds_barrier();   // s_cnt zeroed, cursors and carry counts of the previous tile updated
+#pragma unroll
+        for (int r = 0; r < AGW_RPT; ++r) {
+            const uint32_t i = r * AGW_THREADS + tid;
+            br[r] = 0xFFFFFFFFu;
+            if (i < tn) {
+                const uint32_t b = (slot[r] & ~AG_NULL_MARK) >> gb_shift;
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 128, rank < 16384
+            }
+        }
+        lds_barrier();
+        {
+            const uint32_t tot = tid < B ? s_cnt[tid] + s_carry[tid] : 0u;   // rows of the bucket staged in this tile: carried + new
+            const uint32_t inc = wave_inclusive_scan(tot);
+            if (lane == 63) s_w[wv] = inc;
+            lds_barrier();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < AGW_THREADS / 64; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            if (tid < B) {
+                s_start[tid] = base + inc - tot;
+                const uint32_t g = s_gpos[tid];
+                uint32_t e = tot;   // the chunk's last tile: everything leaves
+                if (!last_tile) {
+                    const uint32_t end = (g + tot) & ~(uint32_t)(AGW_CL - 1);
+                    e = end > g ? end - g : 0u;
+                }
+                s_emit[tid] = e;
+                if (tid == B - 1) s_w[16] = base + inc;
+            }
+        }
+        lds_barrier();
+        const uint32_t total = s_w[16];
+#pragma unroll
+        for (int r = 0; r < AGW_RPT; ++r)
+            if (br[r] != 0xFFFFFFFFu) { const uint32_t b = br[r] >> 16; br[r] = s_start[b] + s_carry[b] + (br[r] & 0xFFFFu); }
+        // windows: stage, (last window: request the next tile -- slot / br / x are dead from there on, which hipcc only sees when the
+        // last window is not an iteration of the loop: as one loop the kernel spilled 111 registers), write out
+        auto window = [&](uint32_t w0, auto last) {
+#pragma unroll
+            for (int r = 0; r < AGW_RPT; ++r) {
+                const uint32_t pos = br[r] - w0;   // invalid rows and rows of the other window fall outside
+                if (pos < (uint32_t)AGW_WIN) {
+                    s_slot[pos] = slot[r];
+                    s_val[pos] = x[r];
+                }
+            }
+            // the carried rows go in front of their bucket's new rows (a bucket's new carry is written by the write-out below, in
+            // the round that holds its LAST rows -- never before the round that stages its first ones)
+            for (uint32_t idx = tid; idx < B * (uint32_t)AGW_CL; idx += AGW_THREADS) {
+                const uint32_t b = idx / AGW_CL, j = idx % AGW_CL;
+                if (j < s_carry[b]) {
+                    const uint32_t pos = s_start[b] + j - w0;
+                    if (pos < (uint32_t)AGW_WIN) { s_slot[pos] = c_slot[idx]; s_val[pos] = c_val[idx]; }
+                }
+            }
+            lds_barrier();
+            if constexpr (decltype(last)::value) {
+                if (!last_tile) load_tile(t0 + AGW_TILE);   // work-group-uniform: the registers are free, the reads run under the write-out
+            }
+            const uint32_t wn = total - w0 < (uint32_t)AGW_WIN ? total - w0 : (uint32_t)AGW_WIN;
+#pragma unroll 3
+            for (int j = 0; j < AGW_WIN / AGW_THREADS; ++j) {
+                const uint32_t i = j * AGW_THREADS + tid;
+                if (i < wn) {
+                    const uint32_t sl = s_slot[i], b = (sl & ~AG_NULL_MARK) >> gb_shift;
+                    const double v = s_val[i];
+                    const uint32_t k = w0 + i - s_start[b], e = s_emit[b];
+                    if (k < e) {
+                        const uint32_t gp = s_gpos[b] + k;
+                        out_slot[gp] = sl;
+                        out_val[gp] = v;
+                    } else {
+                        c_slot[b * AGW_CL + (k - e)] = sl;
+                        c_val[b * AGW_CL + (k - e)] = v;
+                    }
+                }
+            }
+            lds_barrier();
+        };
+        uint32_t w0 = 0;
+        for (; w0 + AGW_WIN < total; w0 += AGW_WIN) window(w0, std::false_type{});
+        window(w0, std::true_type{});
+        if (tid < B) {
+            const uint32_t tot = s_cnt[tid] + s_carry[tid], e = s_emit[tid];
+            s_gpos[tid] += e;
+            s_carry[tid] = tot - e;
+            s_cnt[tid] = 0;
+        }
+    }
+}
+
+// bucket b = slots [b*GB, (b+1)*GB); work-group (b, w) folds its share of the bucket's rows into an LDS table.  GB = AG_GB (2048
+// slots x 28 bytes: all four statistics) or, when no MIN / MAX is asked for, AG_GB_SUM (8192 slots x 12 bytes: sum + count).
+template <bool NEED_MM, int GB = AG_GB, int NT = AG_THREADS>
+__global__ __launch_bounds__(NT) void k_agg_bucket(const uint32_t* __restrict__ slot, const double* __restrict__ val,
+                                                   const uint32_t* __restrict__ scanned, uint32_t S, uint32_t W,
+                                                   double* __restrict__ slab /*[B*W][4][GB]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_sum = reinterpret_cast<double*>(s_raw);
-    double* s_mn = s_sum + AG_GB;
-    double* s_mx = s_mn + AG_GB;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mx + AG_GB);
+    double* s_mn = s_sum + GB;                               // NEED_MM only
+    double* s_mx = s_mn + GB;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(NEED_MM ? s_mx + GB : s_sum + GB);
     const uint32_t b = blockIdx.x / W, w = blockIdx.x % W;
-    for (uint32_t g = threadIdx.x; g < (uint32_t)AG_GB; g += AG_THREADS) { s_sum[g] = 0.0; s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; s_cnt[g] = 0; }
+    for (uint32_t g = threadIdx.x; g < (uint32_t)GB; g += NT) {
+        s_sum[g] = 0.0;
+        s_cnt[g] = 0;
+        if (NEED_MM) { s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; }
+    }
     __syncthreads();
     const uint32_t o0 = scanned[(size_t)b * S], o1 = scanned[(size_t)(b + 1) * S];
     const uint32_t share = (o1 - o0 + W - 1) / W;
     const uint32_t lo = o0 + w * share < o1 ? o0 + w * share : o1;
     const uint32_t hi = lo + share < o1 ? lo + share : o1;
-    const uint32_t kbase = b * AG_GB;
-    for (uint32_t base = lo; base < hi; base += AG_THREADS * 8) {
+    const uint32_t kbase = b * GB;
+    for (uint32_t base = lo; base < hi; base += NT * 8) {
         uint32_t k[8];
         double x[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            uint32_t i = base + r * AG_THREADS + threadIdx.x;
+            uint32_t i = base + r * NT + threadIdx.x;
             if (i >= hi) i = hi - 1;
             k[r] = slot[i];
             x[r] = val[i];
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const uint32_t i = base + r * AG_THREADS + threadIdx.x;
+            const uint32_t i = base + r * NT + threadIdx.x;
             if (i < hi && !(k[r] & AG_NULL_MARK)) {
                 const uint32_t g = k[r] - kbase;
                 atomicAdd(&s_sum[g], x[r]);
@@ -639,25 +803,29 @@ __global__ __launch_bounds__(AG_THREADS) void k_agg_bucket(const uint32_t* __res
         }
     }
     __syncthreads();
-    double* row = slab + (size_t)blockIdx.x * 4 * AG_GB;
-    for (uint32_t g = threadIdx.x; g < (uint32_t)AG_GB; g += AG_THREADS) {
+    double* row = slab + (size_t)blockIdx.x * 4 * GB;
+    for (uint32_t g = threadIdx.x; g < (uint32_t)GB; g += NT) {
         row[g] = s_sum[g];
-        row[AG_GB + g] = (double)s_cnt[g];
-        row[2 * AG_GB + g] = s_mn[g];
-        row[3 * AG_GB + g] = s_mx[g];
+        row[GB + g] = (double)s_cnt[g];
+        if (NEED_MM) {
+            row[2 * GB + g] = s_mn[g];
+            row[3 * GB + g] = s_mx[g];
+        }
     }
 }
 
-__global__ __launch_bounds__(OP_THREADS) void k_agg_bucket_fold(const double* __restrict__ slab, uint32_t W, uint32_t n_groups,
+__global__ __launch_bounds__(OP_THREADS) void k_agg_bucket_fold(const double* __restrict__ slab, uint32_t W, uint32_t n_groups, uint32_t GB, int need_mm,
                                                                 double* __restrict__ stats4) {
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
-        const uint32_t b = g / AG_GB, l = g % AG_GB;
+        const uint32_t b = g / GB, l = g % GB;
         double sum = 0.0, cnt = 0.0, mn = GOLAP_F64_MAX, mx = -GOLAP_F64_MAX;
         for (uint32_t w = 0; w < W; ++w) {   // fixed order: reproducible
-            const double* row = slab + (size_t)(b * W + w) * 4 * AG_GB;
-            sum += row[l]; cnt += row[AG_GB + l];
-            mn = row[2 * AG_GB + l] < mn ? row[2 * AG_GB + l] : mn;
-            mx = row[3 * AG_GB + l] > mx ? row[3 * AG_GB + l] : mx;
+            const double* row = slab + (size_t)(b * W + w) * 4 * GB;
+            sum += row[l]; cnt += row[GB + l];
+            if (need_mm) {   // (the sum-only tables leave these two planes unwritten)
+                mn = row[2 * GB + l] < mn ? row[2 * GB + l] : mn;
+                mx = row[3 * GB + l] > mx ? row[3 * GB + l] : mx;
+            }
         }
         stats4[g * 4 + 0] = sum; stats4[g * 4 + 1] = cnt; stats4[g * 4 + 2] = mn; stats4[g * 4 + 3] = mx;
     }
@@ -923,13 +1091,22 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     const char* part_env = knob("GOLAP_AGG_PART");
     const bool part_path = grouped && !lds_path && G <= (uint32_t)AG_GB * AG_MAX_B && p->n_rows >= (1ull << 22) && p->n_rows < 0xFFFFFFF0ull &&
                            !(part_env && !strcmp(part_env, "0"));
-    const uint32_t pB = part_path ? (uint32_t)ceil_div(G, AG_GB) : 0;
     // big-tile scatter once every chunk holds >= 4 of its 16384-row tiles and there are >= 512 chunks
     const bool p_big = part_path && p->n_rows / (4 * AGB_TILE) >= 512;
+    // no MIN / MAX anywhere: 12-byte table entries, 8192 slots per bucket -> a fan-out <= 128, whose unfinished lines fit in LDS next
+    // to the tile (k_agg_scatter_wc).  GOLAP_AGG_WC=0: A/B hook.
+    bool any_mm = false;
+    for (uint32_t i = 0; i < n_specs; ++i) any_mm = any_mm || specs[i].func == GOLAP_AGG_MIN || specs[i].func == GOLAP_AGG_MAX;
+    const char* wc_env = knob("GOLAP_AGG_WC");
+    const bool p_wc = p_big && !any_mm && ceil_div(G, AG_GB_SUM) <= (uint64_t)AGW_MAX_B && !(wc_env && !strcmp(wc_env, "0"));
+    const uint32_t pGB = p_wc ? (uint32_t)AG_GB_SUM : (uint32_t)AG_GB;
+    const uint32_t gb_shift = p_wc ? 13u : 11u;
+    static_assert(AG_GB == 1 << 11 && AG_GB_SUM == 1 << 13, "bucket = slot >> gb_shift");
+    const uint32_t pB = part_path ? (uint32_t)ceil_div(G, pGB) : 0;
     const uint32_t pS = part_path ? (uint32_t)std::min<uint64_t>(2048, p_big ? p->n_rows / (4 * AGB_TILE) : ceil_div(p->n_rows, AG_TILE)) : 0;
     const uint32_t p_chunk = part_path ? (uint32_t)round_up(ceil_div(p->n_rows, pS), AG_TILE) : 0;
     const uint32_t pS2 = part_path ? (uint32_t)ceil_div(p->n_rows, p_chunk) : 0;   // chunks actually used
-    const uint32_t pW = part_path ? std::max<uint32_t>(1, std::min<uint32_t>(8, 2048 / pB)) : 0;
+    const uint32_t pW = part_path ? std::max<uint32_t>(1, std::min<uint32_t>(8, (p_wc ? 1024u : 2048u) / pB)) : 0;
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
     uint32_t lds_grid = 0;
     uint64_t rows_per_block = 0;
@@ -944,7 +1121,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     ws += lds_path ? (uint64_t)lds_grid * 4 * G * 8 : 0;
     if (part_path)
         ws += round_up(p->n_rows * 4, 256) + round_up(p->n_rows * 8, 256) + round_up(((uint64_t)pB * pS2 + 1) * 4, 256) +
-              round_up(ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4, 256) + round_up((uint64_t)pB * pW * 4 * AG_GB * 8, 256) + 4096;
+              round_up(ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4, 256) + round_up((uint64_t)pB * pW * 4 * pGB * 8, 256) + 4096;
     ws += grouped ? 0 : (uint64_t)red_grid * 32;
     GOLAP_TRY(ws_begin(ctx, ws + 4096, st));
     double* stats4 = (double*)ws_take(ctx, (uint64_t)G * 32);
@@ -958,7 +1135,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
         p_val = (double*)ws_take(ctx, p->n_rows * 8);
         p_hist = (uint32_t*)ws_take(ctx, ((uint64_t)pB * pS2 + 1) * 4);
         p_bsums = (uint32_t*)ws_take(ctx, ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4);
-        p_slab = (double*)ws_take(ctx, (uint64_t)pB * pW * 4 * AG_GB * 8);
+        p_slab = (double*)ws_take(ctx, (uint64_t)pB * pW * 4 * pGB * 8);
         if (!p_slot || !p_val || !p_hist || !p_bsums || !p_slab) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted (partition buffers)");
         if (ctx->attr_done.size() < 3) ctx->attr_done.resize(3, false);   // per context = per device (golap_internal.h)
         if (!ctx->attr_done[1]) {
@@ -967,6 +1144,10 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             const void* big[] = {(const void*)k_agg_scatter_big<int, true>, (const void*)k_agg_scatter_big<int, false>,
                                  (const void*)k_agg_scatter_big<long long, true>, (const void*)k_agg_scatter_big<long long, false>};
             for (const void* f : big) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AGB_LDS));
+            const void* wcs[] = {(const void*)k_agg_scatter_wc<int, true>, (const void*)k_agg_scatter_wc<int, false>,
+                                 (const void*)k_agg_scatter_wc<long long, true>, (const void*)k_agg_scatter_wc<long long, false>};
+            for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AGW_LDS));
+            GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<false, AG_GB_SUM, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB_SUM * 12 + 16));
             ctx->attr_done[1] = true;
         }
     }
@@ -1032,10 +1213,10 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                 KernelTimer t(ctx, "agg_partition_hist", st, key_bytes * p->n_rows);
                 if (p->key_dtype == GOLAP_DT_INT32)
                     hipLaunchKernelGGL(k_agg_hist<int>, dim3(pS2), dim3(AG_THREADS), 0, st, (const int*)p->group_key_ptr, (unsigned long long)p->n_rows, G,
-                                       p_chunk, pS2, pB, p_hist);
+                                       p_chunk, pS2, pB, p_hist, gb_shift);
                 else
                     hipLaunchKernelGGL(k_agg_hist<long long>, dim3(pS2), dim3(AG_THREADS), 0, st, (const long long*)p->group_key_ptr,
-                                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist);
+                                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, gb_shift);
             }
             GOLAP_TRY(flat_scan(ctx, st, p_hist, (uint32_t)(L + 1), p_bsums));
             {
@@ -1046,6 +1227,14 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
 #define GOLAP_AGG_SCB(KT, VF)                                                                                                         \
     hipLaunchKernelGGL((k_agg_scatter_big<KT, VF>), dim3(pS2), dim3(AGB_THREADS), AGB_LDS, st, (const KT*)p->group_key_ptr, val,      \
                        (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
+#define GOLAP_AGG_SCW(KT, VF)                                                                                                         \
+    hipLaunchKernelGGL((k_agg_scatter_wc<KT, VF>), dim3(pS2), dim3(AGW_THREADS), AGW_LDS, st, (const KT*)p->group_key_ptr, val,       \
+                       (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
+                if (p_wc) {
+                    if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_SCW(int, true); else GOLAP_AGG_SCW(int, false); }
+                    else { if (vf) GOLAP_AGG_SCW(long long, true); else GOLAP_AGG_SCW(long long, false); }
+                } else
+#undef GOLAP_AGG_SCW
                 if (p_big) {
                     if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_SCB(int, true); else GOLAP_AGG_SCB(int, false); }
                     else { if (vf) GOLAP_AGG_SCB(long long, true); else GOLAP_AGG_SCB(long long, false); }
@@ -1057,12 +1246,14 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             }
             {
                 KernelTimer t(ctx, "hash_aggregate_lds_buckets", st, 12 * p->n_rows + 12ull * G);
-                if (need_minmax)
+                if (p_wc)
+                    hipLaunchKernelGGL((k_agg_bucket<false, AG_GB_SUM, 1024>), dim3(pB * pW), dim3(1024), AG_GB_SUM * 12 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
+                else if (need_minmax)
                     hipLaunchKernelGGL(k_agg_bucket<true>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
                 else
                     hipLaunchKernelGGL(k_agg_bucket<false>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
                 hipLaunchKernelGGL(k_agg_bucket_fold, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, p_slab,
-                                   pW, G, stats4);
+                                   pW, G, pGB, (int)(need_minmax && !p_wc), stats4);
             }
         } else {
             hipLaunchKernelGGL(k_group_init, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, stats4, G);

@@ -324,7 +324,7 @@ constexpr int P2R_THREADS = 1024;
 constexpr int P2R_LINE = 16;     // rows per 128-byte line
 constexpr int P2R_MAX_F = 512;
 
-static inline size_t part2_ring_lds_bytes(uint32_t F, uint32_t R) { return (size_t)F * R * 8 + (size_t)F * 16 + 64 + 3 * 64 * 4; }
+static inline size_t part2_ring_lds_bytes(uint32_t F, uint32_t R) { return (size_t)F * R * 8 + (size_t)F * 16 + 64 + 3 * 128 * 4; }   // (3 piece arrays of P2R_MAX_SRC words)
 // ring length for a fan-out: F * R = 16384 rows of LDS (128 KiB) whatever the fan-out -- a tile brings TILE / F rows per bucket,
 // and a ring must hold that on top of an unfinished line (R = 32 at F = 512 ... 256 at F <= 64)
 static inline uint32_t part2_ring_rows(uint32_t F) { return F >= 512 ? 32u : F >= 256 ? 64u : F >= 128 ? 128u : 256u; }
@@ -336,7 +336,7 @@ struct SegSrc {
     const uint32_t* len;
     uint32_t n_src;     // 0: use fx.groups
 };
-constexpr int P2R_MAX_SRC = 64;
+constexpr int P2R_MAX_SRC = 128;   // pieces of a group: per-XCD sub-ranges, or (source rank x row chunk x sub-range) after a partition exchange
 
 template <int RPT, int R, bool ASM, int DIAG = 0>   // DIAG 2: timing-only build without the flush stores (wrong results; scripts/ab_p12.py)
 __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_part2_ring(const uint2* __restrict__ in_rows, uint2* __restrict__ out_rows, PassCfg cfg, FixedArgs fx,

@@ -41,7 +41,10 @@ static RcclApi* rccl_api(golap_ctx* ctx) {
     static RcclApi api;
     static bool tried = false;
     std::lock_guard<std::mutex> lk(mu);
-    if (tried) return api.handle ? &api : nullptr;
+    if (tried) {
+        if (!api.handle) fail(ctx, GOLAP_ERR_UNSUPPORTED, "librccl is not available (an earlier attempt to load it failed)");
+        return api.handle ? &api : nullptr;
+    }
     tried = true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
@@ -75,9 +78,13 @@ struct golap_comm {
     golap_transport tr{};
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;          // the exchange runs here, beside the caller's compute stream
-    hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_xchg[2] = {nullptr, nullptr}, ev_misc = nullptr;
+    static constexpr int MAX_CHUNKS = 8;
+    hipEvent_t ev_part[2][MAX_CHUNKS] = {}, ev_xchg[2] = {nullptr, nullptr}, ev_hdr = nullptr, ev_misc = nullptr;   // ordering only (no timing)
+    hipEvent_t ev_t[2 * GOLAP_SHARD_STAGES + 1] = {};   // stage begin / end + call start (timing events; recorded only with profiling on)
     uint32_t* h_status = nullptr;          // pinned: status words / size matrices read back by the host
     uint64_t h_status_bytes = 0;
+    uint32_t* d_agree = nullptr;           // device: [0] this rank's agreement word, [16 ..) every rank's (all-gathered); never in the workspace
+    uint32_t* h_agree = nullptr;           // pinned: [0] word to send, [16 ..) words received
     golap_sharded_join_info info{};
 };
 
@@ -161,8 +168,15 @@ struct ShardPlan {
     bool eligible = false;
     uint32_t world = 1, e1 = 0, F1 = 256, per = 256, local_bits = 0, F2 = 1;
     uint32_t nsub = 1;                         // sub-ranges per bucket of the exchange-time partition (ReserveArgs::nsub): a bucket is nsub * cap rows
-    std::vector<uint64_t> rows[2], cap[2];     // [side][rank]
+    uint32_t K = 1;                            // row chunks per side: chunk k is shipped while chunk k + 1 is partitioned
+    std::vector<uint64_t> rows[2];             // [side][rank]
+    std::vector<uint64_t> chunk_rows[2];       // [side][rank] rows of chunks 0 .. K - 2 (whole first-pass tiles); the last chunk takes the rest
+    std::vector<uint64_t> cap[2];              // [side][rank * K + chunk] rows provisioned per (bucket, sub-range)
     JoinPlan local;                            // the one local pass
+    uint64_t rows_of(int side, uint32_t r, uint32_t c) const {
+        const uint64_t n = rows[side][r], cr = chunk_rows[side][r], lo = std::min<uint64_t>(n, (uint64_t)c * cr);
+        return c + 1 == K ? n - lo : std::min<uint64_t>(n, lo + cr) - lo;
+    }
 };
 
 static uint32_t exchange_extra_bits(uint64_t n_build_total) {
@@ -170,6 +184,19 @@ static uint32_t exchange_extra_bits(uint64_t n_build_total) {
     make_plan(std::max<uint64_t>(1, n_build_total), 0, true, p);
     const int32_t over = (int32_t)p.total_bits - 8 - 9;   // hash bits one local pass (<= 9) cannot resolve
     return (uint32_t)std::max(0, std::min(2, over));
+}
+
+// Row chunks per side.  With peers, a rank's first message can leave once its first chunk is partitioned instead of after the whole
+// side (at 8 GPUs the partition pass of a side, ~0.4 ms, is a seventh of the join); alone there is nothing to overlap.  Every chunk
+// must still be a launch the first-pass kernel is efficient at.  GOLAP_SHARD_CHUNKS: A/B and test hook.
+static uint32_t shard_chunks(uint32_t world, uint64_t min_rows_per_rank, bool forced_small) {
+    uint32_t k = world > 1 ? 4u : 1u;
+    if (const char* e = knob("GOLAP_SHARD_CHUNKS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= golap_comm::MAX_CHUNKS) return (uint32_t)v;
+    }
+    while (k > 1 && !forced_small && !narrow_size_ok(min_rows_per_rank / k)) k >>= 1;
+    return k;
 }
 
 static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_probe_total, const uint64_t* b_rows, const uint64_t* p_rows,
@@ -190,26 +217,40 @@ static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_p
     make_local_plan(&pl, sp.local);
     sp.local_bits = sp.local.total_bits - pl.pre_bits;
     sp.F2 = sp.local.passes.empty() ? 1 : sp.local.passes[0].cfg.F;
-    sp.nsub = std::max<uint32_t>(1, std::min<uint32_t>(narrow_nsub(), (uint32_t)P2R_MAX_SRC / world));   // world * nsub pieces per group in the ring pass
+    const char* env = knob("GOLAP_SHARD_FAST");   // test hook: "1" drops the size conditions, "0" disables the fast path
+    const bool forced = env && !strcmp(env, "1");
+    uint64_t min_rows = ~0ull;
+    for (int side = 0; side < 2; ++side)
+        for (uint32_t r = 0; r < world; ++r) min_rows = std::min(min_rows, sp.rows[side][r]);
+    sp.K = shard_chunks(world, min_rows, forced);
+    // world * K * nsub pieces per group in the ring pass
+    sp.nsub = std::max<uint32_t>(1, std::min<uint32_t>(narrow_nsub(), (uint32_t)P2R_MAX_SRC / (world * sp.K)));
+    const uint32_t tile = part1_narrow_tile();
     for (int side = 0; side < 2; ++side) {
-        sp.cap[side].resize(world);
+        sp.cap[side].resize((size_t)world * sp.K);
+        sp.chunk_rows[side].resize(world);
         for (uint32_t r = 0; r < world; ++r) {
-            uint32_t chunk_rows = 0;
-            const uint32_t chunks = narrow_chunks(sp.rows[side][r], &chunk_rows);
-            sp.cap[side][r] = reserve_cap_sub(sp.rows[side][r], sp.F1, sp.nsub, chunks, chunk_rows);
+            sp.chunk_rows[side][r] = round_up(std::max<uint64_t>(1, ceil_div(sp.rows[side][r], sp.K)), tile);
+            for (uint32_t c = 0; c < sp.K; ++c) {
+                const uint64_t n_c = sp.rows_of(side, r, c);
+                uint32_t cr = 0;
+                const uint32_t chunks = narrow_chunks(n_c, &cr);
+                sp.cap[side][(size_t)r * sp.K + c] = reserve_cap_sub(n_c, sp.F1, sp.nsub, chunks, cr);
+            }
         }
     }
-    // the fast path is the two-pass tuple pipeline: one local pass with a ring-sized fan-out, every rank's first pass large
+    // the fast path is the two-pass tuple pipeline: one local pass with a ring-sized fan-out, every first-pass launch large
     // enough for the big-tile kernel, positions within u32
-    bool ok = world <= (uint32_t)P2R_MAX_SRC && sp.local.passes.size() == 1 && sp.F2 >= 32 && sp.F2 <= (uint32_t)P2R_MAX_F && sp.per <= 1024;
+    bool ok = world * sp.K <= (uint32_t)P2R_MAX_SRC && sp.local.passes.size() == 1 && sp.F2 >= 32 && sp.F2 <= (uint32_t)P2R_MAX_F && sp.per <= 1024;
+    for (int side = 0; side < 2 && ok && !forced; ++side)
+        for (uint32_t r = 0; r < world && ok; ++r)
+            if (!narrow_size_ok(sp.rows[side][r] / sp.K)) ok = false;
     for (int side = 0; side < 2 && ok; ++side)
         for (uint32_t r = 0; r < world && ok; ++r) {
-            if (!narrow_size_ok(sp.rows[side][r])) ok = false;
-            if (sp.cap[side][r] * sp.F1 * sp.nsub >= 0xFFFFFFF0ull) ok = false;
+            uint64_t send = 0;
+            for (uint32_t c = 0; c < sp.K; ++c) send += sp.cap[side][(size_t)r * sp.K + c] * sp.F1 * sp.nsub;
+            if (send >= 0xFFFFFFF0ull) ok = false;
         }
-    const char* env = knob("GOLAP_SHARD_FAST");   // test hook: "1" drops the size condition, "0" disables the fast path
-    if (env && !strcmp(env, "1"))
-        ok = world <= (uint32_t)P2R_MAX_SRC && sp.local.passes.size() == 1 && sp.F2 >= 32 && sp.F2 <= (uint32_t)P2R_MAX_F && sp.per <= 1024;
     if (env && !strcmp(env, "0")) ok = false;
     if (const char* e2 = knob("GOLAP_NARROW")) if (!strcmp(e2, "0")) ok = false;
     sp.eligible = ok;
@@ -219,36 +260,42 @@ static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_p
 // device helpers of the fast path
 // ---------------------------------------------------------------------------
 struct ShardSrcTable {
-    uint32_t cap[P2R_MAX_SRC];    // rows provisioned per bucket by source r
-    uint32_t base[P2R_MAX_SRC];   // row offset (relative to the tuple base pointer) of source r's group 0
+    uint32_t cap[P2R_MAX_SRC];    // [source r * K + chunk c] rows provisioned per (bucket, sub-range)
+    uint32_t base[P2R_MAX_SRC];   // row offset (relative to the tuple base pointer) of that (source, chunk)'s group 0
 };
 
 // Segment table of the ring pass + the slot sizes of k_slots_setup, from the all-gathered reservation cursors:
-//   hdr[r * hdr_stride + b] = rows source r put into bucket b (b owner-major: my buckets are [me * per, (me + 1) * per)),
-//   hdr[r * hdr_stride + F1] = source r's "narrow attempt failed" word.
-__global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restrict__ hdr, uint32_t hdr_stride, uint32_t F1, uint32_t world, uint32_t me,
-                                                        uint32_t per, uint32_t nsub, ShardSrcTable src, uint32_t F2, uint32_t sigmas, uint32_t pad,
-                                                        uint32_t* __restrict__ seg_off, uint32_t* __restrict__ seg_len, uint32_t* __restrict__ slot_base,
-                                                        uint32_t* __restrict__ slot_cap, uint32_t* __restrict__ status, unsigned long long limit_rows) {
+//   hdr[r * hdr_stride + c * F1 * nsub + b * nsub + s] = rows source r put into sub-range s of bucket b in its chunk c (b owner-major:
+//   my buckets are [me * per, (me + 1) * per)),  hdr[r * hdr_stride + K * F1 * nsub] = source r's "narrow attempt failed" word.
+__global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restrict__ hdr, uint32_t hdr_stride, uint32_t F1, uint32_t world, uint32_t K,
+                                                        uint32_t me, uint32_t per, uint32_t nsub, ShardSrcTable src, uint32_t F2, uint32_t sigmas,
+                                                        uint32_t pad, uint32_t* __restrict__ seg_off, uint32_t* __restrict__ seg_len,
+                                                        uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap, uint32_t* __restrict__ status,
+                                                        unsigned long long limit_rows) {
     __shared__ uint32_t s_w[16];
     const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
+    const uint32_t n_src = world * K * nsub;
     uint32_t total = 0;
     if (g < per) {
         uint32_t n_g = 0;
         for (uint32_t r = 0; r < world; ++r)
-            for (uint32_t s = 0; s < nsub; ++s) {
-                const uint32_t c = hdr[(size_t)r * hdr_stride + (me * per + g) * nsub + s];
-                const uint32_t len = c < src.cap[r] ? c : src.cap[r];   // (an overflowing range raised source r's word; the result is discarded)
-                seg_off[(g * world + r) * nsub + s] = src.base[r] + (g * nsub + s) * src.cap[r];
-                seg_len[(g * world + r) * nsub + s] = len;
-                n_g += len;
+            for (uint32_t c = 0; c < K; ++c) {
+                const uint32_t cp = src.cap[r * K + c];
+                for (uint32_t sr = 0; sr < nsub; ++sr) {
+                    const uint32_t cnt = hdr[(size_t)r * hdr_stride + (size_t)c * F1 * nsub + (me * per + g) * nsub + sr];
+                    const uint32_t len = cnt < cp ? cnt : cp;   // (an overflowing range raised source r's word; the result is discarded)
+                    const uint32_t piece = (r * K + c) * nsub + sr;
+                    seg_off[g * n_src + piece] = src.base[r * K + c] + (g * nsub + sr) * cp;
+                    seg_len[g * n_src + piece] = len;
+                    n_g += len;
+                }
             }
         const uint32_t avg = (n_g + F2 - 1) / F2;
         const uint32_t cap = (avg + sigmas * isqrt_u32(avg) + pad + 15u) & ~15u;
         slot_cap[g] = cap;
         total = cap * F2;
     }
-    if (g < world && hdr[(size_t)g * hdr_stride + F1 * nsub]) atomicOr(status, 1u);   // some rank met a wide key / an overflowing bucket
+    if (g < world && hdr[(size_t)g * hdr_stride + (size_t)K * F1 * nsub]) atomicOr(status, 1u);   // some rank met a wide key / an overflowing bucket
     const uint32_t inc = wave_inclusive_scan(total);
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
@@ -283,155 +330,292 @@ static int32_t ensure_host_words(golap_comm* cm, uint64_t bytes) {
 }
 
 // ---------------------------------------------------------------------------
+// agreement: every rank contributes one word (0 = ready, else its error code) and learns everybody's -- the only way a collective
+// call can fail on ONE rank without the others waiting forever in the next ncclSend/ncclRecv.  Runs on the communicator's stream
+// (which waits for nothing at that point) and ends in a host synchronisation; the fast path hides it behind its first partition
+// kernel.  Returns GOLAP_OK when every rank is ready, this rank's own error if it has one, GOLAP_ERR_PEER otherwise.
+// ---------------------------------------------------------------------------
+static int32_t shard_agree(golap_ctx* ctx, golap_comm* cm, int32_t my_err) {
+    const uint32_t P = (uint32_t)cm->world;
+    std::string my_msg = my_err != GOLAP_OK ? ctx->err : std::string();
+    cm->h_agree[0] = (uint32_t)my_err;
+    hipError_t e = hipMemcpyAsync(cm->d_agree, cm->h_agree, 4, hipMemcpyHostToDevice, cm->stream);
+    int32_t st = e == hipSuccess ? comm_all_gather(cm, (uint64_t)cm->d_agree, (uint64_t)(cm->d_agree + 16), 4, cm->stream) : GOLAP_ERR_HIP;
+    if (st == GOLAP_OK) e = hipMemcpyAsync(cm->h_agree + 16, cm->d_agree + 16, (size_t)P * 4, hipMemcpyDeviceToHost, cm->stream);
+    if (st == GOLAP_OK && e == hipSuccess) e = hipStreamSynchronize(cm->stream);
+    cm->info.host_syncs += 1;
+    if (my_err != GOLAP_OK) { ctx->err = my_msg; set_thread_error(my_msg.c_str()); return my_err; }
+    if (st != GOLAP_OK) return st;
+    if (e != hipSuccess) return fail(ctx, GOLAP_ERR_HIP, "agreement round failed: %s", hipGetErrorString(e));
+    for (uint32_t r = 0; r < P; ++r)
+        if (cm->h_agree[16 + r] != 0u)
+            return fail(ctx, GOLAP_ERR_PEER, "golap_sharded_join: rank %u failed before the exchange (its error code %u); no rank exchanged anything", r,
+                        cm->h_agree[16 + r]);
+    return GOLAP_OK;
+}
+
+// Leaves a collective call on an error path with nothing in flight: kernels and transfers still queued on either stream may
+// read or write the workspace and the held slabs, which the caller releases right after.
+struct ShardDrain {
+    golap_ctx* ctx;
+    golap_comm* cm;
+    hipStream_t st;
+    bool armed = true;
+    bool ws_open = false;
+    ShardDrain(golap_ctx* c, golap_comm* m, hipStream_t s) : ctx(c), cm(m), st(s) {}
+    ~ShardDrain() {
+        if (!armed) return;
+        (void)hipStreamSynchronize(cm->stream);
+        (void)hipStreamSynchronize(st);
+        if (ws_open) ws_end(ctx, st);
+    }
+};
+
+// ---------------------------------------------------------------------------
 // fast path
 // ---------------------------------------------------------------------------
-static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, bool* failed) {
-    const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2, nsub = sp.nsub;
+struct ShardFastLayout {   // everything the fast path derives from the plan alone (host only, cannot fail after it has been checked)
+    uint64_t send_rows[2], recv_rows[2], final_rows_[2];
+    uint64_t send_base[2][golap_comm::MAX_CHUNKS];          // [side][chunk] first row of my chunk's partitioned region
+    std::vector<uint64_t> recv_off[2];                       // [side][r * K + c] first row of (source r, chunk c)'s rows bound for me
+    uint32_t hdr_words, hdr_stride;                          // per side: K * F1 * nsub cursors + 4 words; both sides gathered at once
+    uint64_t need;
+};
+
+static int32_t shard_fast_layout(golap_ctx* ctx, const golap_sharded_join_params* p, const ShardPlan& sp, uint32_t me, ShardFastLayout& L) {
+    const uint32_t P = sp.world, F1 = sp.F1, per = sp.per, F2 = sp.F2, nsub = sp.nsub, K = sp.K;
+    for (int side = 0; side < 2; ++side) {
+        uint64_t so = 0;
+        for (uint32_t c = 0; c < K; ++c) {
+            L.send_base[side][c] = so;
+            so += (uint64_t)F1 * nsub * sp.cap[side][(size_t)me * K + c];
+        }
+        L.send_rows[side] = so;
+        L.recv_off[side].assign((size_t)P * K, 0);
+        uint64_t ro = so, n_g_max = 0;
+        for (uint32_t r = 0; r < P; ++r)
+            for (uint32_t c = 0; c < K; ++c) {
+                const uint64_t cp = sp.cap[side][(size_t)r * K + c];
+                n_g_max += (uint64_t)nsub * cp;
+                if (r == me) { L.recv_off[side][(size_t)r * K + c] = L.send_base[side][c] + (uint64_t)me * per * nsub * cp; continue; }   // own buckets are read in place
+                L.recv_off[side][(size_t)r * K + c] = ro;
+                ro += (uint64_t)per * nsub * cp;
+            }
+        L.recv_rows[side] = ro - so;
+        const uint64_t avg = ceil_div(n_g_max, F2);
+        uint32_t sg, pd;
+        provision_of("GOLAP_SLOT_SIGMAS", sg, pd);   // the same head-room k_shard_segments lays the slots out with
+        L.final_rows_[side] = (uint64_t)per * F2 * round_up(avg + (uint64_t)sg * isqrt_host(avg) + pd + 15, 16);
+        if (L.send_rows[side] + L.recv_rows[side] >= 0xFFFFFFF0ull || L.final_rows_[side] >= 0xFFFFFFF0ull)
+            return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: positions exceed u32");
+    }
+    L.hdr_words = K * F1 * nsub + 4;
+    L.hdr_stride = 2 * L.hdr_words;
+    uint64_t small = 0;
+    small += round_up((uint64_t)L.hdr_stride * 4, 256) + round_up((uint64_t)P * L.hdr_stride * 4, 256);                                   // cursors + gathered
+    small += 2 * (2 * round_up((uint64_t)per * P * K * nsub * 4, 256) + 2 * round_up((uint64_t)(per + 1) * 4, 256) + 2 * round_up((uint64_t)per * F2 * 4, 256));
+    small += 2 * K * 2 * round_up(2048 * 4, 256) + 4096 + round_up((uint64_t)P * 4, 256);
+    L.need = small + (1 << 20);
+    for (int side = 0; side < 2; ++side) L.need += round_up((L.send_rows[side] + L.recv_rows[side]) * 8, 256) + round_up(L.final_rows_[side] * 8, 256);
+    if (p->join_type & 2) L.need += round_up(ceil_div(L.final_rows_[1], 32) * 4 + 8, 256);
+    return GOLAP_OK;
+}
+
+static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, bool* failed,
+                                 int32_t arg_err) {
+    const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2, nsub = sp.nsub, K = sp.K;
     const uint64_t max_msg = shard_max_msg(cm, p->max_msg_bytes);
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
     const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
     const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};
-    for (int side = 0; side < 2; ++side)
-        if (n_local[side] != sp.rows[side][me]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "local row count differs from the sharding every rank assumes");
-    GOLAP_TRY(ensure_scatter_lds(ctx));
-    // ---- workspace: per side [send: F1 x cap_me | recv: per x cap_r for r != me | final (slot-provisioned)] + small arrays ----
-    uint64_t send_rows[2], recv_rows[2], final_rows_[2], recv_off_rows[2][P2R_MAX_SRC];
-    for (int side = 0; side < 2; ++side) {
-        send_rows[side] = (uint64_t)F1 * nsub * sp.cap[side][me];
-        uint64_t ro = send_rows[side], n_g_max = 0;
-        for (uint32_t r = 0; r < P; ++r) {
-            n_g_max += (uint64_t)nsub * sp.cap[side][r];
-            if (r == me) { recv_off_rows[side][r] = (uint64_t)me * per * nsub * sp.cap[side][me]; continue; }   // own buckets are read in place
-            recv_off_rows[side][r] = ro;
-            ro += (uint64_t)per * nsub * sp.cap[side][r];
+    const bool timing = ctx->prof.enabled;
+    auto stamp = [&](int which, hipStream_t s) { if (timing) (void)hipEventRecord(cm->ev_t[which], s); };   // which: 2 * stage + {0, 1}; 16 = call start
+    ShardDrain drain(ctx, cm, st);
+    // ---- everything that can fail on the host, BEFORE anything is exchanged: arguments (checked by the caller: arg_err), layout,
+    //      kernel attributes, workspace, small arrays.  Its outcome is this rank's agreement word. ----
+    ShardFastLayout L;
+    struct SideArrays { uint32_t *c_off[golap_comm::MAX_CHUNKS], *c_len[golap_comm::MAX_CHUNKS], *seg_off, *seg_len, *slot_base, *slot_cap, *sub_start, *sub_len; };
+    SideArrays A[2];
+    uint64_t tuples[2] = {0, 0}, finals[2] = {0, 0};
+    uint32_t *words = nullptr, *status_all = nullptr, *probe_hit = nullptr, *hdr = nullptr, *hdr_all = nullptr;
+    uint32_t nc[2][golap_comm::MAX_CHUNKS], ccr[2][golap_comm::MAX_CHUNKS];
+    auto prepare = [&]() -> int32_t {
+        if (arg_err != GOLAP_OK) return arg_err;
+        for (int side = 0; side < 2; ++side)
+            if (n_local[side] != sp.rows[side][me]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "local row count differs from the sharding every rank assumes");
+        GOLAP_TRY(shard_fast_layout(ctx, p, sp, me, L));
+        GOLAP_TRY(ensure_scatter_lds(ctx));
+        GOLAP_TRY(ensure_host_words(cm, (uint64_t)P * 4));
+        GOLAP_TRY(ws_begin(ctx, L.need, st));
+        drain.ws_open = true;
+        const char* oom = "sharded join workspace exhausted";
+        for (int side = 0; side < 2; ++side) {
+            tuples[side] = ws_take(ctx, (L.send_rows[side] + L.recv_rows[side]) * 8);
+            finals[side] = ws_take(ctx, L.final_rows_[side] * 8);
+            if (!tuples[side] || !finals[side]) return fail(ctx, GOLAP_ERR_OOM, oom);
         }
-        recv_rows[side] = ro - send_rows[side];
-        const uint64_t avg = ceil_div(n_g_max, F2);
-        uint32_t sg, pd;
-        provision_of("GOLAP_SLOT_SIGMAS", sg, pd);   // the same head-room k_shard_segments lays the slots out with
-        final_rows_[side] = (uint64_t)per * F2 * round_up(avg + (uint64_t)sg * isqrt_host(avg) + pd + 15, 16);
-        if (send_rows[side] + recv_rows[side] >= 0xFFFFFFF0ull || final_rows_[side] >= 0xFFFFFFF0ull)
-            return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: positions exceed u32");
-    }
-    const uint32_t hdr_stride = F1 * nsub + 4;
-    uint64_t small = 0;
-    small += 2 * (round_up((uint64_t)hdr_stride * 4, 256) + round_up((uint64_t)P * hdr_stride * 4, 256));          // cursors + gathered
-    small += 2 * (2 * round_up((uint64_t)per * P * nsub * 4, 256) + 2 * round_up((uint64_t)(per + 1) * 4, 256) + 2 * round_up((uint64_t)per * F2 * 4, 256));
-    small += 2 * 2 * round_up(2048 * 4, 256) + 4096 + round_up((uint64_t)P * 4, 256);
-    uint64_t need = small + (1 << 20);
-    for (int side = 0; side < 2; ++side) need += round_up((send_rows[side] + recv_rows[side]) * 8, 256) + round_up(final_rows_[side] * 8, 256);
-    if (p->join_type & 2) need += round_up(ceil_div(final_rows_[1], 32) * 4 + 8, 256);
-    GOLAP_TRY(ws_begin(ctx, need, st));
-    uint64_t tuples[2], finals[2];
-    for (int side = 0; side < 2; ++side) {
-        tuples[side] = ws_take(ctx, (send_rows[side] + recv_rows[side]) * 8);
-        finals[side] = ws_take(ctx, final_rows_[side] * 8);
-        if (!tuples[side] || !finals[side]) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
-    }
-    uint32_t* words = (uint32_t*)ws_take(ctx, 16);            // [0] local status (any rank's failure ORed in), [1] constant 0
-    uint32_t* status_all = (uint32_t*)ws_take(ctx, (uint64_t)P * 4);
-    if (!words || !status_all) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
-    GOLAP_TRY(zero_async(ctx, st, words, 16));
-    uint32_t* probe_hit = nullptr;
-    if (p->join_type & 2) {
-        const uint64_t nw = ceil_div(final_rows_[1], 32) + 1;
-        probe_hit = (uint32_t*)ws_take(ctx, nw * 4);
-        if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted (probe bitmap)");
-        GOLAP_TRY(zero_async(ctx, st, probe_hit, nw * 4));
-    }
-    SideResult res[2];
-    uint32_t *hdr[2], *hdr_all[2];
-    // ---- partition both sides (compute stream); each side's gather + exchange follows on the communicator's stream ----
-    for (int side = 0; side < 2; ++side) {
-        hdr[side] = (uint32_t*)ws_take(ctx, (uint64_t)hdr_stride * 4);          // [F1] reservation cursors, [F1] this rank's failure word
-        hdr_all[side] = (uint32_t*)ws_take(ctx, (uint64_t)P * hdr_stride * 4);
-        uint32_t chunk_rows = 0;
-        const uint32_t nc = narrow_chunks(n_local[side], &chunk_rows);
-        uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
-        uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
-        if (!hdr[side] || !hdr_all[side] || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
-        GOLAP_TRY(zero_async(ctx, st, hdr[side], (uint64_t)hdr_stride * 4));
-        hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_local[side], chunk_rows, nc, c_off, c_len);
-        PassCfg cfg;
-        memset(&cfg, 0, sizeof cfg);
-        cfg.F = F1;
-        cfg.S = nc;
-        cfg.mode = 1;
-        cfg.e1 = sp.e1;
-        cfg.owners_log2 = ilog2(P);
-        cfg.pre_hashed = p1n_variant() != 0 ? 1u : 0u;   // the tuples carry hash_int32(key) from here on (PassCfg::pre_hashed): what travels is (hash, row id)
+        words = (uint32_t*)ws_take(ctx, 16);            // [0] local status (any rank's failure ORed in), [1] constant 0
+        status_all = (uint32_t*)ws_take(ctx, (uint64_t)P * 4);
+        hdr = (uint32_t*)ws_take(ctx, (uint64_t)L.hdr_stride * 4);          // [side][K][F1 * nsub] reservation cursors, [side] failure word
+        hdr_all = (uint32_t*)ws_take(ctx, (uint64_t)P * L.hdr_stride * 4);
+        if (!words || !status_all || !hdr || !hdr_all) return fail(ctx, GOLAP_ERR_OOM, oom);
+        if (p->join_type & 2) {
+            probe_hit = (uint32_t*)ws_take(ctx, (ceil_div(L.final_rows_[1], 32) + 1) * 4);
+            if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted (probe bitmap)");
+        }
+        for (int side = 0; side < 2; ++side) {
+            for (uint32_t c = 0; c < K; ++c) {
+                nc[side][c] = narrow_chunks(sp.rows_of(side, me, c), &ccr[side][c]);
+                A[side].c_off[c] = (uint32_t*)ws_take(ctx, (uint64_t)nc[side][c] * 4);
+                A[side].c_len[c] = (uint32_t*)ws_take(ctx, (uint64_t)nc[side][c] * 4);
+                if (!A[side].c_off[c] || !A[side].c_len[c]) return fail(ctx, GOLAP_ERR_OOM, oom);
+            }
+            A[side].seg_off = (uint32_t*)ws_take(ctx, (uint64_t)per * P * K * nsub * 4);
+            A[side].seg_len = (uint32_t*)ws_take(ctx, (uint64_t)per * P * K * nsub * 4);
+            A[side].slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(per + 1) * 4);
+            A[side].slot_cap = (uint32_t*)ws_take(ctx, (uint64_t)per * 4);
+            A[side].sub_start = (uint32_t*)ws_take(ctx, (uint64_t)per * F2 * 4);
+            A[side].sub_len = (uint32_t*)ws_take(ctx, (uint64_t)per * F2 * 4);
+            if (!A[side].seg_off || !A[side].seg_len || !A[side].slot_base || !A[side].slot_cap || !A[side].sub_start || !A[side].sub_len)
+                return fail(ctx, GOLAP_ERR_OOM, oom);
+        }
+        return GOLAP_OK;
+    };
+    const int32_t prep = prepare();
+    // ---- partition: `K` chunks per side on the compute stream.  The first chunk is enqueued BEFORE the agreement round so that
+    //      the round's host synchronisation is hidden behind it; nothing is exchanged until every rank is known to be ready. ----
+    PassCfg cfg1;
+    memset(&cfg1, 0, sizeof cfg1);
+    cfg1.F = F1;
+    cfg1.mode = 1;
+    cfg1.e1 = sp.e1;
+    cfg1.owners_log2 = ilog2(P);
+    cfg1.pre_hashed = p1n_variant() != 0 ? 1u : 0u;   // the tuples carry hash_int32(key) from here on (PassCfg::pre_hashed): what travels is (hash, row id)
+    auto partition_chunk = [&](int side, uint32_t c) -> int32_t {
+        const uint64_t lo = std::min<uint64_t>(n_local[side], (uint64_t)c * sp.chunk_rows[side][me]), n_c = sp.rows_of(side, me, c);
+        uint32_t* cur = hdr + (size_t)side * L.hdr_words + (size_t)c * F1 * nsub;
+        uint32_t* failw = hdr + (size_t)side * L.hdr_words + (size_t)K * F1 * nsub;
+        hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc[side][c], 256)), dim3(256), 0, st, (uint32_t)n_c, ccr[side][c], nc[side][c], A[side].c_off[c],
+                           A[side].c_len[c]);
+        PassCfg cfg = cfg1;
+        cfg.S = nc[side][c];
         {
-            KernelTimer t(ctx, side ? "partition_scatter_probe" : "partition_scatter_build", st, 16 * n_local[side]);
-            launch_part1_narrow(st, keys_in[side], rid_base[side], nc, c_off, c_len, tuples[side], cfg,
-                                ReserveArgs{hdr[side], (uint32_t)sp.cap[side][me], hdr[side] + F1 * nsub, hdr[side] + F1 * nsub, nullptr, nsub});
+            KernelTimer t(ctx, side ? "partition_scatter_probe" : "partition_scatter_build", st, 16 * n_c);
+            launch_part1_narrow(st, keys_in[side] + lo * 8, rid_base[side] + (uint32_t)lo, nc[side][c], A[side].c_off[c], A[side].c_len[c],
+                                tuples[side] + L.send_base[side][c] * 8, cfg, ReserveArgs{cur, (uint32_t)sp.cap[side][(size_t)me * K + c], failw, failw, nullptr, nsub});
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
-        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side], st));
-        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side], 0));
-        GOLAP_TRY(comm_all_gather(cm, (uint64_t)hdr[side], (uint64_t)hdr_all[side], (uint64_t)hdr_stride * 4, cm->stream));
+        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side][c], st));
+        return GOLAP_OK;
+    };
+    int32_t launch_err = prep;
+    if (prep == GOLAP_OK) {
+        stamp(16, st);
+        launch_err = zero_async(ctx, st, words, 16);
+        if (launch_err == GOLAP_OK) launch_err = zero_async(ctx, st, hdr, (uint64_t)L.hdr_stride * 4);
+        if (launch_err == GOLAP_OK && probe_hit) launch_err = zero_async(ctx, st, probe_hit, (ceil_div(L.final_rows_[1], 32) + 1) * 4);
+        stamp(2 * GOLAP_SHARD_ST_PART_BUILD, st);
+        if (launch_err == GOLAP_OK) launch_err = partition_chunk(0, 0);
+    }
+    GOLAP_TRY(shard_agree(ctx, cm, launch_err));   // (on failure `drain` empties both streams and closes the workspace)
+    for (uint32_t c = 1; c < K; ++c) GOLAP_TRY(partition_chunk(0, c));
+    stamp(2 * GOLAP_SHARD_ST_PART_BUILD + 1, st);
+    stamp(2 * GOLAP_SHARD_ST_PART_PROBE, st);
+    for (uint32_t c = 0; c < K; ++c) GOLAP_TRY(partition_chunk(1, c));
+    stamp(2 * GOLAP_SHARD_ST_PART_PROBE + 1, st);
+    // ---- exchange (communicator's stream): build chunks as they are produced, then ONE all-gather of both sides' cursors and
+    //      failure words (the probe side is partitioned long before the build side's last message has left), then the probe chunks ----
+    auto exchange_chunk = [&](int side, uint32_t c) -> int32_t {
+        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side][c], 0));
+        if (c == 0) stamp(2 * (side ? GOLAP_SHARD_ST_XCHG_PROBE : GOLAP_SHARD_ST_XCHG_BUILD), cm->stream);
         std::vector<golap_p2p_op> ops;
+        const uint64_t my_cap = sp.cap[side][(size_t)me * K + c];
         for (uint32_t r = 0; r < P; ++r) {
             if (r == me) continue;
-            const uint64_t sbytes = (uint64_t)per * nsub * sp.cap[side][me] * 8, rbytes = (uint64_t)per * nsub * sp.cap[side][r] * 8;
-            split_message((int32_t)r, true, tuples[side] + (uint64_t)r * per * nsub * sp.cap[side][me] * 8, sbytes, max_msg, ops);
-            split_message((int32_t)r, false, tuples[side] + recv_off_rows[side][r] * 8, rbytes, max_msg, ops);
+            const uint64_t sbytes = (uint64_t)per * nsub * my_cap * 8, rbytes = (uint64_t)per * nsub * sp.cap[side][(size_t)r * K + c] * 8;
+            split_message((int32_t)r, true, tuples[side] + (L.send_base[side][c] + (uint64_t)r * per * nsub * my_cap) * 8, sbytes, max_msg, ops);
+            split_message((int32_t)r, false, tuples[side] + L.recv_off[side][(size_t)r * K + c] * 8, rbytes, max_msg, ops);
             cm->info.bytes_sent[side] += sbytes;
         }
         GOLAP_TRY(comm_exchange(cm, ops, cm->stream));
-        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[side], cm->stream));
-        cm->info.rows_received[side] = recv_rows[side] + (uint64_t)per * nsub * sp.cap[side][me];
-    }
-    // ---- ring pass per side, as soon as that side's rows are in ----
+        return GOLAP_OK;
+    };
+    for (uint32_t c = 0; c < K; ++c) GOLAP_TRY(exchange_chunk(0, c));
+    stamp(2 * GOLAP_SHARD_ST_XCHG_BUILD + 1, cm->stream);
+    GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[0], cm->stream));
+    GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[1][K - 1], 0));
+    GOLAP_TRY(comm_all_gather(cm, (uint64_t)hdr, (uint64_t)hdr_all, (uint64_t)L.hdr_stride * 4, cm->stream));
+    GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_hdr, cm->stream));
+    for (uint32_t c = 0; c < K; ++c) GOLAP_TRY(exchange_chunk(1, c));
+    stamp(2 * GOLAP_SHARD_ST_XCHG_PROBE + 1, cm->stream);
+    GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[1], cm->stream));
+    // ---- ring pass per side, as soon as that side's rows (and the cursors) are in ----
+    SideResult res[2];
     for (int side = 0; side < 2; ++side) {
-        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_xchg[side], 0));
-        uint32_t* seg_off = (uint32_t*)ws_take(ctx, (uint64_t)per * P * nsub * 4);
-        uint32_t* seg_len = (uint32_t*)ws_take(ctx, (uint64_t)per * P * nsub * 4);
-        uint32_t* slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(per + 1) * 4);
-        uint32_t* slot_cap = (uint32_t*)ws_take(ctx, (uint64_t)per * 4);
-        uint32_t* sub_start = (uint32_t*)ws_take(ctx, (uint64_t)per * F2 * 4);
-        uint32_t* sub_len = (uint32_t*)ws_take(ctx, (uint64_t)per * F2 * 4);
-        if (!seg_off || !seg_len || !slot_base || !slot_cap || !sub_start || !sub_len) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted");
+        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, side ? cm->ev_xchg[1] : cm->ev_hdr, 0));   // (ev_hdr is recorded behind ev_xchg[0])
+        cm->info.rows_received[side] = L.recv_rows[side];
+        for (uint32_t c = 0; c < K; ++c) cm->info.rows_received[side] += (uint64_t)per * nsub * sp.cap[side][(size_t)me * K + c];
         ShardSrcTable tab;
         memset(&tab, 0, sizeof tab);
-        for (uint32_t r = 0; r < P; ++r) {
-            tab.cap[r] = (uint32_t)sp.cap[side][r];
-            tab.base[r] = (uint32_t)recv_off_rows[side][r];
-        }
+        for (uint32_t r = 0; r < P; ++r)
+            for (uint32_t c = 0; c < K; ++c) {
+                tab.cap[r * K + c] = (uint32_t)sp.cap[side][(size_t)r * K + c];
+                tab.base[r * K + c] = (uint32_t)L.recv_off[side][(size_t)r * K + c];
+            }
         uint32_t sigmas, pad;
         provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
-        hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)hdr_all[side], hdr_stride, F1, P, me, per, nsub, tab, F2, sigmas, pad,
-                           seg_off, seg_len, slot_base, slot_cap, words, (unsigned long long)final_rows_[side]);
-        FixedArgs fx{GroupSrc{}, slot_base, slot_cap, sub_start, sub_len, words, nullptr};
+        stamp(2 * (side ? GOLAP_SHARD_ST_RING_PROBE : GOLAP_SHARD_ST_RING_BUILD), st);
+        hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)(hdr_all + (size_t)side * L.hdr_words), L.hdr_stride, F1, P, K, me, per,
+                           nsub, tab, F2, sigmas, pad, A[side].seg_off, A[side].seg_len, A[side].slot_base, A[side].slot_cap, words,
+                           (unsigned long long)L.final_rows_[side]);
+        FixedArgs fx{GroupSrc{}, A[side].slot_base, A[side].slot_cap, A[side].sub_start, A[side].sub_len, words, words};
         PassCfg cfg = sp.local.passes[0].cfg;
         cfg.S = 1;
         cfg.pre_hashed = p1n_variant() != 0 ? 1u : 0u;
         {
             KernelTimer t(ctx, side ? "local_scatter_probe" : "local_scatter_build", st, 16 * cm->info.rows_received[side]);
-            launch_part2_ring(st, per, tuples[side], finals[side], cfg, fx, SegSrc{seg_off, seg_len, P * nsub});
+            launch_part2_ring(st, per, tuples[side], finals[side], cfg, fx, SegSrc{A[side].seg_off, A[side].seg_len, P * K * nsub});
         }
         GOLAP_HIP_TRY(ctx, hipGetLastError());
+        stamp(2 * (side ? GOLAP_SHARD_ST_RING_PROBE : GOLAP_SHARD_ST_RING_BUILD) + 1, st);
         res[side] = SideResult();
         res[side].keys = (const long long*)finals[side];
-        res[side].alt_start = sub_start;
-        res[side].alt_len = sub_len;
+        res[side].alt_start = A[side].sub_start;
+        res[side].alt_len = A[side].sub_len;
         res[side].flag = words + 1;
-        res[side].positions = final_rows_[side];
+        res[side].positions = L.final_rows_[side];
     }
     JoinPlan jp = sp.local;
     jp.n_sub = (uint64_t)per * F2;
+    stamp(2 * GOLAP_SHARD_ST_JOIN, st);
     GOLAP_TRY(launch_lds_join(ctx, st, jp, res[0], res[1], cm->info.rows_received[0], cm->info.rows_received[1], p->out_pairs_ptr, p->out_count_ptr,
                               p->max_pairs, p->join_type, true, nullptr, words, probe_hit));
+    stamp(2 * GOLAP_SHARD_ST_JOIN + 1, st);
     // ---- did the narrow attempt hold on EVERY rank?  (all ranks must take the same path: the words are gathered) ----
     GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_misc, st));
     GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_misc, 0));
+    stamp(2 * GOLAP_SHARD_ST_STATUS, cm->stream);
     GOLAP_TRY(comm_all_gather(cm, (uint64_t)words, (uint64_t)status_all, 4, cm->stream));
-    GOLAP_TRY(ensure_host_words(cm, (uint64_t)P * 4));
     GOLAP_HIP_TRY(ctx, hipMemcpyAsync(cm->h_status, status_all, (size_t)P * 4, hipMemcpyDeviceToHost, cm->stream));
+    stamp(2 * GOLAP_SHARD_ST_STATUS + 1, cm->stream);
     GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_misc, cm->stream));
+    drain.ws_open = false;
     ws_end(ctx, st);
     GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_misc, 0));   // the caller's stream also orders behind the communicator's
-    GOLAP_HIP_TRY(ctx, hipEventSynchronize(cm->ev_misc));         // THE host synchronisation of the fast path
+    GOLAP_HIP_TRY(ctx, hipEventSynchronize(cm->ev_misc));         // the host synchronisation at the end of the fast path
+    drain.armed = false;
     cm->info.host_syncs += 1;
+    cm->info.chunks = K;
+    cm->info.sub_ranges = nsub;
+    if (timing) {
+        for (int sg = 0; sg < GOLAP_SHARD_STAGES; ++sg)
+            for (int e = 0; e < 2; ++e) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, cm->ev_t[16], cm->ev_t[2 * sg + e]) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
+                cm->info.stage_ms[sg][e] = ms;
+            }
+        cm->info.total_ms = cm->info.stage_ms[GOLAP_SHARD_ST_STATUS][1];
+    }
     uint32_t any = 0;
     for (uint32_t r = 0; r < P; ++r) any |= cm->h_status[r];
     *failed = any != 0;
@@ -457,22 +641,36 @@ struct SlabHold {   // slabs that must outlive the workspace (the workspace is r
     }
 };
 
-static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st) {
+static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, int32_t arg_err) {
     const uint32_t P = sp.world, me = (uint32_t)cm->rank, e1 = sp.e1, F1 = sp.F1, per = sp.per;
     const uint64_t max_msg = shard_max_msg(cm, p->max_msg_bytes);
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
     const uint64_t keys_in[2] = {p->build_key_ptr, p->probe_key_ptr};
     const uint32_t rid_base[2] = {p->build_rid_base, p->probe_rid_base};
-    SlabHold hold(ctx);
+    SlabHold hold(ctx);                  // (declared before `drain`: on an error path the streams are emptied BEFORE the slabs go back to the pool)
+    ShardDrain drain(ctx, cm, st);
     uint64_t recv_keys[2] = {0, 0}, recv_rids[2] = {0, 0}, n_recv[2] = {0, 0};
     std::vector<uint64_t> seg_off[2], seg_len[2];
     const uint64_t off_words = (uint64_t)F1 + 1;
-    GOLAP_TRY(ensure_host_words(cm, 2 * (uint64_t)P * off_words * 4));
+    // what depends on the arguments alone is allocated first; every rank says so before anything is exchanged (shard_agree).  The
+    // receive buffers depend on the data: they get their own agreement round per side, next to the read-back that sizes them.
+    uint64_t pk_[2] = {0, 0}, pr_[2] = {0, 0}, offs_[2] = {0, 0}, offs_all_[2] = {0, 0};
+    auto prepare = [&]() -> int32_t {
+        if (arg_err != GOLAP_OK) return arg_err;
+        GOLAP_TRY(ensure_host_words(cm, 2 * (uint64_t)P * off_words * 4));
+        for (int side = 0; side < 2; ++side) {
+            pk_[side] = hold.take(std::max<uint64_t>(1, n_local[side]) * 8);
+            pr_[side] = hold.take(std::max<uint64_t>(1, n_local[side]) * 4);
+            offs_[side] = hold.take(off_words * 4);
+            offs_all_[side] = hold.take((uint64_t)P * off_words * 4);
+            if (!pk_[side] || !pr_[side] || !offs_[side] || !offs_all_[side]) return fail(ctx, GOLAP_ERR_OOM, "sharded join: partition buffers");
+        }
+        return GOLAP_OK;
+    };
+    GOLAP_TRY(shard_agree(ctx, cm, prepare()));
     for (int side = 0; side < 2; ++side) {
         // partition this rank's rows (exact layout: contiguous buckets, owner-major)
-        const uint64_t pk = hold.take(std::max<uint64_t>(1, n_local[side]) * 8), pr = hold.take(std::max<uint64_t>(1, n_local[side]) * 4);
-        const uint64_t offs = hold.take(off_words * 4), offs_all = hold.take((uint64_t)P * off_words * 4);
-        if (!pk || !pr || !offs || !offs_all) return GOLAP_ERR_OOM;
+        const uint64_t pk = pk_[side], pr = pr_[side], offs = offs_[side], offs_all = offs_all_[side];
         golap_partition_params pp;
         memset(&pp, 0, sizeof pp);
         pp.key_ptr = keys_in[side];
@@ -485,8 +683,8 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
         pp.out_offsets_ptr = offs;
         GOLAP_TRY(radix_partition_impl(ctx, &pp, st));
         // bucket sizes of every rank: device all-gather, then the one read-back this side needs
-        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side], st));
-        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side], 0));
+        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side][0], st));
+        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side][0], 0));
         GOLAP_TRY(comm_all_gather(cm, offs, offs_all, off_words * 4, cm->stream));
         uint32_t* h = cm->h_status + (uint64_t)side * P * off_words;
         GOLAP_HIP_TRY(ctx, hipMemcpyAsync(h, (const void*)offs_all, (size_t)P * off_words * 4, hipMemcpyDeviceToHost, cm->stream));
@@ -502,7 +700,7 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
         }
         recv_keys[side] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 8);
         recv_rids[side] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 4);
-        if (!recv_keys[side] || !recv_rids[side]) return GOLAP_ERR_OOM;
+        GOLAP_TRY(shard_agree(ctx, cm, recv_keys[side] && recv_rids[side] ? GOLAP_OK : fail(ctx, GOLAP_ERR_OOM, "sharded join: receive buffers")));
         seg_off[side].assign((size_t)per * P, 0);
         seg_len[side].assign((size_t)per * P, 0);
         for (uint32_t r = 0; r < P; ++r) {
@@ -554,9 +752,10 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
         rc = part_side(ctx, side, &sd, st);
     }
     if (rc == GOLAP_OK) rc = part_finish(ctx, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, st, p->join_type);
-    if (rc != GOLAP_OK) { part_abort(ctx); (void)hipStreamSynchronize(cm->stream); return rc; }
+    if (rc != GOLAP_OK) { part_abort(ctx); return rc; }   // (`drain` empties both streams)
     // the slabs above go back to the pool at scope exit: every kernel that reads them must have finished
     GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
+    drain.armed = false;
     cm->info.host_syncs += 1;
     return GOLAP_OK;
 }
@@ -595,10 +794,14 @@ static int32_t comm_common(golap_ctx* ctx, int32_t world, int32_t rank, golap_co
     cm->rank = rank;
     hipError_t e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipEventCreateWithFlags(&cm->ev_part[i], hipEventDisableTiming);
+        for (int c = 0; c < golap_comm::MAX_CHUNKS && e == hipSuccess; ++c) e = hipEventCreateWithFlags(&cm->ev_part[i][c], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_xchg[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_misc, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_hdr, hipEventDisableTiming);
+    for (int i = 0; i < 2 * GOLAP_SHARD_STAGES + 1 && e == hipSuccess; ++i) e = hipEventCreate(&cm->ev_t[i]);
+    if (e == hipSuccess) e = hipMalloc((void**)&cm->d_agree, (16 + P2R_MAX_SRC) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&cm->h_agree, (16 + P2R_MAX_SRC) * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) { golap_comm_destroy(cm); return fail(ctx, GOLAP_ERR_HIP, "communicator setup failed: %s", hipGetErrorString(e)); }
     *made = cm;
     return GOLAP_OK;
@@ -640,10 +843,16 @@ void golap_comm_destroy(golap_comm* cm) {
         if (api) (void)api->CommDestroy(cm->nccl);
     }
     for (int i = 0; i < 2; ++i) {
-        if (cm->ev_part[i]) (void)hipEventDestroy(cm->ev_part[i]);
+        for (int c = 0; c < golap_comm::MAX_CHUNKS; ++c)
+            if (cm->ev_part[i][c]) (void)hipEventDestroy(cm->ev_part[i][c]);
         if (cm->ev_xchg[i]) (void)hipEventDestroy(cm->ev_xchg[i]);
     }
     if (cm->ev_misc) (void)hipEventDestroy(cm->ev_misc);
+    if (cm->ev_hdr) (void)hipEventDestroy(cm->ev_hdr);
+    for (int i = 0; i < 2 * GOLAP_SHARD_STAGES + 1; ++i)
+        if (cm->ev_t[i]) (void)hipEventDestroy(cm->ev_t[i]);
+    if (cm->d_agree) (void)hipFree(cm->d_agree);
+    if (cm->h_agree) (void)hipHostFree(cm->h_agree);
     if (cm->h_status) (void)hipHostFree(cm->h_status);
     if (cm->stream) (void)hipStreamDestroy(cm->stream);
     delete cm;
@@ -662,12 +871,17 @@ int32_t golap_sharded_plan_get(uint32_t world, uint64_t n_build_total, uint64_t 
     out->buckets_per_rank = sp.per;
     out->local_bits = sp.local_bits;
     out->sub_ranges = sp.nsub;
+    out->chunks = sp.K;
     const uint64_t mm = max_msg_bytes ? max_msg_bytes : SHARD_DEFAULT_MAX_MSG;
     for (int side = 0; side < 2; ++side)
         for (uint32_t r = 0; r < world; ++r) {
-            out->cap_rows[side][r] = sp.cap[side][r];
-            out->msg_bytes[side][r] = (uint64_t)sp.per * sp.nsub * sp.cap[side][r] * 8;
-            out->msg_pieces[side][r] = (uint32_t)ceil_div(out->msg_bytes[side][r], mm);
+            out->cap_rows[side][r] = sp.cap[side][(size_t)r * sp.K];
+            out->cap_rows_last[side][r] = sp.cap[side][(size_t)r * sp.K + sp.K - 1];
+            for (uint32_t c = 0; c < sp.K; ++c) {
+                const uint64_t b = (uint64_t)sp.per * sp.nsub * sp.cap[side][(size_t)r * sp.K + c] * 8;
+                out->msg_bytes[side][r] += b;
+                out->msg_pieces[side][r] += (uint32_t)ceil_div(b, mm);
+            }
         }
     return GOLAP_OK;
 }
@@ -723,33 +937,45 @@ int32_t golap_sharded_join_info_get(golap_comm* cm, golap_sharded_join_info* out
 int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, void* stream) {
     if (!ctx || !cm || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (cm->ctx != ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "communicator belongs to another context");
-    if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
-    if (p->max_pairs && !p->out_pairs_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_pairs_ptr is null but max_pairs > 0");
-    if ((p->n_build_local && !p->build_key_ptr) || (p->n_probe_local && !p->probe_key_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null key column");
-    if (p->join_type < 0 || p->join_type > 3) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad join_type %d", p->join_type);
-    if (p->n_build_total >= 0xFFFFFFF0ull || p->n_probe_total >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "global row ids are u32");
-    if ((uint64_t)p->build_rid_base + p->n_build_local > 0xFFFFFFFFull || (uint64_t)p->probe_rid_base + p->n_probe_local > 0xFFFFFFFFull)
-        return fail(ctx, GOLAP_ERR_UNSUPPORTED, "rid_base + rows exceeds the u32 row-id range");
     std::lock_guard<std::mutex> lk(ctx->mu);
     KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     memset(&cm->info, 0, sizeof cm->info);
+    // The call is collective: an argument error on ONE rank must not leave the others waiting in the exchange.  It becomes this
+    // rank's agreement word (shard_agree): every rank leaves the call together, this one with its error, the others with
+    // GOLAP_ERR_PEER.  (The plan below only reads the totals and row-count lists, which every rank passes identically.)
+    auto check_args = [&]() -> int32_t {
+        if (!p->out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+        if (p->max_pairs && !p->out_pairs_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_pairs_ptr is null but max_pairs > 0");
+        if ((p->n_build_local && !p->build_key_ptr) || (p->n_probe_local && !p->probe_key_ptr)) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null key column");
+        if (p->join_type < 0 || p->join_type > 3) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad join_type %d", p->join_type);
+        if (p->n_build_total >= 0xFFFFFFF0ull || p->n_probe_total >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "global row ids are u32");
+        if ((uint64_t)p->build_rid_base + p->n_build_local > 0xFFFFFFFFull || (uint64_t)p->probe_rid_base + p->n_probe_local > 0xFFFFFFFFull)
+            return fail(ctx, GOLAP_ERR_UNSUPPORTED, "rid_base + rows exceeds the u32 row-id range");
+        return GOLAP_OK;
+    };
+    const int32_t arg_err = check_args();
     ShardPlan sp;
     make_shard_plan((uint32_t)cm->world, p->n_build_total, p->n_probe_total, p->build_rows_per_rank, p->probe_rows_per_rank, sp);
     cm->info.extra_bits = sp.e1;
     cm->info.n_groups = sp.per;
     cm->info.local_bits = sp.local_bits;
-    GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
+    if (arg_err == GOLAP_OK) GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
     if (sp.eligible && !p->force_exact) {
         bool failed = false;
-        GOLAP_TRY(sharded_join_fast(ctx, cm, p, sp, st, &failed));
+        GOLAP_TRY(sharded_join_fast(ctx, cm, p, sp, st, &failed, arg_err));
         if (!failed) { cm->info.fast_path = 1; return GOLAP_OK; }
+        const uint32_t syncs = cm->info.host_syncs;
+        memset(&cm->info, 0, sizeof cm->info);
+        cm->info.extra_bits = sp.e1;
+        cm->info.n_groups = sp.per;
+        cm->info.local_bits = sp.local_bits;
+        cm->info.host_syncs = syncs;
         cm->info.fast_path_abandoned = 1;
-        cm->info.bytes_sent[0] = cm->info.bytes_sent[1] = 0;
         GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
     }
-    return sharded_join_exact(ctx, cm, p, sp, st);
+    return sharded_join_exact(ctx, cm, p, sp, st, arg_err);
 }
 
 }  // extern "C"

@@ -432,8 +432,9 @@ def sharded_plan(world, n_build_total, n_probe_total=None, max_msg_bytes=0):
     N.check(None, N.load().golap_sharded_plan_get(world, n_build_total, n_build_total if n_probe_total is None else n_probe_total,
                                                   None, None, max_msg_bytes, C.byref(pl)))
     return {"eligible": bool(pl.eligible), "extra_bits": pl.extra_bits, "n_buckets": pl.n_buckets, "buckets_per_rank": pl.buckets_per_rank,
-            "local_bits": pl.local_bits, "sub_ranges": pl.sub_ranges,
+            "local_bits": pl.local_bits, "sub_ranges": pl.sub_ranges, "chunks": pl.chunks,
             "cap_rows": [[pl.cap_rows[s][r] for r in range(world)] for s in range(2)],
+            "cap_rows_last": [[pl.cap_rows_last[s][r] for r in range(world)] for s in range(2)],
             "msg_bytes": [[pl.msg_bytes[s][r] for r in range(world)] for s in range(2)],
             "msg_pieces": [[pl.msg_pieces[s][r] for r in range(world)] for s in range(2)]}
 
@@ -500,4 +501,7 @@ class Comm:
         self.ctx._ck(self.ctx._lib.golap_sharded_join_info_get(self._h, C.byref(i)))
         return {"fast_path": bool(i.fast_path), "fast_path_abandoned": bool(i.fast_path_abandoned), "extra_bits": i.extra_bits,
                 "n_groups": i.n_groups, "local_bits": i.local_bits, "host_syncs": i.host_syncs,
-                "rows_received": list(i.rows_received), "bytes_sent": list(i.bytes_sent)}
+                "rows_received": list(i.rows_received), "bytes_sent": list(i.bytes_sent), "chunks": i.chunks, "sub_ranges": i.sub_ranges,
+                # device timestamps of the fast path's stages, ms since the call's first kernel: [begin, end] (profiling contexts only)
+                "stage_ms": {nm: [round(i.stage_ms[k][0], 4), round(i.stage_ms[k][1], 4)] for k, nm in enumerate(N.SHARD_STAGES)},
+                "total_ms": round(i.total_ms, 4)}

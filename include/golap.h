@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GOLAP_ABI_VERSION 2
+#define GOLAP_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -39,7 +39,8 @@ enum {
     GOLAP_ERR_HIP = 3,
     GOLAP_ERR_OOM = 4,          /* slab class exhausted / size above largest class */
     GOLAP_ERR_UNSUPPORTED = 5,  /* e.g. SortMergeJoin: out of scope */
-    GOLAP_ERR_CAPACITY = 6      /* informational: join produced more pairs than max_pairs */
+    GOLAP_ERR_CAPACITY = 6,     /* informational: join produced more pairs than max_pairs */
+    GOLAP_ERR_PEER = 7          /* collective call: ANOTHER rank failed before the exchange; every rank has left the call together */
 };
 
 typedef struct golap_ctx golap_ctx;
@@ -309,9 +310,14 @@ int32_t golap_join_partitioned_abort(golap_ctx* ctx);
  * golap_sharded_join is collective: every rank of the communicator calls it with the same totals.  Fast path (large
  * joins whose keys all lie in [0, 2^32)): no histogram and no size exchange -- every bucket owns a fixed, provisioned
  * range, messages have sizes both ends can compute, the per-bucket row counts travel device-to-device (all-gather) and
- * only reach the kernels; ONE host synchronisation per join (the status word at the end).  Anything else (a key outside
+ * only reach the kernels; the host synchronises twice per join: on the agreement word (did every rank get through its argument
+ * checks and allocations? -- read while the first partition kernel runs) and on the status words at the end.  A rank's rows are
+ * partitioned and shipped in chunks, so the exchange runs beside the partition pass from the first chunk on.  Anything else (a key outside
  * [0, 2^32), a skewed bucket, small inputs) takes the exact path: histogram partition, size all-gather read back by the
- * host, variable-size exchange, segment-fed local passes.  All ranks take the same path (the status word is gathered). */
+ * host, variable-size exchange, segment-fed local passes.  All ranks take the same path (the status word is gathered).
+ * Failures: whatever can fail on the host before the exchange (arguments, plan, workspace) is agreed on first -- if any rank
+ * failed, the failing rank returns its error and every other rank GOLAP_ERR_PEER, nobody waits in a collective.  A HIP error in
+ * the middle of the exchange is as fatal as it is for any RCCL program (peers block until the communicator is destroyed). */
 typedef struct golap_comm golap_comm;
 typedef struct golap_p2p_op {
     int32_t  peer;       /* rank in the communicator */
@@ -344,13 +350,23 @@ typedef struct golap_sharded_join_params {
     int32_t  force_exact;                        /* != 0: skip the fast path */
     uint64_t max_msg_bytes;                      /* 0 = 512 MiB: larger messages are split (both ends compute the same pieces); the built-in RCCL transport caps it at 1 GiB */
 } golap_sharded_join_params;
+/* Stages of the fast path, timed on the device when the context has profiling on (begin and end in ms since the call's first
+ * kernel; events on the compute stream and on the communicator's stream): what a scaling line needs to say where the time went. */
+enum { GOLAP_SHARD_ST_PART_BUILD = 0, GOLAP_SHARD_ST_PART_PROBE = 1, GOLAP_SHARD_ST_XCHG_BUILD = 2, GOLAP_SHARD_ST_XCHG_PROBE = 3,
+       GOLAP_SHARD_ST_RING_BUILD = 4, GOLAP_SHARD_ST_RING_PROBE = 5, GOLAP_SHARD_ST_JOIN = 6, GOLAP_SHARD_ST_STATUS = 7, GOLAP_SHARD_STAGES = 8 };
 typedef struct golap_sharded_join_info {          /* what the last golap_sharded_join on this communicator did */
     uint32_t fast_path;          /* 1: the no-histogram tuple path produced the result */
     uint32_t fast_path_abandoned;/* 1: it was tried and its status word sent every rank to the exact path */
     uint32_t extra_bits, n_groups, local_bits;
-    uint32_t host_syncs;         /* host synchronisations inside the call */
+    uint32_t host_syncs;         /* host synchronisations inside the call (fast path: the agreement word, hidden behind the first partition
+                                  * kernel, and the status words at the end) */
     uint64_t rows_received[2];   /* build, probe (exact path; fast path: provisioned rows) */
     uint64_t bytes_sent[2];
+    uint32_t chunks;             /* fast path: row chunks per side; chunk k's messages travel while chunk k + 1 is partitioned */
+    uint32_t sub_ranges;         /* fast path: per-XCD sub-ranges per bucket */
+    float    stage_ms[GOLAP_SHARD_STAGES][2];   /* [stage][begin, end]; zeros without profiling or on the exact path */
+    float    total_ms;           /* first kernel -> status words on the host's side of the last copy */
+    uint32_t reserved0;
 } golap_sharded_join_info;
 int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* comm, const golap_sharded_join_params* params, void* stream);
 int32_t golap_sharded_join_info_get(golap_comm* comm, golap_sharded_join_info* out);
@@ -366,10 +382,11 @@ typedef struct golap_sharded_plan {
     uint32_t eligible;           /* 1: the fast path applies to these sizes */
     uint32_t extra_bits, n_buckets, buckets_per_rank, local_bits;
     uint32_t sub_ranges;         /* every bucket is sub_ranges ranges of cap_rows rows (one per XCD of the partitioning GPU) */
-    uint32_t reserved0;
-    uint64_t cap_rows[2][64];    /* [side][source rank] rows provisioned per bucket sub-range */
-    uint64_t msg_bytes[2][64];   /* [side][source rank] bytes every peer receives from that rank */
-    uint32_t msg_pieces[2][64];  /* pieces that message is split into (max_msg_bytes) */
+    uint32_t chunks;             /* row chunks per side: a rank partitions and ships its rows in `chunks` pieces (all but the last equally long) */
+    uint64_t cap_rows[2][64];    /* [side][source rank] rows provisioned per bucket sub-range of chunks 0 .. chunks - 2 */
+    uint64_t cap_rows_last[2][64];   /* the same for the last chunk (the remainder) */
+    uint64_t msg_bytes[2][64];   /* [side][source rank] bytes every peer receives from that rank (all chunks) */
+    uint32_t msg_pieces[2][64];  /* messages that makes (chunks, each split at max_msg_bytes) */
 } golap_sharded_plan;
 int32_t golap_sharded_plan_get(uint32_t world, uint64_t n_build_total, uint64_t n_probe_total, const uint64_t* build_rows_per_rank,
                                const uint64_t* probe_rows_per_rank, uint64_t max_msg_bytes, golap_sharded_plan* out);

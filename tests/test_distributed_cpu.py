@@ -274,11 +274,18 @@ def test_sharded_plan_is_the_same_on_every_rank(world, n, max_msg):
         for side in range(2):
             for s in range(world):
                 rows = box[s]["rows"]
-                cap, nb, ns = ref["cap_rows"][side][s], ref["n_buckets"], ref["sub_ranges"]
-                avg = -(-rows // (nb * ns))
-                assert cap % 16 == 0 and cap >= avg + 6 * int(avg ** 0.5)          # provisioned sub-range: mean + 6 sigma (Poisson), line aligned
-                assert ref["msg_bytes"][side][s] == ref["buckets_per_rank"] * ns * cap * 8
-                assert (ref["msg_pieces"][side][s] - 1) * mm < ref["msg_bytes"][side][s] <= ref["msg_pieces"][side][s] * mm
+                cap, cap_last, nb, ns, K = ref["cap_rows"][side][s], ref["cap_rows_last"][side][s], ref["n_buckets"], ref["sub_ranges"], ref["chunks"]
+                assert K == 4 and world * K * ns <= 128                              # with peers a side is partitioned and shipped in 4 row chunks
+                tile = 18 * 1024                                                      # chunks 0 .. K-2 are whole first-pass tiles, the last takes the rest
+                chunk = -(-(-(-rows // K)) // tile) * tile
+                last = rows - (K - 1) * chunk
+                assert 0 < last <= chunk
+                for c_rows, c_cap in ((chunk, cap), (last, cap_last)):
+                    avg = -(-c_rows // (nb * ns))
+                    assert c_cap % 16 == 0 and c_cap >= avg + 6 * int(avg ** 0.5)   # provisioned sub-range: mean + 6 sigma (Poisson), line aligned
+                assert ref["msg_bytes"][side][s] == ref["buckets_per_rank"] * ns * ((K - 1) * cap + cap_last) * 8
+                per_chunk = [ref["buckets_per_rank"] * ns * c * 8 for c in [cap] * (K - 1) + [cap_last]]
+                assert ref["msg_pieces"][side][s] == sum(-(-b // mm) for b in per_chunk)   # every chunk's message is split on its own
 
 
 def test_sharded_plan_small_inputs_take_the_exact_path():

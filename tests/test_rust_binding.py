@@ -8,7 +8,8 @@ HDR = open(os.path.join(ROOT, "include", "golap.h")).read()
 RS = open(os.path.join(ROOT, "bindings", "rust", "golap-hip-sys", "src", "lib.rs")).read()
 
 C2R = {"uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "void*": "*mut c_void",
-       "const uint64_t*": "*const u64", "const int32_t*": "*const i32"}
+       "const uint64_t*": "*const u64", "const int32_t*": "*const i32", "float": "f32", "double": "f64"}
+CONSTS = {"GOLAP_SHARD_STAGES": "8"}
 
 
 def c_struct(name):
@@ -25,8 +26,13 @@ def c_struct(name):
         ty, names = decl.rsplit(" ", 1)[0], decl.rsplit(" ", 1)[1]
         for nm in [n.strip() for n in (ty.split(" ", 1)[1] + " " + names if "," in decl else names).split(",")] if "," in decl else [names]:
             base = ty.split(" ")[0] if "," in decl else ty
+            for cname, cval in CONSTS.items():
+                nm = nm.replace(cname, cval)
+            arr2 = re.match(r"(\w+)\[(\d+)\]\[(\d+)\]", nm)
             arr = re.match(r"(\w+)\[(\d+)\]", nm)
-            if arr:
+            if arr2:
+                fields.append((arr2.group(1), f"[[{C2R[base]}; {arr2.group(3)}]; {arr2.group(2)}]"))
+            elif arr:
                 fields.append((arr.group(1), f"[{C2R[base]}; {arr.group(2)}]"))
             else:
                 fields.append((nm, C2R.get(base, base)))
@@ -43,8 +49,12 @@ def rs_struct(name):
 
 
 def test_structs_match_the_header():
-    for s in ["golap_engine_config", "golap_filter_predicate", "golap_filter_params", "golap_join_params", "golap_aggregate_spec",
-              "golap_aggregate_params", "golap_p2p_op", "golap_transport", "golap_sharded_join_params"]:
+    # every #[repr(C)] struct with fields that lib.rs declares (discovered, not listed), field by field
+    names = [n for n in re.findall(r"#\[repr\(C\)\]\n(?:#\[derive[^\n]*\]\n)?pub struct (golap_\w+) \{", RS) if n not in ("golap_ctx", "golap_comm")]
+    for must in ["golap_engine_config", "golap_join_params", "golap_aggregate_params", "golap_sharded_join_params", "golap_sharded_join_info",
+                 "golap_sharded_plan", "golap_join_partitioned_plan", "golap_partition_params"]:
+        assert must in names, must
+    for s in names:
         assert rs_struct(s) == c_struct(s), s
 
 

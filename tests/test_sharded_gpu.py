@@ -104,7 +104,7 @@ def test_sharded_join_ranks_share_one_gpu(world, variant, mode):
     assert got.shape[0] == me and np.array_equal(got, exp)
     for _, _, info in res:
         assert info["fast_path"] == (mode == "fast") and not info["fast_path_abandoned"]
-        assert info["host_syncs"] == (1 if mode == "fast" else 3)
+        assert info["host_syncs"] == (2 if mode == "fast" else 6)   # fast: agreement word + status words; exact: 3 agreement rounds, 2 size read-backs, the end
 
 
 def _worker_big(rank, world, port, n, q):
@@ -161,7 +161,7 @@ def test_sharded_fast_path_at_its_natural_size(world, n):
     assert sum(r[2] for r in res) == n * (n - 1) // 2
     assert all(r[3] for r in res)
     for r in res:
-        assert r[4]["fast_path"] and r[4]["host_syncs"] == 1 and not r[4]["fast_path_abandoned"]
+        assert r[4]["fast_path"] and r[4]["host_syncs"] == 2 and not r[4]["fast_path_abandoned"]
 
 
 def test_sharded_join_one_wide_key_sends_every_rank_to_the_exact_path():
@@ -313,3 +313,67 @@ def test_rccl_message_size_boundary():
         f.write(repr(res) + "\n")
     assert res[0][1] == 0, "a 512 MiB message (the default max_msg_bytes) must arrive intact"
     assert res[1][1] == 0, "1 GiB has arrived intact on every box so far: the default keeps a factor of two below it"
+
+
+def _worker_err(rank, world, port, n, mode, bad_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if mode == "fast":
+        os.environ["GOLAP_DEBUG_ENV"] = "1"
+        os.environ["GOLAP_SHARD_FAST"] = "1"
+        os.environ["GOLAP_LOCAL_BITS"] = "6"
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from gpu_olap_engine_amd import _native as N
+        from gpu_olap_engine_amd.distributed import NativeShardedJoin
+        from gpu_olap_engine_amd.engine import Context, shard_range
+        torch.cuda.set_device(0)
+        c = Context(max_gpu_memory=0)
+        lo, hi = shard_range(n, rank, world)
+        b, p = _keys("unique", n, lo, hi - lo)
+        sj = NativeShardedJoin(c, transport="staged")
+        out = torch.empty((2 * n, 2), dtype=torch.int32, device="cuda")
+        bt, pt = torch.from_numpy(b).cuda(), torch.from_numpy(p).cuda()
+        code, msg = 0, ""
+        try:   # ONE rank passes a bad argument; the call is collective
+            sj.join(bt, pt, lo, lo, n, out_pairs=out, join_type=(9 if rank == bad_rank else 0), force_exact=(mode == "exact"))
+        except N.GolapError as e:
+            code, msg = e.code, e.message
+        # ... and the communicator is still usable: the same join with good arguments on every rank
+        pairs, cnt, info = sj.join(bt, pt, lo, lo, n, out_pairs=out, force_exact=(mode == "exact"))
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        q.put((rank, code, msg, pairs[:m].cpu().numpy().view(np.uint32).copy()))
+        dist.barrier()
+        sj.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_a_failing_rank_takes_every_rank_out_of_the_call(mode):
+    """golap_sharded_join is collective: a rank that fails on the host before the exchange (here: a bad argument on rank 1 of 2) must not
+    leave its peers waiting in ncclSend/ncclRecv.  Every rank returns -- the failing one with its own error, the other with
+    GOLAP_ERR_PEER naming the rank -- and the next call on the same communicator works."""
+    import torch.multiprocessing as mp
+    from gpu_olap_engine_amd import _native as N
+    from np_twin import canonical
+    world, n = 2, 2_000_000
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_err, args=(r, world, port, n, mode, 1, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert res[1][1] == N.ERR_INVALID_ARG and "join_type" in res[1][2]
+    assert res[0][1] == N.ERR_PEER and "rank 1" in res[0][2]
+    exp, me = _expected(n, "unique", 0, world, -1)
+    got = canonical(np.concatenate([r[3] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
