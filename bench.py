@@ -11,8 +11,8 @@ exchange over xGMI when N > 1,] LDS build/probe, pair output).  value = rows of 
 step; join scaling is "strong" (the 1B x 1B table pair is fixed, N GPUs share it).  Rank 0 prints ONE JSON line.
 
 The default C5 run also times the same join with keys outside [0, 2^32) (`wide_keys` in the line): both key columns + 2^40
-(all keys share one upper half: still 8-byte tuples, frame of reference) and with two different upper halves (the
-64-bit-row pipeline).  BASELINE's own generators emit keys below 2^32.
+(all keys share one upper half: still 8-byte tuples, frame of reference), with two different upper halves (8-byte tuples with a
+dictionary index) and with 2^17 upper halves (the 64-bit-row pipeline).  BASELINE's own generators emit keys below 2^32.
 """
 import argparse
 import hashlib
@@ -289,7 +289,12 @@ def bench_join(args, n_total, label):
         wk = leg("offset_2p40", "the same generators + 2^40 on both key columns: every key outside [0, 2^32), one common upper half")
         bkeys += (bkeys & 1) << 41
         pkeys += (pkeys & 1) << 41
-        wk["two_upper_halves"] = leg("two_upper_halves", "as above, odd keys moved by another 2^41: two upper halves -> the 64-bit-row pipeline")
+        wk["two_upper_halves"] = leg("two_upper_halves", "as above, odd keys moved by another 2^41: two upper halves -> still 8-byte tuples, a dictionary "
+                                     "index of the upper half rides in the tuple (up to 4 upper halves; round 2 sent these to the 64-bit-row pipeline)")
+        bkeys += ((bkeys * 0x9E3779B1) & 0xFFFF) << 44
+        pkeys += ((pkeys * 0x9E3779B1) & 0xFFFF) << 44
+        wk["random_upper_halves"] = leg("random_upper_halves", "as above + a key-dependent 16-bit field at bit 44: 2^17 upper halves (hashed / snowflake-like "
+                                        "ids) -> the 64-bit-row pipeline (12-byte rows, 120 GB of traffic for the 88 GB credited)")
         line["wide_keys"] = wk
     # C3 is timed at its full size on the CPU too (the reference's own CPU-runnable scale); C5 on a bounded 16M x 16M sample
     sample = args.cpu_sample if args.cpu_sample >= 0 else (n_total if label == "C3" else 16_000_000)

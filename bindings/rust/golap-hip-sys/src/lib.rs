@@ -269,6 +269,8 @@ extern "C" {
                                 out_count_ptr: u64, stream: *mut c_void) -> i32;
     pub fn golap_filter_compact_nullable(ctx: *mut golap_ctx, pred: *const golap_filter_predicate, column_ptr: u64, validity_ptr: u64, n_rows: u64,
                                          out_indices_ptr: u64, out_count_ptr: u64, stream: *mut c_void) -> i32;
+    pub fn golap_filter_compact_and(ctx: *mut golap_ctx, preds: *const golap_filter_predicate, column_ptrs: *const u64, validity_ptrs: *const u64,
+                                    n_preds: u32, n_rows: u64, out_indices_ptr: u64, out_count_ptr: u64, stream: *mut c_void) -> i32;
     pub fn golap_take_8byte(ctx: *mut golap_ctx, column_ptr: u64, indices_ptr: u64, count_ptr: u64, n_indices_max: u64, out_ptr: u64,
                             stream: *mut c_void) -> i32;
     pub fn golap_filter_sum(ctx: *mut golap_ctx, pred: *const golap_filter_predicate, key_column_ptr: u64, value_column_ptr: u64, value_is_f64: i32,
@@ -289,6 +291,8 @@ extern "C" {
     pub fn golap_comm_create_custom(ctx: *mut golap_ctx, transport: *const golap_transport, world: i32, rank: i32, out: *mut *mut golap_comm) -> i32;
     pub fn golap_comm_destroy(comm: *mut golap_comm);
     pub fn golap_sharded_join(ctx: *mut golap_ctx, comm: *mut golap_comm, params: *const golap_sharded_join_params, stream: *mut c_void) -> i32;
+    pub fn golap_sharded_aggregate(ctx: *mut golap_ctx, comm: *mut golap_comm, specs: *const golap_aggregate_spec, n_specs: u32,
+                                   params: *const golap_aggregate_params, stream: *mut c_void) -> i32;
     pub fn golap_sharded_join_info_get(comm: *mut golap_comm, out: *mut golap_sharded_join_info) -> i32;
     pub fn golap_sharded_plan_get(world: u32, n_build_total: u64, n_probe_total: u64, build_rows_per_rank: *const u64, probe_rows_per_rank: *const u64,
                                   max_msg_bytes: u64, out: *mut golap_sharded_plan) -> i32;

@@ -184,6 +184,7 @@ SIGNATURES = {
     "golap_filter_launch": (C.c_int32, [_VP, _P(FilterPredicate), _P(FilterParams), _VP]),
     "golap_filter_compact": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_filter_compact_nullable": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_filter_compact_and": (C.c_int32, [_VP, _P(FilterPredicate), _P(C.c_uint64), _P(C.c_uint64), C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_filter_sum_nullable": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, _VP]),
     "golap_take_8byte": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_filter_sum": (C.c_int32, [_VP, _P(FilterPredicate), C.c_uint64, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, _VP]),
@@ -208,6 +209,7 @@ SIGNATURES = {
     "golap_sharded_plan_get": (C.c_int32, [C.c_uint32, C.c_uint64, C.c_uint64, _P(C.c_uint64), _P(C.c_uint64), C.c_uint64, _P(ShardedPlan)]),
     "golap_agg_identity_value": (C.c_int64, [C.c_int32]),
     "golap_aggregate": (C.c_int32, [_VP, _P(AggregateSpec), C.c_uint32, _P(AggregateParams), _VP]),
+    "golap_sharded_aggregate": (C.c_int32, [_VP, _VP, _P(AggregateSpec), C.c_uint32, _P(AggregateParams), _VP]),
     "golap_widen_to_8byte": (C.c_int32, [_VP, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_generate": (C.c_int32, [_VP, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_verify_pairs": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _VP]),

@@ -125,8 +125,15 @@ struct PassCfg {
     const uint32_t* key_hi;   // tuple kernels only, may be null (= 0): the upper 32 bits every key of this join shares.  The tuples carry
                               // the LOWER 32 bits; hash_int64(key) = hash_int32(lo ^ hi) (join_kernels.cuh:37-41), so the partitions stay the
                               // reference's for any common upper half -- not just 0.
+                              // Layout: key_hi[0 .. 3] = the DICTIONARY of upper halves (k_key_dict; unused entries repeat entry 0),
+                              // key_hi[4] = D, the number of distinct ones found (1 .. 4).  D == 1: as above.  D > 1 (e.g. small negative AND
+                              // small positive keys: 0xFFFFFFFF and 0): the tuples' first word is (hash >> b1) | (dictionary index << (32 - b1)),
+                              // b1 = hash bits the first pass consumed -- those bits are implied by the bucket from then on, so equality of
+                              // the word inside a sub-partition is still equality of the 64-bit key, and the rows stay 8 bytes.
 };
+constexpr uint32_t KEY_DICT_MAX = 4;
 __device__ __forceinline__ uint32_t key_hi_of(const PassCfg& c) { return c.key_hi ? *c.key_hi : 0u; }
+__device__ __forceinline__ bool key_dict_mode(const PassCfg& c) { return c.key_hi && c.key_hi[KEY_DICT_MAX] > 1u; }
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t h, const PassCfg& c) {
     if (c.mode == 0) return (h >> c.shift) & (c.F - 1u);

@@ -236,8 +236,9 @@ int32_t aux_begin(golap_ctx* ctx, uint64_t bytes, hipStream_t st);   // same thr
 uint64_t aux_take(golap_ctx* ctx, uint64_t bytes);
 void aux_end(golap_ctx* ctx, hipStream_t st);
 
-// in-place exclusive scan of n u32 values (n <= 16.7M); block_sums needs ceil(n/4096)+1 u32 (golap_join.hip)
+// in-place exclusive scan of n u32 values; block_sums needs flat_scan_scratch_words(n) u32 (= ceil(n/4096)+1 while n <= 16.7M) (golap_join.hip)
 int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if = nullptr);
+uint64_t flat_scan_scratch_words(uint64_t n);
 constexpr uint32_t FLAT_SCAN_BLOCK = 4096;
 
 // Zero-fill by a kernel, not hipMemsetAsync: a captured memset node was observed to write garbage on its first

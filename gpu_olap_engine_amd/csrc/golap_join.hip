@@ -638,8 +638,10 @@ __device__ __forceinline__ uint32_t isqrt_u32(uint32_t x) {
 // (sigmas, pad), so this is a guard, not a path that is expected to run.
 __global__ __launch_bounds__(1024) void k_slots_setup(GroupSrc gs, uint32_t G, uint32_t F, uint32_t sigmas,
                                                       uint32_t pad, uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap,
-                                                      unsigned long long limit_rows, uint32_t* __restrict__ overflow) {
+                                                      unsigned long long limit_rows, uint32_t* __restrict__ overflow,
+                                                      const uint32_t* __restrict__ key_dict = nullptr, uint32_t dict_mul = 1) {
     __shared__ uint32_t s_w[16];
+    if (key_dict && key_dict[KEY_DICT_MAX] > 1u) sigmas *= dict_mul;   // several upper key halves: wider slots (reserve_cap's comment)
     const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
     uint32_t total = 0;
     if (g < G) {
@@ -1539,11 +1541,16 @@ static uint32_t isqrt_host(uint64_t x) {
 }
 
 // rows provisioned per first-pass bucket when the first pass reserves its output by atomics (k_scatter_big<.., RESERVE>)
-static uint64_t reserve_cap(uint64_t n_rows, uint32_t F) {
+// sig_mul: DICT_SIGMA_MUL for the tuple pipeline's layouts.  hash_int64 folds the key halves (join_kernels.cuh:37-41), so in a column
+// with D upper halves up to D keys share EVERY hash bit (k and -k-1 in a column of small negative and positive ids): bucket sizes
+// are then sums of weight-D items and their standard deviation grows by sqrt(D) <= 2 (KEY_DICT_MAX = 4).  The layouts that may
+// hold such a column are provisioned for it: +1 % on the first pass's ranges, +9 % on the final buffers.
+constexpr uint32_t DICT_SIGMA_MUL = 2;
+static uint64_t reserve_cap(uint64_t n_rows, uint32_t F, uint32_t sig_mul = 1) {
     uint32_t sigmas, pad;
     provision_of("GOLAP_RESERVE_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
     const uint64_t avg = ceil_div(std::max<uint64_t>(n_rows, 1), F);
-    return round_up(avg + (uint64_t)sigmas * isqrt_host(avg) + pad, 16);
+    return round_up(avg + (uint64_t)sigmas * sig_mul * isqrt_host(avg) + pad, 16);
 }
 
 // Sub-ranges per first-pass bucket in the narrow pipeline (ReserveArgs::nsub): one per XCD.  GOLAP_NSUB: A/B hook.
@@ -1559,10 +1566,10 @@ static uint32_t wide_nsub() {
     return v >= 1 && v <= 8 ? v : 8u;
 }
 // rows provisioned per (bucket, sub-range): the sub-range of work-groups b = s (mod nsub) receives at most ceil(chunks / nsub) chunks
-static uint64_t reserve_cap_sub(uint64_t n_rows, uint32_t F, uint32_t nsub, uint32_t n_chunks, uint32_t chunk_rows) {
-    if (nsub <= 1) return reserve_cap(n_rows, F);
+static uint64_t reserve_cap_sub(uint64_t n_rows, uint32_t F, uint32_t nsub, uint32_t n_chunks, uint32_t chunk_rows, uint32_t sig_mul = 1) {
+    if (nsub <= 1) return reserve_cap(n_rows, F, sig_mul);
     const uint64_t n_s = std::min<uint64_t>(std::max<uint64_t>(n_rows, 1), ceil_div(n_chunks, nsub) * (uint64_t)chunk_rows);
-    return reserve_cap(n_s, F);
+    return reserve_cap(n_s, F, sig_mul);
 }
 
 // No-histogram FIRST pass: single-source global pass of a two-pass plan whose second pass is the no-histogram one,
@@ -1597,7 +1604,7 @@ static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
     const uint32_t wnc = first_pass_chunks(n, &wchunk);
     const uint64_t wide_rows = reserve_cap_sub(n, F, wide_nsub(), wnc, wchunk) * F * wide_nsub();   // the 64-bit pipeline's own chunking
     return std::max<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(n, reserve_cap(n, F) * F), wide_rows),
-                              reserve_cap_sub(n, F, nsub, nc, chunk_rows) * F * nsub);   // (narrow tuples: 8 B per row as well)
+                              reserve_cap_sub(n, F, nsub, nc, chunk_rows, DICT_SIGMA_MUL) * F * nsub);   // (narrow tuples: 8 B per row as well)
 }
 
 // rows the final buffers of one side must hold when the last pass writes into provisioned slots (k_slots_setup: every slot is
@@ -1607,6 +1614,7 @@ static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
 static uint64_t slot_rows_bound(uint64_t n, double FG) {
     uint32_t sigmas, pad;
     provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);
+    sigmas *= DICT_SIGMA_MUL;   // (k_slots_setup widens the slots by this factor when the key column has several upper halves: see reserve_cap)
     return n + (uint64_t)((double)sigmas * (std::sqrt(FG * (double)std::max<uint64_t>(n, 1)) + FG)) + (uint64_t)(((double)pad + 24.0) * FG) + 4096;
 }
 static uint64_t final_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
@@ -1705,14 +1713,29 @@ static void launch_pass_kernel(int tag, bool hist, bool wc, uint32_t n_chunks, h
     }
 }
 
-int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if) {
+// block_sums: ceil(n / 4096) + 1 words while n <= 4096 * 4096 (every caller but the hashed GROUP BY); beyond that the block sums are
+// scanned by a nested call whose own block sums sit behind them: flat_scan_scratch_words(n) words in all.
+uint64_t flat_scan_scratch_words(uint64_t n) {
+    uint64_t words = 0;
+    for (uint64_t m = n; ; ) {
+        const uint64_t nb = ceil_div(std::max<uint64_t>(m, 1), SC_ELEMS);
+        words += nb + 1;
+        if (nb <= (uint64_t)SC_ELEMS) break;
+        m = nb;
+    }
+    return words;
+}
+static int32_t flat_scan_level(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if) {
     const uint32_t n_blocks = (uint32_t)ceil_div(n, SC_ELEMS);
-    if (n_blocks > (uint32_t)SC_ELEMS) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "scan of %u elements exceeds the 2-level limit", n);
-    KernelTimer t(ctx, "scan_offsets", st);
     hipLaunchKernelGGL(k_scan_reduce, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums, run_if);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SC_THREADS), 0, st, block_sums, n_blocks, run_if);
+    if (n_blocks <= (uint32_t)SC_ELEMS) hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SC_THREADS), 0, st, block_sums, n_blocks, run_if);
+    else GOLAP_TRY(flat_scan_level(ctx, st, block_sums, n_blocks, block_sums + n_blocks + 1, run_if));   // (exclusive, in place: what k_scan_top does)
     hipLaunchKernelGGL(k_scan_down, dim3(n_blocks), dim3(SC_THREADS), 0, st, a, n, block_sums, run_if);
     return GOLAP_OK;
+}
+int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if) {
+    KernelTimer t(ctx, "scan_offsets", st);
+    return flat_scan_level(ctx, st, a, n, block_sums, run_if);
 }
 
 // bytes of small scratch one side needs for `plan` (hist/scan arrays + chunk descriptors)
@@ -1918,7 +1941,8 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
                                                (int)scatter_wc_lds_bytes(WC_MAX_F, WCN_CAP, 8)));
         for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
         {
-            const void* p1[] = {(const void*)k_part1_narrow<18, 18432, true, true>, (const void*)k_part1_narrow<18, 18432, true, false>,
+            const void* p1[] = {(const void*)k_part1_narrow<18, 18432, true, true>, (const void*)k_part1_narrow<18, 18432, true, true, 0, 1>,
+                                (const void*)k_part1_narrow<18, 18432, true, false>,
                                 (const void*)k_part1_narrow<18, 18432, false, false>, (const void*)k_part1_narrow<16, 16384, true, true>,
                                 (const void*)k_part1_narrow<16, 16384, true, false>, (const void*)k_part1_narrow<16, 16384, false, false>,
                                 (const void*)k_part1_narrow<24, 12288, false, false>,
@@ -2017,17 +2041,50 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
 // each side are compared with it: columns that really need 64 bits (two or more upper halves) are then known before the narrow
 // attempt starts, and its work-groups return at their first tile instead of partitioning ~5 % of the input in vain (1.1 ms at
 // 1B x 1B).  A lone odd key is still found by the pass itself.
-__global__ __launch_bounds__(1024) void k_key_hi(const long long* __restrict__ bkeys, unsigned long long nb, const long long* __restrict__ pkeys,
-                                                 unsigned long long np, uint32_t* __restrict__ out, uint32_t* __restrict__ wide) {
-    const uint32_t hi = (uint32_t)((unsigned long long)bkeys[0] >> 32);
-    if (threadIdx.x == 0) *out = hi;
-    bool odd = false;
+// out[0 .. 3] = the dictionary of upper halves (unused entries repeat entry 0), out[4] = how many distinct ones the samples hold; more
+// than KEY_DICT_MAX raise *wide.  (Round 3: a column with 2 .. 4 upper halves -- small negative next to small positive keys, two id
+// ranges -- keeps its 8-byte tuples, PassCfg::key_hi; before, a second upper half meant the 64-bit pipeline: 31 instead of 18 ms.)
+__global__ __launch_bounds__(1024) void k_key_dict(const long long* __restrict__ bkeys, unsigned long long nb, const long long* __restrict__ pkeys,
+                                                  unsigned long long np, uint32_t* __restrict__ out, uint32_t* __restrict__ wide, uint32_t max_d) {
+    __shared__ uint32_t s_dict[KEY_DICT_MAX], s_n, s_val, s_has, s_over;   // max_d: entries the first-pass form that will run can use (1 or KEY_DICT_MAX)
+    const uint32_t tid = threadIdx.x;
+    uint32_t smp[16];
+    const uint32_t hi0 = (uint32_t)((unsigned long long)bkeys[0] >> 32);
+#pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
-        const unsigned long long s = (unsigned long long)j * 1024 + threadIdx.x;   // sample s of 8192
-        if (nb) odd |= (uint32_t)((unsigned long long)bkeys[(s * nb) >> 13] >> 32) != hi;
-        if (np) odd |= (uint32_t)((unsigned long long)pkeys[(s * np) >> 13] >> 32) != hi;
+        const unsigned long long s = (unsigned long long)j * 1024 + tid;   // sample s of 8192
+        smp[2 * j] = nb ? (uint32_t)((unsigned long long)bkeys[(s * nb) >> 13] >> 32) : hi0;
+        smp[2 * j + 1] = np ? (uint32_t)((unsigned long long)pkeys[(s * np) >> 13] >> 32) : hi0;
     }
-    if (odd) atomicOr(wide, 1u);
+    if (tid == 0) { s_dict[0] = hi0; s_n = 1; s_over = 0; }
+    __syncthreads();
+    for (uint32_t round = 0; round <= KEY_DICT_MAX; ++round) {   // one new entry per round (the smallest missing upper half)
+        if (tid == 0) { s_val = 0xFFFFFFFFu; s_has = 0; }
+        __syncthreads();
+        const uint32_t n = s_n;
+        uint32_t cand = 0;
+        bool has = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            bool known = false;
+            for (uint32_t d = 0; d < n; ++d) known = known || smp[j] == s_dict[d];
+            if (!known && (!has || smp[j] < cand)) { cand = smp[j]; has = true; }
+        }
+        if (has) { atomicMin(&s_val, cand); s_has = 1; }
+        __syncthreads();
+        if (!s_has) break;   // (work-group-uniform)
+        if (tid == 0) {
+            if (n < max_d) { s_dict[n] = s_val; s_n = n + 1; } else s_over = 1;
+        }
+        __syncthreads();
+        if (s_over) break;
+    }
+    __syncthreads();
+    if (tid < KEY_DICT_MAX) out[tid] = tid < s_n ? s_dict[tid] : s_dict[0];
+    if (tid == 0) {
+        out[KEY_DICT_MAX] = s_n;
+        if (s_over) atomicOr(wide, 1u);
+    }
 }
 
 // A/B hooks for the round-2 narrow kernels (scripts/ab_env.py): GOLAP_P1N = 0 (k_scatter_big) | 24 | 18 | 16, GOLAP_P2R = 0 (k_scatter_wc) | 4 | 2
@@ -2056,8 +2113,10 @@ static void launch_part1_narrow(hipStream_t st, uint64_t in_keys, uint32_t rid_b
     if (v1 == 902) { GOLAP_P1N(18, 18432, true, false, 2); return; }
     if (v1 == 903) { GOLAP_P1N(18, 18432, true, false, 3); return; }
 #endif
-    if (v1 == 118 && al16) GOLAP_P1N(18, 18432, true, true);
-    else if (v1 == 116 && al16) GOLAP_P1N(16, 16384, true, true);
+    if (v1 == 118 && al16) {
+        GOLAP_P1N(18, 18432, true, true);
+        if (cfg.key_hi && cfg.pre_hashed) GOLAP_P1N(18, 18432, true, true, 0, 1);   // the dictionary form: runs instead when the column has 2 .. 4 upper halves
+    } else if (v1 == 116 && al16) GOLAP_P1N(16, 16384, true, true);
     else if (v1 == 24 || v1 == 124) GOLAP_P1N(24, 12288, false, false);
     else if ((v1 == 18 || v1 == 118) && al16) GOLAP_P1N(18, 18432, true, false);
     else if (v1 == 18 || v1 == 118) GOLAP_P1N(18, 18432, false, false);
@@ -2104,7 +2163,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     // k_part1_narrow + k_part2_ring hand the HASH of the key on instead of the key (a bijection of the 32 key bits): the ring pass
     // and the join need not hash again, equality is the same.  (The A/B knobs that pair an old kernel with a new one keep keys.)
     const bool hashed_tuples = p1n_variant() != 0 && p2r_variant() != 0 && F2 <= (uint32_t)P2R_MAX_F;
-    const uint32_t cap1 = (uint32_t)reserve_cap_sub(n_rows, F1, nsub, nc, chunk_rows);
+    const uint32_t cap1 = (uint32_t)reserve_cap_sub(n_rows, F1, nsub, nc, chunk_rows, key_hi ? DICT_SIGMA_MUL : 1u);
     if ((uint64_t)cap1 * F1 * nsub >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "narrow pipeline: first-pass positions exceed u32");
     uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F1 * nsub * 4);
     uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
@@ -2131,7 +2190,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     uint32_t sigmas, pad;
     provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
     hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F2, sigmas, pad, slot_base, slot_cap,
-                       (unsigned long long)final_rows(plan, n_rows, false), wide);
+                       (unsigned long long)final_rows(plan, n_rows, false), wide, key_hi, DICT_SIGMA_MUL);
     {
         FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, wide, wide};
         PassCfg cfg = p2.cfg;
@@ -2207,9 +2266,9 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     uint32_t* probe_hit = nullptr;
     if (use_narrow_keys(plan, p->n_build, p->n_probe)) {
         // optimistic 32-bit pipeline first (its big buffers alias the 64-bit pipeline's: only one of the two does any work)
-        uint32_t* words = (uint32_t*)ws_take(ctx, 16);   // [0] wide flag, [1] constant 0, [2] the upper key half the attempt stands on
+        uint32_t* words = (uint32_t*)ws_take(ctx, 32);   // [0] wide flag, [1] constant 0, [2 .. 5] the dictionary of upper key halves, [6] its size
         if (!words) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
-        GOLAP_TRY(zero_async(ctx, st, (void*)words, 16));
+        GOLAP_TRY(zero_async(ctx, st, (void*)words, 32));
         if (ctx->prof.enabled) {   // profiling: which of the two pipelines did the work is read back (asynchronously) for the byte credits
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
@@ -2220,8 +2279,9 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
         // offset into a common 4 Gi window).  Only the new tuple kernels know about it (knobs that select the old ones keep 0).
         const uint32_t* key_hi = nullptr;
         if (p1n_variant() != 0 && p2r_variant() != 0 && plan.passes[1].cfg.F <= (uint32_t)P2R_MAX_F) {
-            hipLaunchKernelGGL(k_key_hi, dim3(1), dim3(1024), 0, st, (const long long*)p->build_key_ptr, (unsigned long long)p->n_build,
-                               (const long long*)p->probe_key_ptr, (unsigned long long)p->n_probe, words + 2, words);
+            hipLaunchKernelGGL(k_key_dict, dim3(1), dim3(1024), 0, st, (const long long*)p->build_key_ptr, (unsigned long long)p->n_build,
+                               (const long long*)p->probe_key_ptr, (unsigned long long)p->n_probe, words + 2, words,
+                               (p1n_variant() == 118 && ((p->build_key_ptr | p->probe_key_ptr) & 15) == 0) ? KEY_DICT_MAX : 1u);   // (launch_part1_narrow's dictionary form)
             key_hi = words + 2;
         }
         if (p->join_type & 2) {
@@ -2839,3 +2899,4 @@ int32_t golap_join_partitioned_abort(golap_ctx* ctx) {
 }  // extern "C"
 
 #include "golap_shard.inc.h"
+#include "golap_shard_agg.inc.h"

@@ -103,6 +103,51 @@ __global__ __launch_bounds__(OP_THREADS) void k_filter_count(const long long* __
     if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
+// the same for a conjunction of comparisons, each on its own column: one ballot per strip after all columns have been looked at
+struct FilterAnd {
+    const long long* col[GOLAP_FILTER_AND_MAX];
+    const uint8_t* valid[GOLAP_FILTER_AND_MAX];
+    long long lit[GOLAP_FILTER_AND_MAX];
+    int op[GOLAP_FILTER_AND_MAX];
+    uint32_t n;
+};
+__global__ __launch_bounds__(OP_THREADS) void k_filter_count_and(FilterAnd fa, unsigned long long n, uint32_t* __restrict__ counts,
+                                                                 unsigned long long* __restrict__ bits) {
+    __shared__ uint32_t s_w[OP_WAVES];
+    const unsigned long long base = (unsigned long long)blockIdx.x * FC_ROWS;
+    uint32_t keep = 0;   // bit r: row r of this thread passes so far
+#pragma unroll
+    for (int r = 0; r < FC_RPT; ++r) keep |= (base + r * OP_THREADS + threadIdx.x < n ? 1u : 0u) << r;
+    for (uint32_t p = 0; p < fa.n; ++p) {   // (work-group-uniform)
+        long long v[FC_RPT];
+#pragma unroll
+        for (int r = 0; r < FC_RPT; ++r) {   // unconditional (clamped) loads first: all 16 in flight together
+            const unsigned long long i = base + r * OP_THREADS + threadIdx.x;
+            v[r] = fa.col[p][i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int r = 0; r < FC_RPT; ++r) {
+            const unsigned long long i = base + r * OP_THREADS + threadIdx.x;
+            const bool ok = cmp_i64(fa.op[p], v[r], fa.lit[p]) && (!fa.valid[p] || fa.valid[p][i < n ? i : n - 1]);
+            if (!ok) keep &= ~(1u << r);
+        }
+    }
+    uint32_t c = 0;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int r = 0; r < FC_RPT; ++r) {
+        const bool k = (keep >> r) & 1u;
+        c += k ? 1u : 0u;
+        const unsigned long long m = __ballot(k);
+        if ((threadIdx.x & 63) == (uint32_t)r) mine = m;
+    }
+    if ((threadIdx.x & 63) < FC_RPT) bits[((size_t)blockIdx.x * OP_WAVES + (threadIdx.x >> 6)) * FC_RPT + (threadIdx.x & 63)] = mine;
+    c = wave_reduce_add(c);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
 __global__ __launch_bounds__(OP_THREADS) void k_filter_write(const unsigned long long* __restrict__ bits, const uint32_t* __restrict__ scanned,
                                                              uint32_t n_blocks, uint32_t* __restrict__ out_idx,
                                                              unsigned long long* __restrict__ out_count) {
@@ -608,21 +653,21 @@ __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __r
 // last line of a (chunk, bucket) range can be partial.  Same register-resident 16384-row tile as k_agg_scatter_big; the window
 // (9216 rows) holds the carried rows too, so a tile still takes two rounds.
 // ---------------------------------------------------------------------------
-constexpr int AGW_THREADS = 1024;
 constexpr int AGW_RPT = 16;
-constexpr int AGW_TILE = AGW_THREADS * AGW_RPT;
 constexpr int AGW_MAX_B = 128;
 constexpr int AGW_CL = 16;       // rows per carried line
-constexpr int AGW_WIN = 9216;    // 2 * WIN >= TILE + MAX_B * (CL - 1)
-constexpr size_t AGW_LDS = (size_t)AGW_WIN * 12 + (size_t)AGW_MAX_B * AGW_CL * 12 + (size_t)AGW_MAX_B * 5 * 4 + 20 * 4 + 16;
-static_assert(2 * AGW_WIN >= AGW_TILE + AGW_MAX_B * (AGW_CL - 1), "a tile and its carried rows pass the window in two rounds");
-static_assert(AGW_WIN % AGW_THREADS == 0, "window rows per thread");
+// two shapes: one 1024-thread work-group per CU (16384-row tile, two window rounds: the default), or two 512-thread work-groups per
+// CU (8192-row tile, three rounds of a 3584-row window; slower, kept as an A/B reference -- see the launch site)
+static constexpr size_t agw_lds(int win) { return (size_t)win * 12 + (size_t)AGW_MAX_B * AGW_CL * 12 + (size_t)AGW_MAX_B * 5 * 4 + 20 * 4 + 16; }
 
-template <typename KeyT, bool VAL_F64>
+template <typename KeyT, bool VAL_F64, int AGW_THREADS, int AGW_WIN>
 __global__ __launch_bounds__(AGW_THREADS) void k_agg_scatter_wc(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
                                                                 uint32_t n_groups, uint32_t gb_shift, uint32_t chunk_rows, uint32_t S, uint32_t B,
                                                                 const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
                                                                 double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr) {
+    constexpr int AGW_TILE = AGW_THREADS * AGW_RPT;
+    static_assert(AGW_WIN % AGW_THREADS == 0, "window rows per thread");
+    static_assert(3 * AGW_WIN >= AGW_TILE + AGW_MAX_B * (AGW_CL - 1), "a tile and its carried rows pass the window in at most three rounds");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_val = reinterpret_cast<double*>(s_raw);                     // [WIN]      window: values
     double* c_val = s_val + AGW_WIN;                                      // [B][CL]    carried rows: values
@@ -633,7 +678,7 @@ __global__ __launch_bounds__(AGW_THREADS) void k_agg_scatter_wc(const KeyT* __re
     uint32_t* s_gpos = s_start + AGW_MAX_B;                               // [B] output row of the bucket's first staged row
     uint32_t* s_carry = s_gpos + AGW_MAX_B;                               // [B] rows carried into this tile
     uint32_t* s_emit = s_carry + AGW_MAX_B;                               // [B] rows that leave in this tile (the rest is carried on)
-    uint32_t* s_w = s_emit + AGW_MAX_B;                                   // [16] wave totals, [16] rows staged in this tile
+    uint32_t* s_w = s_emit + AGW_MAX_B;                                   // [<= 16] wave totals, [16] rows staged in this tile
     const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
     if (lo >= n) return;
     const unsigned long long hi = lo + chunk_rows < n ? lo + chunk_rows : n;
@@ -1001,6 +1046,52 @@ int32_t golap_filter_compact_nullable(golap_ctx* ctx, const golap_filter_predica
     return GOLAP_OK;
 }
 
+int32_t golap_filter_compact_and(golap_ctx* ctx, const golap_filter_predicate* preds, const uint64_t* column_ptrs, const uint64_t* validity_ptrs,
+                                 uint32_t n_preds, uint64_t n_rows, uint64_t out_indices_ptr, uint64_t out_count_ptr, void* stream) {
+    if (!ctx || !preds || !column_ptrs) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (n_preds == 0 || n_preds > GOLAP_FILTER_AND_MAX) return fail(ctx, GOLAP_ERR_INVALID_ARG, "1 .. %d comparisons per conjunction", GOLAP_FILTER_AND_MAX);
+    if (!out_count_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_count_ptr is null");
+    if (n_rows && !out_indices_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null indices pointer");
+    if (n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row ids are u32: at most 2^32-16 rows per batch");
+    FilterAnd fa;
+    memset(&fa, 0, sizeof fa);
+    fa.n = n_preds;
+    for (uint32_t k = 0; k < n_preds; ++k) {
+        if (preds[k].op < 0 || preds[k].op > GOLAP_CMP_NEVER) return fail(ctx, GOLAP_ERR_INVALID_ARG, "bad cmp op %d", preds[k].op);
+        if (n_rows && !column_ptrs[k]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null column pointer");
+        fa.col[k] = (const long long*)column_ptrs[k];
+        fa.valid[k] = validity_ptrs ? (const uint8_t*)validity_ptrs[k] : nullptr;
+        fa.lit[k] = (long long)preds[k].literal;
+        fa.op[k] = preds[k].op;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    if (n_rows == 0) { GOLAP_TRY(zero_async(ctx, st, (void*)out_count_ptr, 8)); return GOLAP_OK; }
+    const uint32_t n_blocks = (uint32_t)ceil_div(n_rows, FC_ROWS);
+    const uint64_t n_words = (uint64_t)n_blocks * FC_RPT * OP_WAVES;
+    GOLAP_TRY(ws_begin(ctx, (uint64_t)(n_blocks + 1) * 4 + ceil_div(n_blocks + 1, FLAT_SCAN_BLOCK) * 4 + n_words * 8 + 8192, st));
+    uint32_t* counts = (uint32_t*)ws_take(ctx, (uint64_t)(n_blocks + 1) * 4);
+    uint32_t* bsums = (uint32_t*)ws_take(ctx, ceil_div(n_blocks + 1, FLAT_SCAN_BLOCK) * 4 + 4);
+    unsigned long long* bits = (unsigned long long*)ws_take(ctx, n_words * 8);
+    if (!counts || !bsums || !bits) return fail(ctx, GOLAP_ERR_OOM, "filter workspace exhausted");
+    GOLAP_TRY(zero_async(ctx, st, (void*)(counts + n_blocks), 4));
+    {
+        KernelTimer t(ctx, "filter_count_and", st, 8ull * n_preds * n_rows);
+        hipLaunchKernelGGL(k_filter_count_and, dim3(n_blocks), dim3(OP_THREADS), 0, st, fa, (unsigned long long)n_rows, counts, bits);
+    }
+    GOLAP_TRY(flat_scan(ctx, st, counts, n_blocks + 1, bsums));
+    {
+        KernelTimer t(ctx, "filter_compact", st, n_rows / 8);
+        hipLaunchKernelGGL(k_filter_write, dim3(n_blocks), dim3(OP_THREADS), 0, st, (const unsigned long long*)bits, (const uint32_t*)counts, n_blocks,
+                           (uint32_t*)out_indices_ptr, (unsigned long long*)out_count_ptr);
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    ws_end(ctx, st);
+    return GOLAP_OK;
+}
+
 int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_ptr, uint64_t count_ptr, uint64_t n_indices_max, uint64_t out_ptr,
                          void* stream) {
     if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
@@ -1144,9 +1235,12 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             const void* big[] = {(const void*)k_agg_scatter_big<int, true>, (const void*)k_agg_scatter_big<int, false>,
                                  (const void*)k_agg_scatter_big<long long, true>, (const void*)k_agg_scatter_big<long long, false>};
             for (const void* f : big) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AGB_LDS));
-            const void* wcs[] = {(const void*)k_agg_scatter_wc<int, true>, (const void*)k_agg_scatter_wc<int, false>,
-                                 (const void*)k_agg_scatter_wc<long long, true>, (const void*)k_agg_scatter_wc<long long, false>};
-            for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AGW_LDS));
+            const void* wcs[] = {(const void*)k_agg_scatter_wc<int, true, 1024, 9216>, (const void*)k_agg_scatter_wc<int, false, 1024, 9216>,
+                                 (const void*)k_agg_scatter_wc<long long, true, 1024, 9216>, (const void*)k_agg_scatter_wc<long long, false, 1024, 9216>};
+            for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)agw_lds(9216)));
+            const void* wcs2[] = {(const void*)k_agg_scatter_wc<int, true, 512, 3584>, (const void*)k_agg_scatter_wc<int, false, 512, 3584>,
+                                  (const void*)k_agg_scatter_wc<long long, true, 512, 3584>, (const void*)k_agg_scatter_wc<long long, false, 512, 3584>};
+            for (const void* f : wcs2) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)agw_lds(3584)));
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<false, AG_GB_SUM, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB_SUM * 12 + 16));
             ctx->attr_done[1] = true;
         }
@@ -1228,8 +1322,18 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     hipLaunchKernelGGL((k_agg_scatter_big<KT, VF>), dim3(pS2), dim3(AGB_THREADS), AGB_LDS, st, (const KT*)p->group_key_ptr, val,      \
                        (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
 #define GOLAP_AGG_SCW(KT, VF)                                                                                                         \
-    hipLaunchKernelGGL((k_agg_scatter_wc<KT, VF>), dim3(pS2), dim3(AGW_THREADS), AGW_LDS, st, (const KT*)p->group_key_ptr, val,       \
-                       (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
+    do {                                                                                                                              \
+        if (wc_two)                                                                                                                   \
+            hipLaunchKernelGGL((k_agg_scatter_wc<KT, VF, 512, 3584>), dim3(pS2), dim3(512), agw_lds(3584), st, (const KT*)p->group_key_ptr, val, \
+                               (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv);               \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_agg_scatter_wc<KT, VF, 1024, 9216>), dim3(pS2), dim3(1024), agw_lds(9216), st, (const KT*)p->group_key_ptr, val, \
+                               (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv);               \
+    } while (0)
+                // GOLAP_AGG_WC=512: the two-work-groups-per-CU shape (A/B hook).  Measured at 1B rows, 2^20 groups: 8.7 ms against 6.2 ms for
+                // the 1024-thread shape -- the per-tile fixed work (bucket scan, carry staging per window round) is paid twice as often
+                // and outweighs what the second work-group overlaps.
+                const bool wc_two = wc_env && !strcmp(wc_env, "512");
                 if (p_wc) {
                     if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_SCW(int, true); else GOLAP_AGG_SCW(int, false); }
                     else { if (vf) GOLAP_AGG_SCW(long long, true); else GOLAP_AGG_SCW(long long, false); }
@@ -1404,16 +1508,18 @@ __global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict
 
 static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st) {
     if (!p->group_key_ptr && p->n_rows) return fail(ctx, GOLAP_ERR_INVALID_ARG, "GOLAP_KEYS_HASHED needs a group key column");
-    if (p->n_groups > (1u << 22)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^22 groups (key table of 2^23 entries + 1: the two-level scan covers 2^24)");
+    // (round 3: the scan over the key table nests, so the bound is the table's memory -- 2^28 groups = a 4 GiB table -- not 2^22)
+    if (p->n_groups > (1u << 28)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^28 groups (key table of 2^29 entries)");
     if (p->n_rows >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "GOLAP_KEYS_HASHED: at most 2^32-16 rows");
     uint32_t cap = 1024;
     while (cap < 2 * p->n_groups) cap <<= 1;   // load factor <= 0.5 while the bound holds
     const uint32_t mask = cap - 1;
     const uint64_t n = p->n_rows;
-    GOLAP_TRY(aux_begin(ctx, round_up((uint64_t)cap * 8, 256) + 2 * round_up(((uint64_t)cap + 1) * 4, 256) + round_up(std::max<uint64_t>(n, 1) * 4, 256) + 8192, st));
+    GOLAP_TRY(aux_begin(ctx, round_up((uint64_t)cap * 8, 256) + round_up(((uint64_t)cap + 1) * 4, 256) + round_up(flat_scan_scratch_words((uint64_t)cap + 1) * 4, 256) +
+                                 round_up(std::max<uint64_t>(n, 1) * 4, 256) + 8192, st));
     long long* table = (long long*)aux_take(ctx, (uint64_t)cap * 8);
     uint32_t* ids = (uint32_t*)aux_take(ctx, ((uint64_t)cap + 1) * 4);
-    uint32_t* bsums = (uint32_t*)aux_take(ctx, ceil_div((uint64_t)cap + 1, FLAT_SCAN_BLOCK) * 4 + 4);
+    uint32_t* bsums = (uint32_t*)aux_take(ctx, flat_scan_scratch_words((uint64_t)cap + 1) * 4);
     uint32_t* slots = (uint32_t*)aux_take(ctx, std::max<uint64_t>(n, 1) * 4);
     uint32_t* flags = (uint32_t*)aux_take(ctx, 8);
     if (!table || !ids || !bsums || !slots || !flags) return fail(ctx, GOLAP_ERR_OOM, "aggregate scratch exhausted (key table)");

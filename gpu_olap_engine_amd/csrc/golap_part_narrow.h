@@ -131,7 +131,10 @@ static inline size_t part1_narrow_lds_bytes(uint32_t F, uint32_t win) { return (
 // VEC2: 16-byte loads (needs a 16-byte aligned column); ASM: hidden loads/stores + counted waits (implies VEC2).
 // DIAG != 0: timing-only diagnostic builds for scripts/ab_p12.py (WRONG results, never launched by the product path):
 //   1 = write-out goes to the tile's own input positions (linear, no scatter), 2 = no stores at all, 3 = no loads (keys made up).
-template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG = 0>
+// DICT != 0: the form for key columns with 2 .. 4 distinct upper halves (PassCfg::key_hi): every key's upper half is looked up in the
+// dictionary (scalar registers), the tuple's first word is (hash >> b1) | (index << (32 - b1)).  Both forms are enqueued; each
+// returns at once unless the dictionary size on the device says it is the one to run.
+template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG = 0, int DICT = 0>
 __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* __restrict__ in_keys, uint32_t rid_base,
                                                               const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
                                                               uint2* __restrict__ out_rows, PassCfg cfg, ReserveArgs rs) {
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     // the attempt may be over before it starts (k_key_hi's sample found two upper key halves): ~2000 work-groups that each load and
     // rank one tile before they notice cost 0.45 ms per side; asking first costs the good case one L2 round trip per work-group
     if (__hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if (key_dict_mode(cfg) != (DICT != 0)) return;   // (work-group-uniform: the other form of this pass does the work)
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
     if (len == 0) return;
@@ -163,6 +167,10 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     if (tid < F) s_cnt[tid] = 0;
     const uint32_t khi = __builtin_amdgcn_readfirstlane(key_hi_of(cfg));   // the upper key half this attempt stands on (see PassCfg::key_hi)
     const bool emit_hash = cfg.pre_hashed != 0;
+    // DICT: the dictionary's other entries and the position of the index in the tuple's first word
+    const uint32_t kd1 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[1]) : 0u, kd2 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[2]) : 0u,
+                   kd3 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[3]) : 0u;
+    const uint32_t b1 = 31u - (uint32_t)__builtin_clz(F);   // hash bits this pass consumes (F = 256 << e1: the low 8 + e1 bits, bucket_of)
 
     // keys of the tile: kv[h] = (lo, hi) of key 2h, (lo, hi) of key 2h + 1
     u32x4 kv[(RPT + 1) / 2];
@@ -227,10 +235,21 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             k32[r] = (r & 1) ? kv[r >> 1].z : kv[r >> 1].x;
-            hi |= ((r & 1) ? kv[r >> 1].w : kv[r >> 1].y) ^ khi;   // clamped duplicates are real keys too
+            const uint32_t khi_r = (r & 1) ? kv[r >> 1].w : kv[r >> 1].y;
             br[r] = 0xFFFFFFFFu;
-            const uint32_t h = hash_int32((int32_t)(k32[r] ^ khi));                       // == hash_int64 of the whole key
-            if (emit_hash) k32[r] = h;       // the tuple carries the hash from here on (PassCfg::pre_hashed); work-group-uniform
+            uint32_t h;
+            if (DICT) {
+                const uint32_t m0 = khi_r ^ khi, m1 = khi_r ^ kd1, m2 = khi_r ^ kd2, m3 = khi_r ^ kd3;
+                const uint32_t ma = m0 < m1 ? m0 : m1, mb = m2 < m3 ? m2 : m3;
+                hi |= ma < mb ? ma : mb;                                                  // 0 iff the upper half is one of the dictionary's
+                const uint32_t id = m3 == 0u ? 3u : (m2 == 0u ? 2u : (m1 == 0u ? 1u : 0u));
+                h = hash_int32((int32_t)(k32[r] ^ khi_r));                                // == hash_int64 of the whole key
+                k32[r] = (h >> b1) | (id << (32u - b1));                                  // (DICT implies pre_hashed)
+            } else {
+                hi |= khi_r ^ khi;   // clamped duplicates are real keys too
+                h = hash_int32((int32_t)(k32[r] ^ khi));                                  // == hash_int64 of the whole key
+                if (emit_hash) k32[r] = h;       // the tuple carries the hash from here on (PassCfg::pre_hashed); work-group-uniform
+            }
             if (tile_pos(r) < tn) {
                 const uint32_t b = bucket_of(h, cfg);
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);                    // b < 1024, rank < 32768
@@ -387,6 +406,9 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
     const uint32_t slot0 = __builtin_amdgcn_readfirstlane(fx.slot_base[g]), cap = __builtin_amdgcn_readfirstlane(fx.slot_cap[g]);
     const uint32_t khi = __builtin_amdgcn_readfirstlane(key_hi_of(cfg));
     const bool hashed = cfg.pre_hashed != 0;   // the tuples carry hash_int32(key) instead of the key (k_part1_narrow wrote them so)
+    // dictionary mode (PassCfg::key_hi): the first word is (hash >> b1) | (index << (32 - b1)) with b1 = cfg.shift, the bits the first
+    // pass consumed -- this pass's digit sits at bit 0
+    if (hashed && key_dict_mode(cfg)) cfg.shift = 0;
     uint2* const out_group = out_rows + slot0;   // work-group-uniform base of every store of this group (byte offsets fit 32 bits)
     if (n_tiles == 0) {
         if (tid < F) { fx.sub_start[(size_t)g * F + tid] = slot0 + tid * cap; fx.sub_len[(size_t)g * F + tid] = 0; }

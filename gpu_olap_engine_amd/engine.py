@@ -195,6 +195,21 @@ class Context:
         self._ck(self._lib.golap_filter_compact_nullable(self._h, C.byref(pred), _ptr(column), _ptr(valid), n, _ptr(idx), _ptr(cnt), _stream()))
         return idx, cnt
 
+    def filter_compact_and(self, columns, ops, literals, valids=None):
+        """golap_filter_compact_and: rows for which EVERY comparison columns[k] <ops[k]> literals[k] is true (NULL operands: not true).
+        -> (indices, count) as filter_compact."""
+        k = len(columns)
+        for c in columns:
+            _chk_tensor(c, torch.int64, "column")
+        n = columns[0].numel()
+        idx = torch.empty(max(n, 1), dtype=torch.int32, device=columns[0].device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=columns[0].device)
+        preds = (N.FilterPredicate * k)(*[N.FilterPredicate(i, o if isinstance(o, int) else parse_cmp_op(o), int(l)) for i, (o, l) in enumerate(zip(ops, literals))])
+        cptrs = (C.c_uint64 * k)(*[_ptr(c) for c in columns])
+        vptrs = (C.c_uint64 * k)(*[_ptr(v) for v in valids]) if valids is not None else None
+        self._ck(self._lib.golap_filter_compact_and(self._h, preds, cptrs, vptrs, k, n, _ptr(idx), _ptr(cnt), _stream()))
+        return idx, cnt
+
     def take(self, column, indices, count=None, n_max=None):
         if column.element_size() != 8:
             raise TypeError("take: 8-byte columns only (executor.rs:496-507)")
@@ -333,7 +348,7 @@ class Context:
         return c
 
     # ---- GpuAggregate -----------------------------------------------------------
-    def aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False, hashed=False, value_valid=None):
+    def aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False, hashed=False, value_valid=None, _comm=None):
         """AggregateKernel::aggregate.
 
         specs  : list of (func, value_col_index) -- output plane i belongs to specs[i]
@@ -376,7 +391,10 @@ class Context:
             vvp = (C.c_uint64 * nv)(*[_ptr(v) for v in value_valid])
         prm = N.AggregateParams(_ptr(group_keys), vptrs, nv, n_rows, n_groups, _ptr(out), kd, vdt, _ptr(counts),
                                 N.KEYS_HASHED if hashed else N.KEYS_DENSE, 0, _ptr(okeys), _ptr(ong), vvp)
-        self._ck(self._lib.golap_aggregate(self._h, sp, len(specs), C.byref(prm), _stream()))
+        if _comm is not None:   # collective form over row-sharded inputs (Comm.sharded_aggregate)
+            self._ck(self._lib.golap_sharded_aggregate(self._h, _comm._h, sp, len(specs), C.byref(prm), _stream()))
+        else:
+            self._ck(self._lib.golap_aggregate(self._h, sp, len(specs), C.byref(prm), _stream()))
         if hashed:
             return (out, counts, okeys, ong) if want_counts else (out, okeys, ong)
         return (out, counts) if want_counts else out
@@ -489,6 +507,12 @@ class Comm:
                                   1 if force_exact else 0, max_msg_bytes)
         self.ctx._ck(self.ctx._lib.golap_sharded_join(self.ctx._h, self._h, C.byref(prm), _stream()))
         return out_pairs, out_count
+
+    def sharded_aggregate(self, specs, values, group_keys=None, n_groups=1, want_counts=False, hashed=False, value_valid=None):
+        """golap_sharded_aggregate (collective): Context.aggregate over THIS rank's rows of a row-sharded table.  Dense keys: the result
+        is replicated on every rank; hashed keys: it stays sharded (every key is reported by exactly one rank)."""
+        return self.ctx.aggregate(specs, values, group_keys=group_keys, n_groups=n_groups, want_counts=want_counts, hashed=hashed,
+                                  value_valid=value_valid, _comm=self)
 
     def selftest(self, nbytes):
         """golap_comm_selftest -> (wrong 4-byte words, index of the first one or None)."""

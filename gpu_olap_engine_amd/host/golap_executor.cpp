@@ -274,6 +274,7 @@ struct Exec {
     int32_t projection(std::vector<RecordBatch>& in, const std::vector<std::unique_ptr<golap_expr>>& exprs, std::vector<RecordBatch>& out);
     int32_t hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out);
     int32_t aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
+    int32_t aggregate_multi_key(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
 };
 
 bool parse_i64(const std::string& s, int64_t& v) {
@@ -299,36 +300,71 @@ golap_cmp_op flip(golap_cmp_op op) {
 // ---------------------------------------------------------------------------
 // execute_filter, executor.rs:161-178 / eval_filter_mask :443-476 / filter_record_batch :478-494
 // ---------------------------------------------------------------------------
+// leaves of a conjunction: `a AND b AND ...` of <column> <op> <literal> comparisons (optimizer.rs:155-159 merges stacked filters with
+// AND).  The reference's CPU mask knows no AND (eval_filter_mask, executor.rs:457-465: unknown operator -> no row); evaluating it
+// with SQL semantics on the device is an extension -- one pass over the columns involved, every leaf with the reference's own edge
+// cases (non-Int64 operands: that leaf passes every row; unknown comparison: no row).
+// (only a node whose operands are themselves comparisons / conjunctions: `a AND 3` keeps the reference's reading -- an unknown
+// operator between two Int64 operands, no row)
+static bool is_and(const golap_expr& e) {
+    return e.kind == golap_expr::Binary && (e.op == "AND" || e.op == "and" || e.op == "&&") && e.left && e.right && e.left->kind == golap_expr::Binary &&
+           e.right->kind == golap_expr::Binary;
+}
+static void and_leaves(const golap_expr& e, std::vector<const golap_expr*>& out) {
+    if (is_and(e) && e.left && e.right) { and_leaves(*e.left, out); and_leaves(*e.right, out); }
+    else out.push_back(&e);
+}
+
 int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::vector<RecordBatch>& out) {
     for (RecordBatch& b : in) {
         // non-binary predicate => every row passes (:474)
         if (pred.kind != golap_expr::Binary) { out.push_back(std::move(b)); continue; }
-        const golap_expr *l = pred.left.get(), *r = pred.right.get();
-        golap_cmp_op op = golap_parse_cmp_op(pred.op.c_str());
-        const golap_expr *colx = nullptr, *litx = nullptr;
-        if (l->kind == golap_expr::Column && r->kind == golap_expr::Literal) { colx = l; litx = r; }
-        else if (l->kind == golap_expr::Literal && r->kind == golap_expr::Column) { colx = r; litx = l; op = flip(op); }
-        else return herr(GOLAP_ERR_UNSUPPORTED, "GpuFilter: only <column> <op> <literal> predicates run on the device");
-        const int ci = resolve_column(*colx, b);
-        if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + colx->name + "' not found in batch");   // :386
-        int64_t lit;
-        // operands that are not both Int64 => every row passes (:449-452, :471-472)
-        if (b.cols[ci].dtype != DType::Int64 || !parse_i64(litx->value, lit)) { out.push_back(std::move(b)); continue; }
+        std::vector<const golap_expr*> leaves;
+        and_leaves(pred, leaves);
+        if (leaves.size() > GOLAP_FILTER_AND_MAX) return herr(GOLAP_ERR_UNSUPPORTED, "GpuFilter: at most " + std::to_string(GOLAP_FILTER_AND_MAX) + " comparisons in one conjunction");
+        std::vector<golap_filter_predicate> fps;
+        std::vector<int> fcols;
+        for (const golap_expr* lf : leaves) {
+            if (lf->kind != golap_expr::Binary) continue;   // a non-binary leaf passes every row (:474)
+            const golap_expr *l = lf->left.get(), *r = lf->right.get();
+            golap_cmp_op op = golap_parse_cmp_op(lf->op.c_str());
+            const golap_expr *colx = nullptr, *litx = nullptr;
+            if (l->kind == golap_expr::Column && r->kind == golap_expr::Literal) { colx = l; litx = r; }
+            else if (l->kind == golap_expr::Literal && r->kind == golap_expr::Column) { colx = r; litx = l; op = flip(op); }
+            else return herr(GOLAP_ERR_UNSUPPORTED, "GpuFilter: only <column> <op> <literal> predicates (and conjunctions of them) run on the device");
+            const int ci = resolve_column(*colx, b);
+            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + colx->name + "' not found in batch");   // :386
+            int64_t lit;
+            // operands that are not both Int64 => every row passes (:449-452, :471-472)
+            if (b.cols[ci].dtype != DType::Int64 || !parse_i64(litx->value, lit)) continue;
+            fps.push_back(golap_filter_predicate{(uint64_t)ci, (int32_t)op, lit});
+            fcols.push_back(ci);
+        }
+        if (fps.empty()) { out.push_back(std::move(b)); continue; }
         const uint64_t n = b.num_rows;
         if (n == 0) continue;   // empty batches are dropped (:173)
-        DevBuf dkey, didx, dcnt, dval;
-        H_TRY(dkey.alloc(ctx, n * 8));
+        DevBuf didx, dcnt;
+        std::vector<DevBuf> dkeys(fps.size()), dvals(fps.size());
+        std::vector<uint64_t> kptrs(fps.size(), 0), vptrs(fps.size(), 0);
         H_TRY(didx.alloc(ctx, n * 4));
         H_TRY(dcnt.alloc(ctx, 8));
-        H_TRY(h2d(b.cols[ci].data.data(), dkey.ptr, n * 8));
-        const bool key_has_nulls = !b.cols[ci].in_valid.empty();
-        if (key_has_nulls) {   // a comparison with NULL is not true: such rows do not pass
-            H_TRY(dval.alloc(ctx, n));
-            H_TRY(h2d(b.cols[ci].in_valid.data(), dval.ptr, n));
+        for (size_t k = 0; k < fps.size(); ++k) {
+            const Column& c = b.cols[fcols[k]];
+            size_t same = k;
+            for (size_t j = 0; j < k; ++j) if (fcols[j] == fcols[k]) { same = j; break; }
+            if (same != k) { kptrs[k] = kptrs[same]; vptrs[k] = vptrs[same]; continue; }   // (a range: lo <= x AND x < hi reads the column once)
+            H_TRY(dkeys[k].alloc(ctx, n * 8));
+            H_TRY(h2d(c.data.data(), dkeys[k].ptr, n * 8));
+            kptrs[k] = dkeys[k].ptr;
+            if (!c.in_valid.empty()) {   // a comparison with NULL is not true: such rows do not pass
+                H_TRY(dvals[k].alloc(ctx, n));
+                H_TRY(h2d(c.in_valid.data(), dvals[k].ptr, n));
+                vptrs[k] = dvals[k].ptr;
+            }
         }
         H_TRY(xsync());
-        golap_filter_predicate fp{(uint64_t)ci, (int32_t)op, lit};
-        H_TRY(golap_filter_compact_nullable(ctx, &fp, dkey.ptr, key_has_nulls ? dval.ptr : 0, n, didx.ptr, dcnt.ptr, nullptr));
+        if (fps.size() == 1) H_TRY(golap_filter_compact_nullable(ctx, &fps[0], kptrs[0], vptrs[0], n, didx.ptr, dcnt.ptr, nullptr));
+        else H_TRY(golap_filter_compact_and(ctx, fps.data(), kptrs.data(), vptrs.data(), (uint32_t)fps.size(), n, didx.ptr, dcnt.ptr, nullptr));
         H_TRY(ksync());
         uint64_t kept = 0;
         H_TRY(d2h(dcnt.ptr, &kept, 8));
@@ -578,8 +614,108 @@ static RecordBatch take_rows(const RecordBatch& b, const std::vector<uint64_t>& 
     return o;
 }
 
+// GROUP BY over several columns (physical_plan.rs:52-54: group_by is a Vec<PhysicalExpr>; lowering :157-172 keeps every column; the
+// reference's executor ignores it, executor.rs:307).  The columns are Int64 / Int32, so a row's composite key is a mixed-radix number:
+// digit_c = value - min_c (NULL: one past the column's largest digit -- NULLs sort last, and (NULL, 1) is a group of its own), weight_c
+// = the product of the later columns' digit counts.  While that number fits 62 bits -- dictionary-like ids, dates, small codes: the
+// usual GROUP BY columns -- it IS a single Int64 key: exact, no collisions, and the one-column path below (dense or hashed) does the
+// rest; the result's packed key column is unpacked into the key columns again.  Wider composites are refused with their sizes.
+int32_t Exec::aggregate_multi_key(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out) {
+    const size_t K = p.group_by.size();
+    const uint32_t na = (uint32_t)p.aggr_inputs.size();
+    uint64_t n = 0;
+    for (const RecordBatch& b : in) n += b.num_rows;
+    std::vector<std::vector<int64_t>> vals(K);
+    std::vector<std::vector<uint8_t>> valid(K);
+    std::vector<int64_t> mn(K, INT64_MAX), mx(K, INT64_MIN);
+    std::vector<bool> has_null(K, false);
+    for (size_t c = 0; c < K; ++c) {
+        if (p.group_by[c]->kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group-by expressions must be column references");
+        vals[c].reserve(n);
+        valid[c].reserve(n);
+        for (const RecordBatch& b : in) {
+            const int ci = resolve_column(*p.group_by[c], b);
+            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + p.group_by[c]->name + "' not found in batch");
+            const Column& col = b.cols[ci];
+            if (col.dtype != DType::Int64 && col.dtype != DType::Int32) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group key must be Int64 or Int32");
+            for (uint64_t i = 0; i < b.num_rows; ++i) {
+                const int64_t v = col.dtype == DType::Int64 ? ((const int64_t*)col.data.data())[i] : (int64_t)((const int32_t*)col.data.data())[i];
+                const uint8_t ok = col.in_valid.empty() ? 1 : col.in_valid[i];
+                vals[c].push_back(v);
+                valid[c].push_back(ok);
+                if (ok) { mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); } else has_null[c] = true;
+            }
+        }
+        if (mn[c] > mx[c]) mn[c] = mx[c] = 0;   // no valid value at all
+    }
+    // digit counts and weights (first column most significant: rows come out sorted by (k0, k1, ...), NULLS LAST per column)
+    std::vector<unsigned __int128> digits(K);
+    std::vector<uint64_t> weight(K, 1);
+    unsigned __int128 total = 1;
+    for (size_t c = K; c-- > 0;) {
+        digits[c] = (unsigned __int128)((__int128)mx[c] - (__int128)mn[c]) + 1 + (has_null[c] ? 1 : 0);
+        weight[c] = (uint64_t)total;
+        total *= digits[c];
+        if (total > ((unsigned __int128)1 << 62)) {
+            std::string sizes;
+            for (size_t k = 0; k < K; ++k) sizes += (k ? " x " : "") + std::to_string((double)((__int128)mx[k] - (__int128)mn[k]) + 1.0);
+            return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: the composite group key does not fit 62 bits (value ranges " + sizes + ")");
+        }
+    }
+    // one packed Int64 key column per batch, under a name no input column has
+    const std::string pk = "__golap_group_key";
+    uint64_t o = 0;
+    for (RecordBatch& b : in) {
+        Column kc;
+        kc.name = pk; kc.dtype = DType::Int64; kc.rows = b.num_rows;
+        kc.data.resize(b.num_rows * 8);
+        int64_t* d = (int64_t*)kc.data.data();
+        for (uint64_t i = 0; i < b.num_rows; ++i) {
+            uint64_t key = 0;
+            for (size_t c = 0; c < K; ++c) {
+                const uint64_t dg = valid[c][o + i] ? (uint64_t)(vals[c][o + i] - mn[c]) : (uint64_t)(digits[c] - 1);
+                key += dg * weight[c];
+            }
+            d[i] = (int64_t)key;
+        }
+        o += b.num_rows;
+        b.cols.push_back(std::move(kc));
+    }
+    auto gb = std::move(p.group_by);
+    p.group_by.clear();
+    p.group_by.emplace_back(new golap_expr());
+    p.group_by[0]->kind = golap_expr::Column;
+    p.group_by[0]->name = pk;
+    std::vector<RecordBatch> g;
+    const int32_t rc = aggregate(in, p, g);
+    p.group_by = std::move(gb);
+    for (RecordBatch& b : in) b.cols.pop_back();
+    H_TRY(rc);
+    if (g.empty() || g[0].cols.size() != 1 + (size_t)na) return herr(GOLAP_ERR_INVALID_ARG, "GpuAggregate: unexpected grouped result");
+    RecordBatch ob;
+    ob.num_rows = g[0].num_rows;
+    const int64_t* packed = (const int64_t*)g[0].cols[0].data.data();
+    for (size_t c = 0; c < K; ++c) {
+        Column kc;
+        kc.name = p.group_by[c]->name; kc.dtype = DType::Int64; kc.rows = ob.num_rows;
+        kc.data.resize(ob.num_rows * 8);
+        if (has_null[c]) kc.in_valid.assign(ob.num_rows, 1);
+        int64_t* d = (int64_t*)kc.data.data();
+        for (uint64_t i = 0; i < ob.num_rows; ++i) {
+            const uint64_t dg = (uint64_t)(((unsigned __int128)(uint64_t)packed[i] / weight[c]) % digits[c]);
+            if (has_null[c] && dg == (uint64_t)(digits[c] - 1)) { d[i] = 0; kc.in_valid[i] = 0; }
+            else d[i] = mn[c] + (int64_t)dg;
+        }
+        ob.cols.push_back(std::move(kc));
+    }
+    for (uint32_t i = 0; i < na; ++i) ob.cols.push_back(std::move(g[0].cols[1 + i]));
+    out.push_back(std::move(ob));
+    return GOLAP_OK;
+}
+
 int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out) {
     const uint32_t na = (uint32_t)p.aggr_inputs.size();
+    if (p.group_by.size() > 1) return aggregate_multi_key(in, p, out);
     // NULL group keys: SQL puts them into ONE group of their own.  Only when the key column really carries NULLs: the rows are
     // split on the host, the rows with a key take the ordinary path below, the others an ungrouped aggregate, and the result
     // gets one more row whose key is NULL (last, like NULLS LAST).
@@ -760,7 +896,7 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
         // (GOLAP_KEYS_HASHED, aggregate_kernel.rs:76-77)
         const bool dense_keys = mmv[0] >= 0 && mmv[1] <= 9e15 && (mmv[1] - mmv[0]) < (double)(64ull << 20) && (mmv[1] - mmv[0]) <= 4.0 * (double)n + 1024.0;
         if (!dense_keys) {
-            const uint64_t bound = std::min<uint64_t>(n, 1ull << 22);   // distinct keys <= rows; the key table holds at most 2^22 groups
+            const uint64_t bound = std::min<uint64_t>(n, 1ull << 28);   // distinct keys <= rows; the key table holds at most 2^28 groups
             DevBuf dout, dcnt, dkeys, dn;
             H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * bound * 8));
             H_TRY(dcnt.alloc(ctx, bound * 8));
@@ -782,7 +918,7 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
             uint32_t nd = 0;
             H_TRY(d2h(dn.ptr, &nd, 4));
             H_TRY(xsync());
-            if (nd > bound) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^22 distinct group keys");
+            if (nd > bound) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^28 distinct group keys");
             std::vector<int64_t> gk(nd);
             std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * bound);
             if (nd) H_TRY(d2h(dkeys.ptr, gk.data(), (uint64_t)nd * 8));

@@ -158,6 +158,14 @@ int32_t golap_filter_compact(golap_ctx* ctx, const golap_filter_predicate* pred,
 /* The same with a validity byte per row (0 = NULL; 0 pointer = no NULLs): NULL rows never pass. */
 int32_t golap_filter_compact_nullable(golap_ctx* ctx, const golap_filter_predicate* pred, uint64_t column_ptr, uint64_t validity_ptr, uint64_t n_rows,
                                       uint64_t out_indices_ptr, uint64_t out_count_ptr, void* stream);
+/* Conjunction of up to GOLAP_FILTER_AND_MAX comparisons, each on its own int64 column (the same column may appear twice: a range), in
+ * ONE pass: a row passes when every comparison is true (a NULL operand makes a comparison not true).  optimizer.rs:155-159 merges
+ * stacked filters into `a AND b`; the reference's CPU mask has no AND (executor.rs:457-465 -> no row): SQL semantics here are an
+ * extension.  preds[k].col_index is informational; column_ptrs[k] / validity_ptrs[k] (0 = no NULLs; the array may be NULL) are
+ * host arrays of device pointers. */
+#define GOLAP_FILTER_AND_MAX 4
+int32_t golap_filter_compact_and(golap_ctx* ctx, const golap_filter_predicate* preds, const uint64_t* column_ptrs, const uint64_t* validity_ptrs,
+                                 uint32_t n_preds, uint64_t n_rows, uint64_t out_indices_ptr /*u32[n_rows]*/, uint64_t out_count_ptr /*u64*/, void* stream);
 /* take_int64, executor.rs:496-507: out[i] = col[indices[i]] for 8-byte columns (index 0xFFFFFFFF = NULL row -> 0). */
 int32_t golap_take_8byte(golap_ctx* ctx, uint64_t column_ptr, uint64_t indices_ptr, uint64_t count_ptr /*u64 device, or 0*/,
                          uint64_t n_indices_max, uint64_t out_ptr, void* stream);
@@ -440,6 +448,17 @@ enum { GOLAP_KEYS_DENSE = 0, GOLAP_KEYS_HASHED = 1 };
  * (group_key_ptr == 0, n_groups == 1) reproduces execute_aggregate. */
 int32_t golap_aggregate(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs,
                         const golap_aggregate_params* params, void* stream);
+
+/* GROUP BY over row-sharded inputs, one process per GPU (collective; same communicator as golap_sharded_join).  Same parameter
+ * structs as golap_aggregate, describing THIS rank's rows; every rank passes the same specs, key_mode and n_groups.
+ *   GOLAP_KEYS_DENSE (and ungrouped): local pre-aggregation, all-gather of the [statistic][group] tables, fold in rank order (a
+ *     fixed order: identical on every rank, reproducible) -- the result (out_ptr, out_count_ptr) is REPLICATED on every rank.
+ *   GOLAP_KEYS_HASHED: local pre-aggregation by key, partial groups exchanged by key hash (the join's partition function), merged by
+ *     the owner -- the result stays SHARDED: a key is reported by exactly one rank (out_keys_ptr / out_n_groups_ptr as
+ *     golap_aggregate; n_groups bounds the distinct keys of any one rank's input AND of any one rank's share of the result).
+ * Host-side failures before the exchange are agreed on like golap_sharded_join's (GOLAP_ERR_PEER).  Synchronises the stream. */
+int32_t golap_sharded_aggregate(golap_ctx* ctx, golap_comm* comm, const golap_aggregate_spec* specs, uint32_t n_specs,
+                                const golap_aggregate_params* params, void* stream);
 
 /* ---- arrow-interop -------------------------------------------------------
  * record_batch_convert.rs:35-110: numeric columns widened to 8-byte LE, nulls -> 0

@@ -203,6 +203,17 @@ def eval_filter_mask(col, op, literal):
     return mask
 
 
+def eval_filter_mask_and(cols, ops, literals, valids=None):
+    """Conjunction with SQL semantics (an EXTENSION: the reference's mask has no AND, executor.rs:457-465): the elementwise AND of the
+    reference's own per-comparison masks (eval_filter_mask), a NULL operand making its comparison not true."""
+    m = np.ones(len(cols[0]), dtype=bool)
+    for k, (c, o, l) in enumerate(zip(cols, ops, literals)):
+        m &= eval_filter_mask(c, o, l).astype(bool)
+        if valids is not None and valids[k] is not None:
+            m &= np.asarray(valids[k]).astype(bool)
+    return m
+
+
 def mask_to_indices(mask):
     mask = _c(mask, np.uint8)
     idx = np.empty(mask.size, np.uint32)

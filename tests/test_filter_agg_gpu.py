@@ -357,3 +357,24 @@ def test_aggregates_skip_null_values(ctx, shape):
             np.testing.assert_array_equal(out[pl], exp[:, st], err_msg=f"{shape}: column {col} {names[st]}")
     g0 = int(np.searchsorted(present, keys[0]))
     assert out[1, g0] == 0.0 and out[0, g0] == 0.0                 # the all-NULL group: COUNT 0, SUM 0
+
+
+@pytest.mark.parametrize("n", [1, 4095, 4097, 300_001])
+def test_filter_compact_and_matches_the_oracle(ctx, n):
+    """golap_filter_compact_and through the C ABI: 2 to 4 comparisons on 2 to 3 columns (one column twice: a range), with and without
+    validity, every operator incl. an unknown one (selects nothing), against the AND of the oracle's per-comparison masks."""
+    rng = np.random.default_rng(n)
+    cols = [rng.integers(-50, 50, n).astype(np.int64) for _ in range(3)]
+    valid = [None, (rng.random(n) > 0.2).astype(np.uint8), None]
+    tc = [torch.from_numpy(c).cuda() for c in cols]
+    tv = [None if v is None else torch.from_numpy(v).cuda() for v in valid]
+    cases = [([0, 0], [">=", "<"], [-10, 20]), ([0, 1, 2], ["<", "!=", ">"], [30, 0, -40]), ([2, 1, 0, 2], ["<=", ">", "=", "<>"], [45, -45, 3, 7]),
+             ([0, 1], ["<", "~"], [10, 10])]
+    for which, ops, lits in cases:
+        for use_valid in (False, True):
+            idx, cnt = ctx.filter_compact_and([tc[w] for w in which], ops, lits, valids=[tv[w] for w in which] if use_valid else None)
+            torch.cuda.synchronize()
+            m = oracle.eval_filter_mask_and([cols[w] for w in which], ops, lits, [valid[w] for w in which] if use_valid else None)
+            k = int(cnt.item())
+            assert k == int(m.sum())
+            assert np.array_equal(idx[:k].cpu().numpy().view(np.uint32), np.nonzero(m)[0].astype(np.uint32))

@@ -291,12 +291,14 @@ def test_asymmetric_sides_mix_first_pass_forms(ctx, nb, npr):
         assert int(v[0]) == npr and int(v[2]) == npr * (npr - 1) // 2
 
 
-@pytest.mark.parametrize("shape", ["narrow", "common_upper_half", "negative_small", "two_upper_halves", "one_wide_key_last", "negative_key_first"])
+@pytest.mark.parametrize("shape", ["narrow", "common_upper_half", "negative_small", "two_upper_halves", "negative_and_positive", "four_upper_halves",
+                                   "five_upper_halves", "many_upper_halves", "one_wide_key_last", "negative_key_first", "two_halves_and_one_odd_key_last"])
 def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
-    """Large joins first try 8-byte (key32, row id) tuples, which stand while every key of both sides shares its upper 32 bits with
-    the first build key (0 for small ids, but also keys offset by 2^40, or small negative keys); any other key -- in the first
-    tile or in the very last row -- must hand the whole join over to the 64-bit pipeline on the device, with identical results
-    (checked on the device: every pair key-equal, probe ids a permutation)."""
+    """Large joins first try 8-byte (key32, row id) tuples, which stand while the keys of both sides have at most four different
+    upper halves (one: 0 for small ids, but also keys offset by 2^40, or small negative keys; two to four: a dictionary index rides
+    in the tuple, e.g. small negative NEXT TO small positive keys); a fifth upper half -- in the sample, in the first tile or in the
+    very last row -- must hand the whole join over to the 64-bit pipeline on the device, with identical results (checked on the
+    device: every pair key-equal, probe ids a permutation)."""
     n = 60_000_000
     bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
     pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
@@ -310,6 +312,23 @@ def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
     elif shape == "two_upper_halves":
         bt += (bt & 1) << 40
         pt += (pt & 1) << 40
+    elif shape == "negative_and_positive":
+        bt -= n // 2
+        pt -= n // 2
+    elif shape in ("four_upper_halves", "five_upper_halves"):
+        k = 4 if shape.startswith("four") else 5
+        bt += (bt % k) << 40
+        pt += (pt % k) << 40
+    elif shape == "many_upper_halves":
+        bt += ((bt * 0x9E3779B1) & 0xFFFF) << 32
+        pt += ((pt * 0x9E3779B1) & 0xFFFF) << 32
+    elif shape == "two_halves_and_one_odd_key_last":
+        bt += (bt & 1) << 40
+        pt += (pt & 1) << 40
+        old = int(bt[n - 1].item())
+        bt[n - 1] = (5 << 40) + 11
+        pt[n - 1] = (5 << 40) + 11                                     # a third upper half the sample cannot have seen
+        orphans = int((pt == old).sum().item())
     elif shape != "narrow":
         idx, key = (n - 1, (1 << 35) + 7) if shape == "one_wide_key_last" else (0, -5)
         old = int(bt[idx].item())
@@ -326,7 +345,9 @@ def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
     if orphans == 0:
         assert int(v[2]) == n * (n - 1) // 2                           # every probe row exactly once
     wide_ms, narrow_ms = st["join_build_probe_lds_wide"]["total_ms"], st["join_build_probe_lds"]["total_ms"]
-    tuples = shape in ("narrow", "common_upper_half", "negative_small")
+    # (negative_key_first: the first build key is the dictionary's first entry, every other key's upper half its second -- tuples;
+    #  one_wide_key_last: no sample sees the odd key, the first pass meets it in its last tile and hands over)
+    tuples = shape in ("narrow", "common_upper_half", "negative_small", "two_upper_halves", "negative_and_positive", "four_upper_halves", "negative_key_first")
     assert (wide_ms < narrow_ms) if tuples else (wide_ms > narrow_ms)   # which pipeline did the work (the other returns at once)
 
 

@@ -175,3 +175,15 @@ def test_multi_column_null_aware_join_vs_brute_force(seed, jt):
     exp = T.canonical(np.array(pairs, np.uint32).reshape(-1, 2))
     got, m = oracle.hash_join_multi(bc, pc, jt, bv, pv)
     assert m == exp.shape[0] and np.array_equal(got, exp)
+
+
+def test_filter_conjunction_is_the_and_of_the_reference_masks():
+    """eval_filter_mask_and (an extension: the reference's mask has no AND, executor.rs:457-465) = AND of the per-comparison reference masks;
+    checked against plain numpy comparisons, with a NULL operand making a comparison not true."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(-20, 20, 5000).astype(np.int64)
+    b = rng.integers(0, 9, 5000).astype(np.int64)
+    va = (rng.random(5000) > 0.3).astype(np.uint8)
+    m = oracle.eval_filter_mask_and([a, a, b], [">=", "<", "!="], [-5, 12, 4], [va, va, None])
+    assert np.array_equal(m, (a >= -5) & (a < 12) & (b != 4) & va.astype(bool))
+    assert not oracle.eval_filter_mask_and([a, b], ["<", "~"], [100, 1]).any()     # an unknown operator selects nothing (executor.rs:464)

@@ -377,3 +377,90 @@ def test_a_failing_rank_takes_every_rank_out_of_the_call(mode):
     exp, me = _expected(n, "unique", 0, world, -1)
     got = canonical(np.concatenate([r[3] for r in res]))
     assert got.shape[0] == me and np.array_equal(got, exp)
+
+
+def _worker_agg(rank, world, port, n, groups, hashed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from gpu_olap_engine_amd import _native as N
+        from gpu_olap_engine_amd.distributed import NativeShardedJoin
+        from gpu_olap_engine_amd.engine import Context, shard_range
+        torch.cuda.set_device(0)
+        c = Context(max_gpu_memory=0)
+        lo, hi = shard_range(n, rank, world)
+        k, v, vn = _agg_rows(n, groups, hashed)
+        kt = torch.from_numpy(k[lo:hi]).cuda()
+        vt = torch.from_numpy(v[lo:hi]).cuda()
+        vv = torch.from_numpy((~vn[lo:hi]).astype(np.uint8)).cuda()
+        sj = NativeShardedJoin(c, transport="staged")
+        specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0)]
+        if hashed:
+            out, cnt, okeys, ong = sj.comm.sharded_aggregate(specs, [vt], group_keys=kt, n_groups=groups + 8, want_counts=True, hashed=True, value_valid=[vv])
+            torch.cuda.synchronize()
+            g = int(ong.item())
+            q.put((rank, okeys[:g].cpu().numpy(), out[:, :g].cpu().numpy(), cnt[:g].cpu().numpy()))
+        else:
+            out, cnt = sj.comm.sharded_aggregate(specs, [vt], group_keys=kt, n_groups=groups, want_counts=True, value_valid=[vv])
+            torch.cuda.synchronize()
+            q.put((rank, None, out.cpu().numpy(), cnt.cpu().numpy()))
+        dist.barrier()
+        sj.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _agg_rows(n, groups, hashed):
+    rng = np.random.default_rng(groups * 7 + n)
+    ids = rng.integers(0, groups, n)
+    k = (ids * 1_000_003 - 5_000_000_000).astype(np.int64) if hashed else ids.astype(np.int64)   # hashed: sparse, negative and positive keys
+    v = rng.integers(-1000, 1000, n).astype(np.float64)
+    vn = rng.random(n) < 0.05                                                                   # NULL values
+    return k, v, vn
+
+
+@pytest.mark.parametrize("world,groups,hashed", [(2, 1000, False), (4, 200_000, False), (2, 5000, True), (4, 300_000, True)])
+def test_sharded_aggregate_ranks_share_one_gpu(world, groups, hashed):
+    """golap_sharded_aggregate (C++, the join's communicator) with 2 and 4 ranks on one GPU through the staged transport: SUM / COUNT /
+    MIN / MAX / AVG with NULL values, dense keys (replicated result, identical on every rank) and hashed keys (sharded result: every
+    key on exactly one rank), against a numpy GROUP BY of the whole table."""
+    import torch.multiprocessing as mp
+    n = 1_500_000
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_agg, args=(r, world, port, n, groups, hashed, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    k, v, vn = _agg_rows(n, groups, hashed)
+    uk, inv = np.unique(k, return_inverse=True)
+    live = ~vn
+    G = uk.size
+    s = np.zeros(G); np.add.at(s, inv[live], v[live])
+    c = np.zeros(G); np.add.at(c, inv[live], 1.0)
+    mn = np.full(G, np.finfo(np.float64).max); np.minimum.at(mn, inv[live], v[live])
+    mx = np.full(G, -np.finfo(np.float64).max); np.maximum.at(mx, inv[live], v[live])
+    avg = np.where(c > 0, s / np.maximum(c, 1), 0.0)
+    exp = np.stack([s, c, mn, mx, avg])
+    if hashed:
+        keys = np.concatenate([r[1] for r in res])
+        outs = np.concatenate([r[2] for r in res], axis=1)
+        cnts = np.concatenate([r[3] for r in res])
+        assert keys.size == G and np.unique(keys).size == G                 # every key on exactly one rank
+        order = np.argsort(keys)
+        assert np.array_equal(keys[order], uk)
+        assert np.array_equal(outs[:, order], exp) and np.array_equal(cnts[order].astype(np.float64), c)
+        assert all(r[1].size > 0 for r in res)                               # and the result is spread over the ranks
+    else:
+        full = np.zeros((5, groups)); full[2] = np.finfo(np.float64).max; full[3] = -np.finfo(np.float64).max
+        full[:, uk] = exp
+        for r in res:                                                        # replicated, bit-identical on every rank
+            assert np.array_equal(r[2], full) and np.array_equal(r[3].astype(np.float64), full[1])
