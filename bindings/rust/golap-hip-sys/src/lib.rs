@@ -151,6 +151,12 @@ pub struct golap_sharded_join_params {
     pub join_type: i32,
     pub force_exact: i32,
     pub max_msg_bytes: u64,
+    pub n_key_cols: u32,
+    pub reserved0: u32,
+    pub build_key_extra: [u64; 3],
+    pub probe_key_extra: [u64; 3],
+    pub build_validity: [u64; 4],
+    pub probe_validity: [u64; 4],
 }
 
 /// what the last `golap_sharded_join` on a communicator did; `stage_ms[stage][begin, end]` in ms since the call's first kernel
@@ -285,6 +291,7 @@ extern "C" {
                            stream: *mut c_void) -> i32;
     // ---- arrow-interop widening (record_batch_convert.rs:35-110) ----
     pub fn golap_widen_to_8byte(ctx: *mut golap_ctx, in_ptr: u64, in_dtype: i32, validity_ptr: u64, n_rows: u64, out_ptr: u64, stream: *mut c_void) -> i32;
+    pub fn golap_hash_utf8(ctx: *mut golap_ctx, offsets_ptr: u64, data_ptr: u64, validity_ptr: u64, n_rows: u64, out_ptr: u64, stream: *mut c_void) -> i32;
     // ---- multi-GPU (no counterpart in the reference, README.md:414) ----
     pub fn golap_comm_unique_id(out_id: *mut u8) -> i32;
     pub fn golap_comm_create_rccl(ctx: *mut golap_ctx, id: *const u8, world: i32, rank: i32, out: *mut *mut golap_comm) -> i32;

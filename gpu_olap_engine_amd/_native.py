@@ -116,7 +116,9 @@ class ShardedJoinParams(C.Structure):
                 ("build_rid_base", C.c_uint32), ("probe_rid_base", C.c_uint32), ("n_build_total", C.c_uint64), ("n_probe_total", C.c_uint64),
                 ("build_rows_per_rank", C.POINTER(C.c_uint64)), ("probe_rows_per_rank", C.POINTER(C.c_uint64)),
                 ("out_pairs_ptr", C.c_uint64), ("out_count_ptr", C.c_uint64), ("max_pairs", C.c_uint64),
-                ("join_type", C.c_int32), ("force_exact", C.c_int32), ("max_msg_bytes", C.c_uint64)]
+                ("join_type", C.c_int32), ("force_exact", C.c_int32), ("max_msg_bytes", C.c_uint64),
+                ("n_key_cols", C.c_uint32), ("reserved0", C.c_uint32), ("build_key_extra", C.c_uint64 * 3), ("probe_key_extra", C.c_uint64 * 3),
+                ("build_validity", C.c_uint64 * 4), ("probe_validity", C.c_uint64 * 4)]
 
 
 class ShardedJoinInfo(C.Structure):
@@ -211,6 +213,7 @@ SIGNATURES = {
     "golap_aggregate": (C.c_int32, [_VP, _P(AggregateSpec), C.c_uint32, _P(AggregateParams), _VP]),
     "golap_sharded_aggregate": (C.c_int32, [_VP, _VP, _P(AggregateSpec), C.c_uint32, _P(AggregateParams), _VP]),
     "golap_widen_to_8byte": (C.c_int32, [_VP, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_hash_utf8": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_generate": (C.c_int32, [_VP, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_verify_pairs": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _VP]),
     "golap_stats_get": (C.c_int32, [_VP, _P(Stats)]),

@@ -914,6 +914,17 @@ __global__ __launch_bounds__(OP_THREADS) void k_widen(const In* __restrict__ in,
         out[i] = (validity && !validity[i]) ? (Out)0 : (Out)in[i];
 }
 
+// Utf8 -> FNV-1a 64 (record_batch_convert.rs:123-130), one value per thread; NULL -> 0 (:112-121)
+__global__ __launch_bounds__(OP_THREADS) void k_hash_utf8(const long long* __restrict__ off, const uint8_t* __restrict__ data, const uint8_t* __restrict__ valid,
+                                                          unsigned long long n, long long* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long h = 14695981039346656037ull;
+        if (valid && !valid[i]) { out[i] = 0; continue; }
+        for (long long j = off[i], e = off[i + 1]; j < e; ++j) { h ^= (unsigned long long)data[j]; h *= 1099511628211ull; }
+        out[i] = (long long)h;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // generators
 // ---------------------------------------------------------------------------
@@ -1590,6 +1601,21 @@ int32_t golap_widen_to_8byte(golap_ctx* ctx, uint64_t in_ptr, int32_t in_dtype, 
         case GOLAP_WIDEN_F64: hipLaunchKernelGGL((k_widen<double, double>), g, b, 0, st, (const double*)in_ptr, v, n, (double*)out_ptr); break;
         default: return fail(ctx, GOLAP_ERR_INVALID_ARG, "unsupported column type for GPU conversion: %d", in_dtype);   // record_batch_convert.rs:98
     }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+int32_t golap_hash_utf8(golap_ctx* ctx, uint64_t offsets_ptr, uint64_t data_ptr, uint64_t validity_ptr, uint64_t n_rows, uint64_t out_ptr, void* stream) {
+    if (!ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null ctx");
+    if (n_rows == 0) return GOLAP_OK;
+    if (!offsets_ptr || !out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    KernelTimer t(ctx, "hash_utf8", st, 16 * n_rows);
+    hipLaunchKernelGGL(k_hash_utf8, dim3(stream_grid(ctx, n_rows, OP_THREADS)), dim3(OP_THREADS), 0, st, (const long long*)offsets_ptr, (const uint8_t*)data_ptr,
+                       (const uint8_t*)validity_ptr, (unsigned long long)n_rows, (long long*)out_ptr);
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     return GOLAP_OK;
 }

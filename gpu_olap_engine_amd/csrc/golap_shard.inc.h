@@ -934,14 +934,160 @@ int32_t golap_sharded_join_info_get(golap_comm* cm, golap_sharded_join_info* out
     return GOLAP_OK;
 }
 
-int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, void* stream) {
-    if (!ctx || !cm || !p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+}  // extern "C"
+
+namespace golap {
+
+// ---------------------------------------------------------------------------
+// composite keys and NULLs on the sharded join: the ranks agree on every key column's value range and join on the exact
+// mixed-radix number of the digits (value - min); a row with a NULL in any key column gets a key no other row has
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_key_minmax(const long long* __restrict__ col, const uint8_t* __restrict__ valid, unsigned long long n,
+                                                    long long* __restrict__ out /*[0] min, [1] max (of the valid rows)*/) {
+    long long mn = INT64_MAX, mx = INT64_MIN;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        if (!valid || valid[i]) { const long long v = col[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const long long a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mn != INT64_MAX) __hip_atomic_fetch_min(&out[0], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mx != INT64_MIN) __hip_atomic_fetch_max(&out[1], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+struct PackCols {
+    const long long* col[4];
+    const uint8_t* valid[4];
+    long long mn[4];
+    unsigned long long weight[4];
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void k_pack_keys(PackCols pc, unsigned long long n, unsigned long long null_base, long long* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long key = 0;
+        bool null = false;
+        for (uint32_t c = 0; c < pc.n; ++c) {
+            null = null || (pc.valid[c] && !pc.valid[c][i]);
+            key += (unsigned long long)(pc.col[c][i] - pc.mn[c]) * pc.weight[c];
+        }
+        out[i] = (long long)(null ? null_base + i : key);   // NULL rows: 2^62 + side * 2^61 + global row id -- above every packed key, unique
+    }
+}
+
+// -> *packed_b / *packed_p: device int64 columns (slabs in `hold`) that replace the key columns; collective (one all-gather + host read)
+static int32_t shard_pack_keys(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, hipStream_t st, SlabHold& hold, uint64_t* packed_b,
+                               uint64_t* packed_p) {
+    const uint32_t P = (uint32_t)cm->world, K = std::max<uint32_t>(1, p->n_key_cols);
+    const uint64_t n[2] = {p->n_build_local, p->n_probe_local};
+    uint64_t cols[2][4], valids[2][4];
+    for (uint32_t c = 0; c < K; ++c) {
+        cols[0][c] = c ? p->build_key_extra[c - 1] : p->build_key_ptr;
+        cols[1][c] = c ? p->probe_key_extra[c - 1] : p->probe_key_ptr;
+        valids[0][c] = p->build_validity[c];
+        valids[1][c] = p->probe_validity[c];
+    }
+    uint64_t d_mm = 0, d_all = 0;
+    auto prepare = [&]() -> int32_t {
+        if (K > 4) return fail(ctx, GOLAP_ERR_INVALID_ARG, "at most 4 key columns");
+        for (int side = 0; side < 2; ++side)
+            for (uint32_t c = 0; c < K; ++c)
+                if (n[side] && !cols[side][c]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null key column %u", c);
+        *packed_b = hold.take(std::max<uint64_t>(1, n[0]) * 8);
+        *packed_p = hold.take(std::max<uint64_t>(1, n[1]) * 8);
+        d_mm = hold.take(256);
+        d_all = hold.take((uint64_t)P * 64 + 256);
+        if (!*packed_b || !*packed_p || !d_mm || !d_all) return fail(ctx, GOLAP_ERR_OOM, "sharded join: packed key columns");
+        GOLAP_TRY(ensure_host_words(cm, (uint64_t)P * 64 + 64));
+        return GOLAP_OK;
+    };
+    GOLAP_TRY(shard_agree(ctx, cm, prepare()));
+    // value range of every key column over BOTH sides of this rank, then over all ranks
+    long long init[8];
+    for (uint32_t c = 0; c < 4; ++c) { init[2 * c] = INT64_MAX; init[2 * c + 1] = INT64_MIN; }
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)d_mm, init, 64, hipMemcpyHostToDevice, st));
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    for (int side = 0; side < 2; ++side)
+        for (uint32_t c = 0; c < K && n[side]; ++c)
+            hipLaunchKernelGGL(k_key_minmax, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 8, ceil_div(n[side], 2048)))), dim3(256), 0, st,
+                               (const long long*)cols[side][c], (const uint8_t*)valids[side][c], (unsigned long long)n[side], (long long*)d_mm + 2 * c);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_misc, st));
+    GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_misc, 0));
+    GOLAP_TRY(comm_all_gather(cm, d_mm, d_all, 64, cm->stream));
+    long long* h = (long long*)cm->h_status;
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync(h, (const void*)d_all, (size_t)P * 64, hipMemcpyDeviceToHost, cm->stream));
+    GOLAP_HIP_TRY(ctx, hipStreamSynchronize(cm->stream));
+    cm->info.host_syncs += 1;
+    PackCols pc[2];
+    memset(pc, 0, sizeof pc);
+    unsigned __int128 total = 1;
+    long long mn[4], mx[4];
+    for (uint32_t c = 0; c < K; ++c) {
+        mn[c] = INT64_MAX; mx[c] = INT64_MIN;
+        for (uint32_t r = 0; r < P; ++r) { mn[c] = std::min(mn[c], h[r * 8 + 2 * c]); mx[c] = std::max(mx[c], h[r * 8 + 2 * c + 1]); }
+        if (mn[c] > mx[c]) mn[c] = mx[c] = 0;   // no valid value anywhere
+    }
+    unsigned long long weight[4] = {1, 1, 1, 1};
+    for (uint32_t c = K; c-- > 0;) {
+        weight[c] = (unsigned long long)total;
+        total *= (unsigned __int128)((__int128)mx[c] - (__int128)mn[c]) + 1;
+        if (total > ((unsigned __int128)1 << 62))   // (the same numbers on every rank: every rank refuses)
+            return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: the composite key does not fit 62 bits (column %u spans %.0f values)", c,
+                        (double)((__int128)mx[c] - (__int128)mn[c]) + 1.0);
+    }
+    for (int side = 0; side < 2; ++side) {
+        pc[side].n = K;
+        for (uint32_t c = 0; c < K; ++c) {
+            pc[side].col[c] = (const long long*)cols[side][c];
+            pc[side].valid[c] = (const uint8_t*)valids[side][c];
+            pc[side].mn[c] = mn[c];
+            pc[side].weight[c] = weight[c];
+        }
+        if (!n[side]) continue;
+        const unsigned long long null_base = (1ull << 62) + ((unsigned long long)side << 61) + (side ? p->probe_rid_base : p->build_rid_base);
+        hipLaunchKernelGGL(k_pack_keys, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 8, ceil_div(n[side], 1024)))), dim3(256), 0, st, pc[side],
+                           (unsigned long long)n[side], null_base, (long long*)(side ? *packed_p : *packed_b));
+    }
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+}  // namespace golap
+
+extern "C" {
+
+int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p_in, void* stream) {
+    if (!ctx || !cm || !p_in) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
     if (cm->ctx != ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "communicator belongs to another context");
     std::lock_guard<std::mutex> lk(ctx->mu);
     KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
     memset(&cm->info, 0, sizeof cm->info);
+    // composite keys / NULLs: the key columns are replaced by ONE exact int64 column per side first (every rank takes this branch
+    // or none: n_key_cols and the presence of validity arrays are part of the query, not of the data)
+    golap_sharded_join_params p_local = *p_in;
+    const golap_sharded_join_params* p = &p_local;
+    SlabHold packed_hold(ctx);
+    struct PackedSync {   // the packed columns are read by kernels of this call: they go back to the pool only when the stream is done
+        hipStream_t st; bool on = false;
+        ~PackedSync() { if (on) (void)hipStreamSynchronize(st); }
+    } packed_sync{st};
+    bool general = p_in->n_key_cols > 1;
+    for (int c = 0; c < 4; ++c) general = general || p_in->build_validity[c] || p_in->probe_validity[c];
+    if (general) {
+        uint64_t pb = 0, pp = 0;
+        packed_sync.on = true;
+        GOLAP_TRY(shard_pack_keys(ctx, cm, p_in, st, packed_hold, &pb, &pp));
+        p_local.build_key_ptr = pb;
+        p_local.probe_key_ptr = pp;
+        p_local.n_key_cols = 1;
+        memset(p_local.build_validity, 0, sizeof p_local.build_validity);
+        memset(p_local.probe_validity, 0, sizeof p_local.probe_validity);
+    }
+
     // The call is collective: an argument error on ONE rank must not leave the others waiting in the exchange.  It becomes this
     // rank's agreement word (shard_agree): every rank leaves the call together, this one with its error, the others with
     // GOLAP_ERR_PEER.  (The plan below only reads the totals and row-count lists, which every rank passes identically.)

@@ -399,12 +399,13 @@ class NativeShardedJoin:
             raise ValueError("transport must be 'rccl' or 'staged'")
 
     def join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, n_probe_total=None, out_pairs=None,
-             max_pairs=None, join_type=0, force_exact=False, build_rows_per_rank=None, probe_rows_per_rank=None):
+             max_pairs=None, join_type=0, force_exact=False, build_rows_per_rank=None, probe_rows_per_rank=None, build_valid=None,
+             probe_valid=None):
         """-> (pairs int32[.,2] with GLOBAL u32 row ids, count int64[1] device, info dict)."""
         pairs, cnt = self.comm.sharded_join(build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, n_probe_total,
                                             out_pairs=out_pairs, max_pairs=max_pairs, join_type=join_type, force_exact=force_exact,
                                             max_msg_bytes=self.max_msg_bytes, build_rows_per_rank=build_rows_per_rank,
-                                            probe_rows_per_rank=probe_rows_per_rank)
+                                            probe_rows_per_rank=probe_rows_per_rank, build_valid=build_valid, probe_valid=probe_valid)
         return pairs, cnt, self.comm.info()
 
     def close(self):

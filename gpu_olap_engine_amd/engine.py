@@ -410,6 +410,14 @@ class Context:
         self._ck(self._lib.golap_widen_to_8byte(self._h, _ptr(column), code, _ptr(validity), column.numel(), _ptr(out), _stream()))
         return out
 
+    def hash_utf8(self, offsets, data, valid=None):
+        """golap_hash_utf8: FNV-1a 64 of every value of a Utf8 column (offsets int64[n + 1], data uint8 bytes; NULL rows -> 0) -> int64[n]."""
+        _chk_tensor(offsets, torch.int64, "offsets")
+        n = offsets.numel() - 1
+        out = torch.empty(max(n, 0), dtype=torch.int64, device=offsets.device)
+        self._ck(self._lib.golap_hash_utf8(self._h, _ptr(offsets), _ptr(data), _ptr(valid), max(n, 0), _ptr(out), _stream()))
+        return out
+
     # ---- generators / verifier ---------------------------------------------------
     def generate(self, kind, count, modulus=1, seed=0, first=0, out=None):
         dt = {N.GEN_BUILD_KEYS: torch.int64, N.GEN_SM64_MOD_I64: torch.int64, N.GEN_SM64_MOD_I32: torch.int32,
@@ -480,12 +488,19 @@ class Comm:
 
     def sharded_join(self, build_keys, probe_keys, build_rid_base, probe_rid_base, n_build_total, n_probe_total=None, out_pairs=None,
                      max_pairs=None, out_count=None, join_type=0, force_exact=False, max_msg_bytes=0, build_rows_per_rank=None,
-                     probe_rows_per_rank=None):
+                     probe_rows_per_rank=None, build_valid=None, probe_valid=None):
         """golap_sharded_join (collective).  -> (pairs int32[max_pairs,2] with GLOBAL u32 row ids, count int64[1] device).
         *_rows_per_rank: the row count of every rank's shard (sequences of world ints) when the split is not shard_range's even one --
-        every rank must pass the same lists (the fast path sizes its messages from them without asking anybody)."""
-        _chk_tensor(build_keys, torch.int64, "build_keys")
-        _chk_tensor(probe_keys, torch.int64, "probe_keys")
+        every rank must pass the same lists (the fast path sizes its messages from them without asking anybody).
+        build_keys / probe_keys: one int64 tensor, or a list of up to 4 (a composite key); *_valid: None or a list (one entry per key
+        column) of None | uint8 tensors, 0 = NULL (such rows match nothing)."""
+        bcols = list(build_keys) if isinstance(build_keys, (list, tuple)) else [build_keys]
+        pcols = list(probe_keys) if isinstance(probe_keys, (list, tuple)) else [probe_keys]
+        if len(bcols) != len(pcols) or not 1 <= len(bcols) <= 4:
+            raise ValueError("1 to 4 key columns, the same number on both sides")
+        for t in bcols + pcols:
+            _chk_tensor(t, torch.int64, "key column")
+        build_keys, probe_keys = bcols[0], pcols[0]
         if n_probe_total is None:
             n_probe_total = n_build_total
         if out_pairs is None:
@@ -505,6 +520,16 @@ class Comm:
         prm = N.ShardedJoinParams(_ptr(build_keys), _ptr(probe_keys), build_keys.numel(), probe_keys.numel(), build_rid_base, probe_rid_base,
                                   n_build_total, n_probe_total, brows, prows, _ptr(out_pairs), _ptr(out_count), max_pairs, join_type,
                                   1 if force_exact else 0, max_msg_bytes)
+        prm.n_key_cols = len(bcols)
+        for c in range(1, len(bcols)):
+            prm.build_key_extra[c - 1] = _ptr(bcols[c])
+            prm.probe_key_extra[c - 1] = _ptr(pcols[c])
+        for side_valid, dst in ((build_valid, prm.build_validity), (probe_valid, prm.probe_validity)):
+            if side_valid is not None:
+                for c, v in enumerate(side_valid):
+                    if v is not None:
+                        _chk_tensor(v, torch.uint8, "validity column")
+                        dst[c] = _ptr(v)
         self.ctx._ck(self.ctx._lib.golap_sharded_join(self.ctx._h, self._h, C.byref(prm), _stream()))
         return out_pairs, out_count
 

@@ -28,7 +28,7 @@ namespace {
 // ---------------------------------------------------------------------------
 // host RecordBatch
 // ---------------------------------------------------------------------------
-enum class DType { Int64, Float64, Int32, Other };
+enum class DType { Int64, Float64, Int32, Utf8Raw, Other };
 
 struct Column {
     std::string name;
@@ -40,6 +40,11 @@ struct Column {
                                      // match nothing), GpuAggregate skips NULL values and puts NULL group keys into a group of their own
     uint64_t null_count = 0;
     uint64_t rows = 0;
+    // Utf8 / LargeUtf8 as imported: value i = str_bytes[str_off[i] .. str_off[i + 1]).  golap_execute turns such a column into its
+    // FNV-1a 64 hashes on the device before any operator runs (record_batch_convert.rs:93-97, :112-130: the reference's GPU columns
+    // hold the hash, null -> 0): from then on it is an Int64 column.
+    std::vector<int64_t> str_off;
+    std::vector<uint8_t> str_bytes;
     size_t width() const { return dtype == DType::Int32 ? 4 : 8; }
 };
 
@@ -64,7 +69,7 @@ DType dtype_of_format(const char* f) {
     if (!strcmp(f, "l")) return DType::Int64;
     if (!strcmp(f, "g")) return DType::Float64;
     if (!strcmp(f, "i")) return DType::Int32;
-    return DType::Other;
+    return DType::Other;   // ("u" / "U" strings become DType::Utf8Raw in import_batch)
 }
 const char* format_of_dtype(DType d) { return d == DType::Int64 ? "l" : d == DType::Float64 ? "g" : d == DType::Int32 ? "i" : "n"; }
 
@@ -79,7 +84,31 @@ bool import_batch(ArrowArray* arr, ArrowSchema* sch, RecordBatch& out, std::stri
         col.name = cs->name ? cs->name : "";
         col.dtype = dtype_of_format(cs->format);
         col.rows = out.num_rows;
-        if (col.dtype != DType::Other) {
+        if (cs->format && (!strcmp(cs->format, "u") || !strcmp(cs->format, "U"))) {
+            const bool large = cs->format[0] == 'U';
+            const int64_t off = ca->offset + arr->offset;
+            const uint8_t* valid = ca->n_buffers >= 1 ? (const uint8_t*)ca->buffers[0] : nullptr;
+            if (ca->n_buffers < 3 || (out.num_rows && (!ca->buffers[1] || !ca->buffers[2]))) {
+                if (out.num_rows) { err = "string column '" + col.name + "' has no offsets / data buffer"; return false; }
+            }
+            col.dtype = DType::Utf8Raw;
+            col.str_off.resize((size_t)out.num_rows + 1, 0);
+            int64_t first = 0, last = 0;
+            for (uint64_t i = 0; i <= out.num_rows && out.num_rows; ++i) {
+                const int64_t o = large ? ((const int64_t*)ca->buffers[1])[off + (int64_t)i] : (int64_t)((const int32_t*)ca->buffers[1])[off + (int64_t)i];
+                if (i == 0) first = o;
+                col.str_off[i] = o - first;
+                last = o;
+            }
+            if (out.num_rows) col.str_bytes.assign((const uint8_t*)ca->buffers[2] + first, (const uint8_t*)ca->buffers[2] + last);
+            if (valid && ca->null_count != 0) {
+                col.in_valid.assign((size_t)out.num_rows, 1);
+                for (uint64_t i = 0; i < out.num_rows; ++i) {
+                    const int64_t j = off + (int64_t)i;
+                    if (!((valid[j >> 3] >> (j & 7)) & 1)) col.in_valid[i] = 0;
+                }
+            }
+        } else if (col.dtype != DType::Other) {
             const size_t w = col.width();
             col.data.resize((size_t)out.num_rows * w);
             const uint8_t* src = ca->n_buffers >= 2 ? (const uint8_t*)ca->buffers[1] : nullptr;
@@ -275,6 +304,7 @@ struct Exec {
     int32_t hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out);
     int32_t aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
     int32_t aggregate_multi_key(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
+    int32_t hash_strings(golap_plan& p);
 };
 
 bool parse_i64(const std::string& s, int64_t& v) {
@@ -992,6 +1022,42 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
     return GOLAP_OK;
 }
 
+// record_batch_to_gpu_buffers for Utf8 columns (record_batch_convert.rs:93-97, :112-130): every string column of every input batch
+// becomes its FNV-1a 64 hashes (as Int64, null -> 0) -- on the device: offsets and bytes go up, one thread hashes one value.  From
+// here on the column is what the reference's GPU path sees: an 8-byte key that joins, groups and filters like any Int64 (two different
+// strings with the same 64-bit hash are one key, as in the reference; the column comes back as its hash).
+int32_t Exec::hash_strings(golap_plan& p) {
+    if (p.input) H_TRY(hash_strings(*p.input));
+    if (p.right) H_TRY(hash_strings(*p.right));
+    for (RecordBatch& b : p.batches)
+        for (Column& c : b.cols) {
+            if (c.dtype != DType::Utf8Raw) continue;
+            const uint64_t n = b.num_rows;
+            c.data.assign(n * 8, 0);
+            if (n) {
+                DevBuf doff, dbytes, dvalid, dout;
+                H_TRY(doff.alloc(ctx, (n + 1) * 8));
+                H_TRY(dbytes.alloc(ctx, std::max<size_t>(c.str_bytes.size(), 8)));
+                H_TRY(dout.alloc(ctx, n * 8));
+                H_TRY(h2d(c.str_off.data(), doff.ptr, (n + 1) * 8));
+                if (!c.str_bytes.empty()) H_TRY(h2d(c.str_bytes.data(), dbytes.ptr, c.str_bytes.size()));
+                if (!c.in_valid.empty()) {
+                    H_TRY(dvalid.alloc(ctx, n));
+                    H_TRY(h2d(c.in_valid.data(), dvalid.ptr, n));
+                }
+                H_TRY(xsync());
+                H_TRY(golap_hash_utf8(ctx, doff.ptr, dbytes.ptr, c.in_valid.empty() ? 0 : dvalid.ptr, n, dout.ptr, nullptr));
+                H_TRY(ksync());
+                H_TRY(d2h(dout.ptr, c.data.data(), n * 8));
+                H_TRY(xsync());
+            }
+            c.dtype = DType::Int64;
+            c.str_off.clear(); c.str_off.shrink_to_fit();
+            c.str_bytes.clear(); c.str_bytes.shrink_to_fit();
+        }
+    return GOLAP_OK;
+}
+
 // GpuExecutor::execute, executor.rs:37-104: children fully materialised before the parent runs
 int32_t Exec::run(golap_plan& p, std::vector<RecordBatch>& out) {
     switch (p.kind) {
@@ -1130,7 +1196,8 @@ int32_t golap_execute(golap_ctx* ctx, golap_plan* plan, golap_result** out_resul
     g_err.clear();
     Exec ex{ctx};
     auto res = std::make_unique<golap_result>();
-    int32_t s = ex.run(*plan, res->batches);
+    int32_t s = ex.hash_strings(*plan);
+    if (s == GOLAP_OK) s = ex.run(*plan, res->batches);
     if (s != GOLAP_OK) {
         if (g_err.empty()) g_err = golap_last_error(ctx);
         if (g_err.empty()) g_err = golap_last_error(nullptr);

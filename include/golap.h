@@ -357,6 +357,15 @@ typedef struct golap_sharded_join_params {
     int32_t  join_type;                          /* as golap_join_params */
     int32_t  force_exact;                        /* != 0: skip the fast path */
     uint64_t max_msg_bytes;                      /* 0 = 512 MiB: larger messages are split (both ends compute the same pieces); the built-in RCCL transport caps it at 1 GiB */
+    /* Composite keys and NULLs, as golap_join_params (physical_plan.rs:35-36, column_buffer.rs:59-60): up to 4 key columns per side
+     * (column 0 = build_key_ptr / probe_key_ptr) and one validity byte array per column (0 pointer = no NULLs; a row with a NULL in any
+     * key column matches nothing, an outer join keeps it as an unmatched row).  The ranks agree on every column's value range
+     * (one small all-gather, read by the host) and join on the exact mixed-radix number of the columns' digits -- no hashing, no
+     * collisions; a composite wider than 62 bits is refused on every rank alike (GOLAP_ERR_UNSUPPORTED). */
+    uint32_t n_key_cols;                         /* 0 or 1: one key column */
+    uint32_t reserved0;
+    uint64_t build_key_extra[3], probe_key_extra[3];
+    uint64_t build_validity[4], probe_validity[4];
 } golap_sharded_join_params;
 /* Stages of the fast path, timed on the device when the context has profiling on (begin and end in ms since the call's first
  * kernel; events on the compute stream and on the communicator's stream): what a scaling line needs to say where the time went. */
@@ -465,6 +474,10 @@ int32_t golap_sharded_aggregate(golap_ctx* ctx, golap_comm* comm, const golap_ag
  * (validity = one byte per row, column_buffer.rs:59-60; 0 pointer = all valid). */
 int32_t golap_widen_to_8byte(golap_ctx* ctx, uint64_t in_ptr, int32_t in_dtype /*GOLAP_WIDEN_* */, uint64_t validity_ptr,
                              uint64_t n_rows, uint64_t out_ptr, void* stream);
+/* Utf8 columns, record_batch_convert.rs:93-97 + :112-130: out[i] = FNV-1a 64 of bytes [offsets[i], offsets[i + 1]) as int64 (offset
+ * basis 14695981039346656037, prime 1099511628211), NULL rows (validity byte 0) -> 0.  offsets: device int64[n_rows + 1] (Arrow's
+ * int32 offsets widened by the caller), data: device bytes, validity: device u8[n_rows] or 0. */
+int32_t golap_hash_utf8(golap_ctx* ctx, uint64_t offsets_ptr, uint64_t data_ptr, uint64_t validity_ptr, uint64_t n_rows, uint64_t out_ptr, void* stream);
 enum { GOLAP_WIDEN_I8 = 0, GOLAP_WIDEN_I16, GOLAP_WIDEN_I32, GOLAP_WIDEN_I64, GOLAP_WIDEN_U8, GOLAP_WIDEN_U16,
        GOLAP_WIDEN_U32, GOLAP_WIDEN_U64, GOLAP_WIDEN_F32, GOLAP_WIDEN_F64 };
 

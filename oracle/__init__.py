@@ -196,6 +196,12 @@ def radix_join_mt(build, probe, n_threads):
     return int(m), int(cs.value)
 
 
+def fnv1a_hash(data: bytes):
+    """record_batch_convert.rs:123-130 (FNV-1a 64) -> python int (u64)"""
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    return int(lib().orc_fnv1a_hash(buf, len(data)))
+
+
 def eval_filter_mask(col, op, literal):
     col = _c(col, np.int64)
     mask = np.empty(col.size, np.uint8)

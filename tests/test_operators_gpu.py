@@ -429,3 +429,44 @@ def test_filter_conjunction(ctx):
     # a leaf with an unknown comparison selects nothing (executor.rs:464), and so does the conjunction
     out = O.execute(O.GpuFilter(O.Batches([rb]), And(O.BinaryExpr(A, "~", O.Literal("1")), O.BinaryExpr(B, "<", O.Literal("500")))), ctx)
     assert sum(x.num_rows for x in out) == 0
+
+
+def test_utf8_hash_known_answers(ctx):
+    """golap_hash_utf8 = the reference's fnv1a_hash (record_batch_convert.rs:123-130) on the device: the published FNV-1a 64 test vectors,
+    the oracle's restatement on random strings (incl. empty and multi-byte ones), NULL -> 0 (:112-121)."""
+    import torch
+    strs = ["", "a", "foobar", "hello world", "ünïcödé", "x" * 1000, None, "b"]
+    rng = np.random.default_rng(2)
+    strs += ["".join(chr(int(c)) for c in rng.integers(32, 127, int(l))) for l in rng.integers(0, 40, 500)]
+    enc = [b"" if s is None else s.encode() for s in strs]
+    off = np.zeros(len(strs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(e) for e in enc])
+    data = np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8)
+    valid = np.array([0 if s is None else 1 for s in strs], dtype=np.uint8)
+    got = ctx.hash_utf8(torch.from_numpy(off).cuda(), torch.from_numpy(data.copy()).cuda(), torch.from_numpy(valid).cuda()).cpu().numpy().view(np.uint64)
+    assert got[0] == 0xcbf29ce484222325 and got[1] == 0xaf63dc4c8601ec8c and got[2] == 0x85944171f73967e8     # FNV-1a 64 test vectors
+    exp = np.array([0 if s is None else oracle.fnv1a_hash(e) for s, e in zip(strs, enc)], dtype=np.uint64)
+    assert np.array_equal(got, exp)
+
+
+def test_string_keys_join_and_group_by(ctx):
+    """Utf8 key columns (record_batch_convert.rs:93-97: a string column reaches the GPU as its FNV-1a 64 hashes): a join and a GROUP BY
+    on string keys against plain Python over the strings -- equal unless two different strings share a 64-bit hash (none here)."""
+    rng = np.random.default_rng(12)
+    names = [f"customer-{i:05d}" for i in range(300)]
+    lk = [names[i] for i in rng.integers(0, 300, 2000)]
+    rk = [names[i] for i in rng.integers(0, 350, 1500) if i < 300] + [None, "nobody"]
+    lv = rng.integers(0, 100, len(lk)).astype(np.int64)
+    rv = rng.integers(0, 100, len(rk)).astype(np.int64)
+    left = pa.RecordBatch.from_arrays([pa.array(lk, pa.string()), pa.array(lv)], names=["name", "lv"])
+    right = pa.RecordBatch.from_arrays([pa.array(rk, pa.large_string()), pa.array(rv)], names=["rname", "rv"])
+    out = O.execute(O.GpuHashJoin(O.Batches([left]), O.Batches([right]), [O.Column(0, "name")], [O.Column(0, "rname")], "Inner"), ctx)
+    got = sorted(zip(out[0].column("lv").to_pylist(), out[0].column("rv").to_pylist(), out[0].column("name").to_pylist()))
+    h = lambda s: int(np.uint64(oracle.fnv1a_hash(s.encode())).astype(np.int64))
+    exp = sorted((int(a), int(b), h(x)) for x, a in zip(lk, lv) for y, b in zip(rk, rv) if y is not None and x == y)
+    assert got == exp and len(exp) > 1000
+    g = O.execute(O.GpuAggregate(O.Batches([left]), [O.Column(0, "name")], [O.Sum(O.Column(1, "lv")), O.Count(O.Column(1, "lv"))]), ctx)[0]
+    sums = {}
+    for x, a in zip(lk, lv):
+        s = sums.setdefault(h(x), [0.0, 0.0]); s[0] += a; s[1] += 1
+    assert dict(zip(g.column(0).to_pylist(), zip(g.column(1).to_pylist(), g.column(2).to_pylist()))) == {k: tuple(v) for k, v in sums.items()}

@@ -464,3 +464,64 @@ def test_sharded_aggregate_ranks_share_one_gpu(world, groups, hashed):
         full[:, uk] = exp
         for r in res:                                                        # replicated, bit-identical on every rank
             assert np.array_equal(r[2], full) and np.array_equal(r[3].astype(np.float64), full[1])
+
+
+def _composite_rows(n):
+    rng = np.random.default_rng(n + 3)
+    mk = lambda: (rng.integers(-40, 40, n).astype(np.int64), rng.integers(1000, 1030, n).astype(np.int64))
+    (b0, b1), (p0, p1) = mk(), mk()
+    bv = [(rng.random(n) > 0.05).astype(np.uint8), None]
+    pv = [(rng.random(n) > 0.05).astype(np.uint8), (rng.random(n) > 0.05).astype(np.uint8)]
+    return [b0, b1], [p0, p1], bv, pv
+
+
+def _worker_composite(rank, world, port, n, jt, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpu_olap_engine_amd.distributed import NativeShardedJoin
+        from gpu_olap_engine_amd.engine import Context, shard_range
+        torch.cuda.set_device(0)
+        c = Context(max_gpu_memory=0)
+        lo, hi = shard_range(n, rank, world)
+        bc, pc, bv, pv = _composite_rows(n)
+        cu = lambda a: None if a is None else torch.from_numpy(a[lo:hi]).cuda()
+        sj = NativeShardedJoin(c, transport="staged")
+        out = torch.empty((60 * n + 16, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt, info = sj.join([cu(x) for x in bc], [cu(x) for x in pc], lo, lo, n, out_pairs=out, join_type=jt,
+                                   build_valid=[cu(x) for x in bv], probe_valid=[cu(x) for x in pv])
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        q.put((rank, pairs[:m].cpu().numpy().view(np.uint32).copy()))
+        dist.barrier()
+        sj.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,jt", [(2, 0), (4, 3), (2, 1)])
+def test_sharded_join_composite_and_null_keys(world, jt):
+    """golap_sharded_join with a two-column key and NULLs in three of the four key columns: the ranks agree on the columns' value ranges and
+    join on the exact mixed-radix key; a row with a NULL in any key column matches nothing and an outer join keeps it -- against the
+    oracle's multi-column NULL-aware join of the whole tables."""
+    import oracle
+    import torch.multiprocessing as mp
+    from np_twin import canonical
+    n = 40_000
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_composite, args=(r, world, port, n, jt, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    bc, pc, bv, pv = _composite_rows(n)
+    exp, me = oracle.hash_join_multi(bc, pc, jt, bv, pv)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
