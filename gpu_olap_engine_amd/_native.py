@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgolap_hip.so")
+LIB_PATH = os.environ.get("GOLAP_DEV_LIB") or os.path.join(_HERE, "lib", "libgolap_hip.so")   # (GOLAP_DEV_LIB: developer builds, e.g. `make DIAG=1 OUT=...`)
 
 GOLAP_OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_PEER = 1, 2, 3, 4, 5, 6, 7

@@ -212,7 +212,22 @@ int32_t TransferQueue::enqueue(golap_ctx* ctx, int32_t direction, uint64_t src, 
     const hipMemcpyKind kind = direction == GOLAP_HOST_TO_DEVICE ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
     const void* host = direction == GOLAP_HOST_TO_DEVICE ? (const void*)src : (const void*)dst;
     if (is_pinned_or_device(host)) {
-        GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)dst, (const void*)src, size, kind, s->stream));   // :93 / :115
+        hipEvent_t permit = nullptr;
+        {   // :49, :63-64: a permit per transfer in flight, 4N in all
+            std::lock_guard<std::mutex> pk(permit_mu);
+            const size_t slots = 4 * streams.size();
+            if (permits.size() < slots) { permits.resize(slots, nullptr); permit_used.resize(slots, 0); }
+            const size_t k = (size_t)(permit_next++ % slots);
+            if (!permits[k]) GOLAP_HIP_TRY(ctx, hipEventCreateWithFlags(&permits[k], hipEventDisableTiming));
+            if (permit_used[k]) {
+                if (hipEventQuery(permits[k]) != hipSuccess) { (void)hipGetLastError(); ++permit_waits; }
+                GOLAP_HIP_TRY(ctx, hipEventSynchronize(permits[k]));
+            }
+            permit_used[k] = 1;
+            permit = permits[k];
+            GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)dst, (const void*)src, size, kind, s->stream));   // :93 / :115
+            GOLAP_HIP_TRY(ctx, hipEventRecord(permit, s->stream));
+        }
         return GOLAP_OK;
     }
     // Pageable host memory: stage through two pinned bounce buffers so the copy
@@ -263,6 +278,10 @@ void TransferQueue::destroy() {
         delete s;
     }
     streams.clear();
+    for (hipEvent_t e : permits)
+        if (e) (void)hipEventDestroy(e);
+    permits.clear();
+    permit_used.clear();
 }
 
 // ---------------------------------------------------------------------------

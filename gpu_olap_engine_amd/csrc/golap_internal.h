@@ -72,6 +72,13 @@ struct XferStream {
 struct TransferQueue {
     std::vector<XferStream*> streams;
     uint64_t bounce_bytes = 0;
+    // back-pressure, transfer_queue.rs:49 (`Semaphore::new(num_streams * 4)`): at most 4N asynchronous transfers are in flight -- the
+    // caller of enqueue number k + 4N waits until transfer k has completed (a ring of 4N events; the reference's permit only spans
+    // the enqueue call itself, its copies being no-ops)
+    std::mutex permit_mu;
+    std::vector<hipEvent_t> permits;
+    std::vector<uint8_t> permit_used;
+    uint64_t permit_next = 0, permit_waits = 0;
     int32_t init(golap_ctx* ctx, uint32_t num_streams);
     int32_t enqueue(golap_ctx* ctx, int32_t direction, uint64_t src, uint64_t dst, uint64_t size, uint32_t stream_id);
     int32_t synchronize(golap_ctx* ctx);

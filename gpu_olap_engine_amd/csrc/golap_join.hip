@@ -1234,9 +1234,16 @@ template <int JT, bool NARROW = false, bool STRIDE = false>
 __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
                                                          unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
                                                          uint32_t* __restrict__ probe_hit, uint32_t n_sub, const uint32_t* __restrict__ run_if,
-                                                         const uint32_t* __restrict__ skip_if) {
+                                                         const uint32_t* __restrict__ skip_if
+#ifdef GOLAP_DIAG   // timing-only experiment (WRONG results): n_spread output counters instead of one -- what does the single counter cost?
+                                                         , unsigned long long* __restrict__ spread, uint32_t n_spread
+#endif
+                                                         ) {
     if (run_if && *run_if == 0) return;
     if (skip_if && *skip_if != 0) return;
+#ifdef GOLAP_DIAG
+    if (n_spread) { out_count = spread + (size_t)(blockIdx.x % n_spread) * 16; max_pairs = max_pairs > (1u << 20) ? max_pairs - (1u << 20) : 0; }
+#endif
     if (!STRIDE) {
         join_sub_partition<JT, NARROW>(blockIdx.x, B, P, out_pairs, out_count, max_pairs, probe_hit);
     } else {
@@ -1471,7 +1478,21 @@ static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out, uin
     uint64_t c1 = std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n, PT_TILE)));
     const uint64_t big = n / ((uint64_t)min_tiles * 24576);
     if (big >= 256) c1 = std::min<uint64_t>(2048, big / 256 * 256);   // whole rounds of one 1024-thread work-group per CU (256 CUs)
-    const uint32_t chunk_rows = (uint32_t)round_up(round_up(ceil_div(n, c1), PT_TILE), big >= 256 ? tile : PT_TILE);
+    uint32_t chunk_rows = (uint32_t)round_up(round_up(ceil_div(n, c1), PT_TILE), big >= 256 ? tile : PT_TILE);
+    if (big >= 256 && tile > (uint32_t)PT_TILE && !(knob("GOLAP_CHUNK_ROUNDS") && !strcmp(knob("GOLAP_CHUNK_ROUNDS"), "0"))) {
+        // Chunks are whole tiles, so the rule above leaves the last round of work-groups partly empty (1B rows, 18432-row tiles: 2010
+        // chunks of 27 tiles = 7.85 rounds of 256).  Pick the tiles per chunk so that the chunks fill whole rounds: among 4 .. 8 rounds
+        // the split with the least idle tile slots (1B rows: 1024 chunks of 53 tiles, 4 rounds, 0.03 % idle instead of 1.9 %).
+        const uint64_t tiles = ceil_div(n, tile);
+        double best = -1.0;
+        for (uint64_t rounds = 4; rounds <= 8; ++rounds) {
+            const uint64_t T = ceil_div(tiles, 256 * rounds);
+            if (T < min_tiles) continue;
+            const uint64_t nc = ceil_div(tiles, T);
+            const double util = (double)tiles / (double)(ceil_div(nc, 256) * 256 * T);
+            if (util >= best) { best = util; chunk_rows = (uint32_t)(T * tile); }
+        }
+    }
     if (chunk_rows_out) *chunk_rows_out = chunk_rows;
     return (uint32_t)std::max<uint64_t>(1, ceil_div(n, chunk_rows));
 }
@@ -1586,13 +1607,19 @@ static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool h
 }
 
 static uint32_t part1_narrow_tile();
+// the 64-bit pipeline's reserving first pass: k_part1_narrow<.., WIDE> (12288-row tiles) when the column is 16-byte aligned, else
+// round 1's k_scatter_big.  GOLAP_P1W=0: the old kernel (A/B hook), 2: the new one with compiler-visible loads and stores.
+static int p1w_variant() { const char* e = knob("GOLAP_P1W"); return e ? atoi(e) : 1; }
+static uint32_t wide_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) {
+    return p1w_variant() != 0 ? first_pass_chunks(n_rows, chunk_rows_out, 12288, 4) : first_pass_chunks(n_rows, chunk_rows_out);
+}
 // chunking of the tuple pipeline's first pass (k_part1_narrow: one 1024-thread work-group per chunk, whole tiles per chunk) and the
 // size rule for using it: (almost) every CU gets a chunk of at least big_tile_min_tiles() tiles
 static uint32_t narrow_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) { return first_pass_chunks(n_rows, chunk_rows_out, part1_narrow_tile(), big_tile_min_tiles()); }
 static bool narrow_size_ok(uint64_t n_rows) {
     uint32_t chunk_rows = 0;
     const uint32_t chunks = narrow_chunks(n_rows, &chunk_rows);
-    return chunks >= 192 && n_rows / chunks >= (uint64_t)big_tile_min_tiles() * part1_narrow_tile();
+    return chunks >= 192 && chunk_rows >= big_tile_min_tiles() * part1_narrow_tile();   // (whole chunks of at least that many tiles; only the last one may be shorter)
 }
 // rows the first-pass output buffer must hold
 static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
@@ -1601,7 +1628,7 @@ static uint64_t pass1_rows(const JoinPlan& plan, uint64_t n, bool has_segs) {
     uint32_t chunk_rows = 0;
     const uint32_t nc = narrow_chunks(n, &chunk_rows);
     uint32_t wchunk = 0;
-    const uint32_t wnc = first_pass_chunks(n, &wchunk);
+    const uint32_t wnc = wide_chunks(n, &wchunk);
     const uint64_t wide_rows = reserve_cap_sub(n, F, wide_nsub(), wnc, wchunk) * F * wide_nsub();   // the 64-bit pipeline's own chunking
     return std::max<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(n, reserve_cap(n, F) * F), wide_rows),
                               reserve_cap_sub(n, F, nsub, nc, chunk_rows, DICT_SIGMA_MUL) * F * nsub);   // (narrow tuples: 8 B per row as well)
@@ -1783,7 +1810,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         if (reserve_first && k == 0) {
             // ---- no-histogram first pass: tiles reserve their bucket runs by atomics (k_scatter_big<.., RESERVE>) ----
             const uint32_t F = pp.cfg.F;
-            const uint32_t nc = first_pass_chunks(n_rows, &chunk_rows);
+            const uint32_t nc = wide_chunks(n_rows, &chunk_rows);
             const uint32_t nsub = wide_nsub();   // per-XCD sub-ranges (ReserveArgs::nsub), as in the tuple pipeline
             const uint32_t cap = (uint32_t)reserve_cap_sub(n_rows, F, nsub, nc, chunk_rows);
             uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F * nsub * 4);
@@ -1803,7 +1830,20 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     hipLaunchKernelGGL((k_scatter_big<1, RPT, 1024, WIN, 4, false, WU, true>), dim3(nc), dim3(1024), scatter_big_lds_bytes(F, WIN, 1024), st,      \
                        (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (const uint32_t*)nullptr,         \
                        (long long*)buf.tmp_keys[0], (uint32_t*)buf.tmp_rids[0], cfg, ReserveArgs{cursor, cap, flag1, nullptr, gate, nsub})
-                GOLAP_RSV(24, 12288, 3);
+                const int pw = p1w_variant();
+                if (pw != 0 && (cur_keys & 15) == 0 && F <= (uint32_t)WC_MAX_F) {
+                    const ReserveArgs rsa{cursor, cap, flag1, nullptr, gate, nsub};
+                    if (pw == 2)
+                        hipLaunchKernelGGL((k_part1_narrow<12, 12288, true, false, 0, 0, 1>), dim3(nc), dim3(P1N_THREADS), part1_narrow_lds_bytes(F, 12288, true), st,
+                                           (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (uint2*)buf.tmp_keys[0], cfg, rsa,
+                                           (uint32_t*)buf.tmp_rids[0]);
+                    else
+                        hipLaunchKernelGGL((k_part1_narrow<12, 12288, true, true, 0, 0, 1>), dim3(nc), dim3(P1N_THREADS), part1_narrow_lds_bytes(F, 12288, true), st,
+                                           (const long long*)cur_keys, rid_base, (const uint32_t*)c_off, (const uint32_t*)c_len, (uint2*)buf.tmp_keys[0], cfg, rsa,
+                                           (uint32_t*)buf.tmp_rids[0]);
+                } else {
+                    GOLAP_RSV(24, 12288, 3);
+                }
 #undef GOLAP_RSV
             }
             GOLAP_HIP_TRY(ctx, hipGetLastError());
@@ -1952,6 +1992,8 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
 #endif
             };
             for (const void* f : p1) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part1_narrow_lds_bytes(PT_MAX_F, 18432)));
+            const void* p1w[] = {(const void*)k_part1_narrow<12, 12288, true, true, 0, 0, 1>, (const void*)k_part1_narrow<12, 12288, true, false, 0, 0, 1>};
+            for (const void* f : p1w) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part1_narrow_lds_bytes(WC_MAX_F, 12288, true)));
             const void* p2[] = {(const void*)k_part2_ring<4, 32, true>, (const void*)k_part2_ring<4, 64, true>, (const void*)k_part2_ring<4, 128, true>,
                                 (const void*)k_part2_ring<4, 256, true>, (const void*)k_part2_ring<4, 32, false>, (const void*)k_part2_ring<4, 64, false>,
                                 (const void*)k_part2_ring<4, 128, false>, (const void*)k_part2_ring<4, 256, false>,
@@ -2014,7 +2056,21 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     if (const char* e = knob("GOLAP_JOIN_STRIDE_GRID")) stride_grid = (uint32_t)std::max(1, atoi(e));   // debug hook
     const dim3 grid(run_if ? std::min<uint32_t>(n_sub, stride_grid) : n_sub), block(JN_THREADS);   // stand-by launch: small striding grid
     unsigned long long* oc = (unsigned long long*)out_count;
+#ifdef GOLAP_DIAG
+    uint32_t n_spread = 0;
+    unsigned long long* spread = nullptr;
+    if (const char* e = knob("GOLAP_JOIN_SPREAD")) {
+        n_spread = (uint32_t)std::max(0, atoi(e));
+        if (n_spread) {
+            spread = (unsigned long long*)ws_take(ctx, (uint64_t)n_spread * 128);
+            if (!spread) return fail(ctx, GOLAP_ERR_OOM, "diag");
+            GOLAP_TRY(zero_async(ctx, st, spread, (uint64_t)n_spread * 128));
+        }
+    }
+#define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if, spread, n_spread
+#else
 #define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if
+#endif
 #define GOLAP_JN(JT)                                                                                          \
     if (narrow)                                                                                               \
         hipLaunchKernelGGL((k_join_lds<JT, true, false>), grid, block, 0, st, GOLAP_JN_ARGS);                 \
@@ -2107,7 +2163,7 @@ static void launch_part1_narrow(hipStream_t st, uint64_t in_keys, uint32_t rid_b
     const uint32_t F1 = cfg.F;
 #define GOLAP_P1N(RPT, WIN, VEC, ASM, ...)                                                                                                            \
     hipLaunchKernelGGL((k_part1_narrow<RPT, WIN, VEC, ASM, ##__VA_ARGS__>), dim3(nc), dim3(P1N_THREADS), part1_narrow_lds_bytes(F1, WIN), st, (const long long*)in_keys, \
-                       rid_base, c_off, c_len, (uint2*)tmp_rows, cfg, rsa)
+                       rid_base, c_off, c_len, (uint2*)tmp_rows, cfg, rsa, (uint32_t*)nullptr)
 #ifdef GOLAP_DIAG
     if (v1 == 901) { GOLAP_P1N(18, 18432, true, false, 1); return; }   // 9xx: timing-only diagnostic builds (scripts/ab_p12.py; make DIAG=1)
     if (v1 == 902) { GOLAP_P1N(18, 18432, true, false, 2); return; }

@@ -110,6 +110,14 @@ __device__ __forceinline__ void st16_hidden_mask_s(void* sbase, uint32_t off, u3
                  : "v"(off), "v"(v), "s"(sbase), "s"(mask)
                  : "memory", "scc");
 }
+// 4-byte store of the lanes with ok != 0 (one vmcnt event per call)
+__device__ __forceinline__ void st4_hidden_if(void* p, uint32_t v, uint32_t ok) {
+    unsigned long long saved;
+    asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\tglobal_store_dword %1, %2, off\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(p), "v"(v), "v"(ok)
+                 : "memory", "vcc", "scc");
+}
 // returning global atomic add of the active lanes (inactive lanes keep `ret`)
 __device__ __forceinline__ void atomic_add_rtn_hidden(uint32_t& ret, uint32_t* p, uint32_t v) {
     asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(ret) : "v"(p), "v"(v) : "memory");
@@ -126,7 +134,7 @@ __device__ __forceinline__ void ld4_hidden_sc1(uint32_t& v, const uint32_t* p) {
 constexpr int P1N_THREADS = 1024;
 constexpr int P1N_WAVES = P1N_THREADS / 64;
 
-static inline size_t part1_narrow_lds_bytes(uint32_t F, uint32_t win) { return (size_t)win * 8 + (size_t)F * 12 + (P1N_WAVES + 2) * 4 + 16; }
+static inline size_t part1_narrow_lds_bytes(uint32_t F, uint32_t win, bool wide = false) { return (size_t)win * (wide ? 12 : 8) + (size_t)F * 12 + (P1N_WAVES + 2) * 4 + 16; }
 
 // VEC2: 16-byte loads (needs a 16-byte aligned column); ASM: hidden loads/stores + counted waits (implies VEC2).
 // DIAG != 0: timing-only diagnostic builds for scripts/ab_p12.py (WRONG results, never launched by the product path):
@@ -134,21 +142,27 @@ static inline size_t part1_narrow_lds_bytes(uint32_t F, uint32_t win) { return (
 // DICT != 0: the form for key columns with 2 .. 4 distinct upper halves (PassCfg::key_hi): every key's upper half is looked up in the
 // dictionary (scalar registers), the tuple's first word is (hash >> b1) | (index << (32 - b1)).  Both forms are enqueued; each
 // returns at once unless the dictionary size on the device says it is the one to run.
-template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG = 0, int DICT = 0>
+// WIDE != 0 (round 3): the first pass of the 64-bit-row pipeline in the same shape -- whole 64-bit keys and row ids out as two arrays
+// (out_rows = the key array, out_rids), 12 bytes per row through the LDS window, so a 12288-row tile; no key check and no abandon
+// word (the launch is gated by rs.run_if instead), two hidden stores per row.  Replaces k_scatter_big<.., RESERVE>, which loaded a
+// tile only after the previous one had been written out.
+template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG = 0, int DICT = 0, int WIDE = 0>
 __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* __restrict__ in_keys, uint32_t rid_base,
                                                               const uint32_t* __restrict__ chunk_off, const uint32_t* __restrict__ chunk_len,
-                                                              uint2* __restrict__ out_rows, PassCfg cfg, ReserveArgs rs) {
+                                                              uint2* __restrict__ out_rows, PassCfg cfg, ReserveArgs rs, uint32_t* __restrict__ out_rids) {
     constexpr int NT = P1N_THREADS, NW = P1N_WAVES;
     constexpr int TILE = NT * RPT;
     constexpr int ROUNDS = (TILE + WIN - 1) / WIN;
-    constexpr int STORES = WIN / NT;   // store instructions per wave behind the next tile's loads: those of the last window (ASM: all issued at uniform control flow)
+    constexpr int STORES = (WIDE ? 2 : 1) * (WIN / NT);   // store instructions per wave behind the next tile's loads: those of the last window (ASM: all issued at uniform control flow)
+    static_assert(!WIDE || (DICT == 0 && DIAG == 0), "the 64-bit form has no dictionary and no diagnostic builds");
     static_assert(TILE <= 32768, "tile position is packed into 15 bits");
     static_assert(!VEC2 || RPT % 2 == 0, "16-byte loads take two keys");
     static_assert(!ASM || VEC2, "the hidden loads are the 16-byte ones");
     static_assert(WIN % NT == 0 && STORES <= 60, "window rows per thread; vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    uint2* s_rows = reinterpret_cast<uint2*>(s_raw);                       // [WIN] (key32, bucket << 15 | tile position)
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_raw + (size_t)WIN * 8);   // [F] rows of the bucket in this tile
+    uint2* s_rows = reinterpret_cast<uint2*>(s_raw);                       // [WIN] (key32, bucket << 15 | tile position); WIDE: the 64-bit key
+    uint32_t* s_meta = reinterpret_cast<uint32_t*>(s_raw + (size_t)WIN * 8);  // WIDE: [WIN] bucket << 15 | tile position
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_raw + (size_t)WIN * (WIDE ? 12 : 8));   // [F] rows of the bucket in this tile
     uint32_t* s_start = s_cnt + cfg.F;                                     // [F] tile-local slot of the bucket's first row
     uint32_t* s_delta = s_start + cfg.F;                                   // [F] global position - tile-local slot
     uint32_t* s_w = s_delta + cfg.F;                                       // [NW] wave totals, [NW] abandon flag
@@ -156,8 +170,8 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     if (rs.run_if && *rs.run_if == 0) return;
     // the attempt may be over before it starts (k_key_hi's sample found two upper key halves): ~2000 work-groups that each load and
     // rank one tile before they notice cost 0.45 ms per side; asking first costs the good case one L2 round trip per work-group
-    if (__hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    if (key_dict_mode(cfg) != (DICT != 0)) return;   // (work-group-uniform: the other form of this pass does the work)
+    if (!WIDE && __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if (!WIDE && key_dict_mode(cfg) != (DICT != 0)) return;   // (work-group-uniform: the other form of this pass does the work)
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
     if (len == 0) return;
@@ -165,7 +179,8 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t F = cfg.F;   // <= NT: one bucket per thread in the scan
     if (tid < F) s_cnt[tid] = 0;
-    const uint32_t khi = __builtin_amdgcn_readfirstlane(key_hi_of(cfg));   // the upper key half this attempt stands on (see PassCfg::key_hi)
+    if (WIDE && tid == 0) s_w[NW] = 0;   // (no abandon word in the 64-bit form)
+    const uint32_t khi = WIDE ? 0u : __builtin_amdgcn_readfirstlane(key_hi_of(cfg));   // the upper key half this attempt stands on (see PassCfg::key_hi)
     const bool emit_hash = cfg.pre_hashed != 0;
     // DICT: the dictionary's other entries and the position of the index in the tuple's first word
     const uint32_t kd1 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[1]) : 0u, kd2 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[2]) : 0u,
@@ -210,13 +225,13 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
         }
     };
     uint32_t polled = 0;
-    if (ASM && wv == 0) ld4_hidden_sc1(polled, rs.wide);
+    if (ASM && !WIDE && wv == 0) ld4_hidden_sc1(polled, rs.wide);
     load_tile(0);
     for (uint32_t t0 = 0; t0 < len; t0 += TILE) {
         const uint32_t tn = len - t0 < (uint32_t)TILE ? len - t0 : (uint32_t)TILE;
         const uint32_t rbase = off + t0;
         // has the narrow attempt been abandoned?  (one thread asks, everybody learns it behind the next barrier)
-        if (!ASM && tid == 0) s_w[NW] = __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ASM && !WIDE && tid == 0) s_w[NW] = __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t0 == 0) lds_barrier();   // s_cnt zeroed (later tiles: re-zeroed two barriers ago by the scan below)
         if (ASM) {
             // the keys (and, in wave 0, the abandon word in front of them) were requested before the STORES stores of the
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
             if (t0 == 0) wait_vmcnt<0>(); else wait_vmcnt<STORES>();
 #pragma unroll
             for (int h = 0; h < RPT / 2; ++h) pin(kv[h]);
-            if (wv == 0) {
+            if (!WIDE && wv == 0) {
                 asm volatile("" : "+v"(polled));
                 if (tid == 0) s_w[NW] = polled;
             }
@@ -238,7 +253,9 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
             const uint32_t khi_r = (r & 1) ? kv[r >> 1].w : kv[r >> 1].y;
             br[r] = 0xFFFFFFFFu;
             uint32_t h;
-            if (DICT) {
+            if (WIDE) {
+                h = hash_int32((int32_t)(k32[r] ^ khi_r));                                // == hash_int64 of the whole key (join_kernels.cuh:37-41)
+            } else if (DICT) {
                 const uint32_t m0 = khi_r ^ khi, m1 = khi_r ^ kd1, m2 = khi_r ^ kd2, m3 = khi_r ^ kd3;
                 const uint32_t ma = m0 < m1 ? m0 : m1, mb = m2 < m3 ? m2 : m3;
                 hi |= ma < mb ? ma : mb;                                                  // 0 iff the upper half is one of the dictionary's
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);                    // b < 1024, rank < 32768
             }
         }
-        if (hi) atomicOr(rs.wide, 1u);
+        if (!WIDE && hi) atomicOr(rs.wide, 1u);
         lds_barrier();
         if (s_w[NW]) return;   // work-group-uniform: some key somewhere does not fit 32 bits, the 64-bit pipeline takes over
         // exclusive scan of the bucket counts; the bucket's run in the output is reserved meanwhile (one returning
@@ -290,7 +307,12 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
                     const uint32_t pos = (br[r] & 0xFFFFu) - w0;   // rows of other windows fall outside
-                    if (br[r] != 0xFFFFFFFFu && pos < (uint32_t)WIN) s_rows[pos] = make_uint2(k32[r], ((br[r] >> 16) << 15) | tile_pos(r));
+                    if (br[r] != 0xFFFFFFFFu && pos < (uint32_t)WIN) {
+                        if (WIDE) {
+                            s_rows[pos] = make_uint2(k32[r], (r & 1) ? kv[r >> 1].w : kv[r >> 1].y);
+                            s_meta[pos] = ((br[r] >> 16) << 15) | tile_pos(r);
+                        } else s_rows[pos] = make_uint2(k32[r], ((br[r] >> 16) << 15) | tile_pos(r));
+                    }
                 }
             }
             if (ASM && rd == 0) {   // nothing hidden is younger than the reservation here (the next tile's loads follow below)
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
                 if (rsv + c > rs.cap) atomicOr(rs.overflow, 1u);   // rsv + c cannot wrap: both < 2^31
             }
             if (rd == ROUNDS - 1 && t0 + TILE < len) {   // key registers are dead: the next tile streams in during the write-out
-                if (ASM && wv == 0) ld4_hidden_sc1(polled, rs.wide);   // (one tile stale when it is read: abandoning is an optimisation)
+                if (ASM && !WIDE && wv == 0) ld4_hidden_sc1(polled, rs.wide);   // (one tile stale when it is read: abandoning is an optimisation)
                 load_tile(t0 + TILE);
             }
             lds_barrier();
@@ -312,10 +334,12 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
                 for (int j = 0; j < WIN / NT; ++j) {   // every store instruction is issued, whatever the data (see the file header)
                     const uint32_t i = (uint32_t)j * NT + tid;
                     const uint2 row = s_rows[i];
-                    const uint32_t b = (row.y >> 15) & (F - 1u);   // (masked: rows beyond wn hold stale words)
+                    const uint32_t meta = WIDE ? s_meta[i] : row.y;
+                    const uint32_t b = (meta >> 15) & (F - 1u);   // (masked: rows beyond wn hold stale words)
                     const uint32_t gp = s_delta[b] + w0 + i;
                     const uint32_t ok = (i < wn && gp < (reserve_slot(rs, b) + 1u) * rs.cap) ? 1u : 0u;
-                    st8_hidden_if(out_rows + gp, u32x2{row.x, rid_base + rbase + (row.y & 0x7FFFu)}, ok);
+                    st8_hidden_if(out_rows + gp, u32x2{row.x, WIDE ? row.y : rid_base + rbase + (meta & 0x7FFFu)}, ok);
+                    if (WIDE) st4_hidden_if(out_rids + gp, rid_base + rbase + (meta & 0x7FFFu), ok);
                 }
             } else if (wn) {
 #pragma unroll 4
@@ -323,10 +347,13 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
                     const uint32_t i = (uint32_t)j * NT + tid;
                     if (i < wn) {
                         const uint2 row = s_rows[i];
-                        const uint32_t b = row.y >> 15;
+                        const uint32_t meta = WIDE ? s_meta[i] : row.y;
+                        const uint32_t b = meta >> 15;
                         const uint32_t gp = DIAG == 1 ? rbase + w0 + i : s_delta[b] + w0 + i;
-                        if (DIAG != 2 && (DIAG == 1 || gp < (reserve_slot(rs, b) + 1u) * rs.cap))   // rows past a bucket's range are dropped (overflow raised above)
-                            out_rows[gp] = make_uint2(row.x, rid_base + rbase + (row.y & 0x7FFFu));   // join_kernels.cuh:75
+                        if (DIAG != 2 && (DIAG == 1 || gp < (reserve_slot(rs, b) + 1u) * rs.cap)) {   // rows past a bucket's range are dropped (overflow raised above)
+                            out_rows[gp] = make_uint2(row.x, WIDE ? row.y : rid_base + rbase + (meta & 0x7FFFu));   // join_kernels.cuh:75
+                            if (WIDE) out_rids[gp] = rid_base + rbase + (meta & 0x7FFFu);
+                        }
                     }
                 }
             }

@@ -5,10 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gpu_olap_engine_amd import _native as N
 from gpu_olap_engine_amd.engine import Context
+wide = "--wide" in sys.argv      # keys with 2^16 different upper halves: the 64-bit-row pipeline
+if wide: sys.argv.remove("--wide")
 n = int(sys.argv[1]); var = sys.argv[2]; vals = sys.argv[3:]
 torch.cuda.set_device(0)
 ctx = Context(profiling=True, max_gpu_memory=0)
 b = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n); p = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+if wide:
+    b += ((b * 0x9E3779B1) & 0xFFFF) << 32; p += ((p * 0x9E3779B1) & 0xFFFF) << 32
 out = torch.empty((n, 2), dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
 res = {v: {} for v in vals}
 for rnd in range(5):

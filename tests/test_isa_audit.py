@@ -17,9 +17,10 @@ CSRC = os.path.join(ROOT, "gpu_olap_engine_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 # The instantiations the product is known to launch by default (k_part1_narrow<18, 18432, VEC2, ASM> and the four ring lengths): they
 # must be present; every OTHER instantiation with ASM = true found in the assembly is audited as well (discovered, not listed).
-EXPECTED = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi0EEE", "k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi1EEE", "k_part2_ringILi4ELi32ELb1ELi0EEE",
+EXPECTED = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi0ELi0EEE", "k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi1ELi0EEE",
+            "k_part1_narrowILi12ELi12288ELb1ELb1ELi0ELi0ELi1EEE", "k_part2_ringILi4ELi32ELb1ELi0EEE",
             "k_part2_ringILi4ELi64ELb1ELi0EEE", "k_part2_ringILi4ELi128ELb1ELi0EEE", "k_part2_ringILi4ELi256ELb1ELi0EEE"]
-# template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG, int DICT> k_part1_narrow / template <int RPT, int R, bool ASM, int DIAG> k_part2_ring
+# template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG, int DICT, int WIDE> k_part1_narrow / template <int RPT, int R, bool ASM, int DIAG> k_part2_ring
 # (the whole template argument list is part of the key, up to the EEE that closes it: a new template parameter shows up as a new key)
 ASM_FORMS = re.compile(r"^_ZN5golap\d+(k_part1_narrowILi\d+ELi\d+ELb[01]ELb1E(?:Li\d+E)+EE|k_part2_ringILi\d+ELi\d+ELb1E(?:Li\d+E)+EE)\w*:", re.M)
 # The audit reads ONE compiler's output: the hand-counted waits and the fixed-register scheme were validated (on the GPU, row by row:
@@ -62,7 +63,7 @@ def test_every_hidden_memory_instantiation_is_discovered(asm):
     for k in EXPECTED:
         assert k in found, f"{k} (a default launch form) is missing from the assembly"
     # the shipped library must not contain the timing-only diagnostic forms (DIAG != 0: wrong results by design)
-    diag = re.findall(r"^_ZN5golap\d+(k_part1_narrowILi\d+ELi\d+ELb[01]ELb[01]ELi[1-9]\d*ELi\d+EEE|k_part2_ringILi\d+ELi\d+ELb[01]ELi[1-9]\d*EEE)\w*:", asm, re.M)
+    diag = re.findall(r"^_ZN5golap\d+(k_part1_narrowILi\d+ELi\d+ELb[01]ELb[01]ELi[1-9]\d*ELi\d+ELi\d+EEE|k_part2_ringILi\d+ELi\d+ELb[01]ELi[1-9]\d*EEE)\w*:", asm, re.M)
     assert not diag, f"diagnostic kernel forms in the default build: {sorted(set(diag))}"
 
 
