@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--rehearse", action="store_true",
                     help="developer: run the N > 1 code path on ONE GPU (all ranks on device 0, gloo + host-staged transport instead of RCCL); "
                          "the numbers mean nothing, the line is marked")
+    ap.add_argument("--keys", default="narrow", choices=["narrow", "offset", "two", "random"],
+                    help="C5/C3 main leg: key columns as generated (below 2^32) | + 2^40 | two upper halves | 2^16 key-dependent upper halves (the 64-bit-row "
+                         "pipeline): what the profiles of the wide kernels are taken on")
     ap.add_argument("--no-others", action="store_true", help="C5 default run: skip the other_configs block (C3, C4, C4L, C1)")
     ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (golap_sharded_join) even with 1 rank")
     return ap.parse_args()
@@ -164,6 +167,14 @@ def bench_join(args, n_total, label):
     n_local = hi - lo
     bkeys = ctx.generate(N.GEN_BUILD_KEYS, n_local, modulus=n_total, first=lo)
     pkeys = ctx.generate(N.GEN_SM64_MOD_I64, n_local, modulus=n_total, seed=43, first=lo)
+    if args.keys != "narrow":   # (functions of the key value: equal keys stay equal on both sides)
+        for t in (bkeys, pkeys):
+            if args.keys in ("offset", "two"):
+                t += 1 << 40
+            if args.keys == "two":
+                t += (t & 1) << 41
+            if args.keys == "random":
+                t += ((t * 0x9E3779B1) & 0xFFFF) << 44
     torch.cuda.synchronize()
     join_info = None
     if not sharded:
@@ -246,7 +257,7 @@ def bench_join(args, n_total, label):
         "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, host-staged transport -- not a measurement)" if args.rehearse else ""),
         "config": {"workload": f"{label} radix hash join {n_total} x {n_total} int64 keys (all below 2^32: the 8-byte tuple pipeline), 256 radix "
                                f"partitions, unique build keys, M = N_probe",
-                   "n_build": n_total, "n_probe": n_total, "rows_per_gpu_per_side": n_local, "narrow_keys": True,
+                   "n_build": n_total, "n_probe": n_total, "rows_per_gpu_per_side": n_local, "narrow_keys": args.keys == "narrow", "keys": args.keys,
                    "parallelism": f"partition-sharded x{world}" + (" + RCCL grouped send/recv (golap_sharded_join)" if sharded else ""),
                    "plan": ctx.join_plan(n_total if world == 1 else max(1, n_total // world))},
         "probe_rows_per_s": round(n_total / (ms_per_step * 1e-3), 1),
@@ -268,7 +279,7 @@ def bench_join(args, n_total, label):
     # ---- further legs: the same join with keys outside [0, 2^32) -------------------------------
     # (a) both key columns + 2^40: every key is a genuine 64-bit value, all share one upper half -> still 8-byte tuples (frame of
     #     reference on the first build key); (b) two different upper halves -> the 64-bit-row pipeline (12-byte rows)
-    if label == "C5" and not args.no_wide and not sharded:
+    if label == "C5" and not args.no_wide and not sharded and args.keys == "narrow":
         def leg(name, what):
             torch.cuda.synchronize()
             (pr, cn), dtw = timed(step, args.steps, args.warmup, barrier, ctx)
