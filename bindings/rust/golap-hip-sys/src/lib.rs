@@ -176,7 +176,7 @@ pub struct golap_sharded_join_info {
     pub sub_ranges: u32,
     pub stage_ms: [[f32; 2]; 8],
     pub total_ms: f32,
-    pub reserved0: u32,
+    pub halves: u32,
 }
 
 /// host-only description of the fast path's messages (every rank computes the same numbers)

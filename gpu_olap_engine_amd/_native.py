@@ -124,7 +124,7 @@ class ShardedJoinParams(C.Structure):
 class ShardedJoinInfo(C.Structure):
     _fields_ = [("fast_path", C.c_uint32), ("fast_path_abandoned", C.c_uint32), ("extra_bits", C.c_uint32), ("n_groups", C.c_uint32),
                 ("local_bits", C.c_uint32), ("host_syncs", C.c_uint32), ("rows_received", C.c_uint64 * 2), ("bytes_sent", C.c_uint64 * 2),
-                ("chunks", C.c_uint32), ("sub_ranges", C.c_uint32), ("stage_ms", (C.c_float * 2) * 8), ("total_ms", C.c_float), ("reserved0", C.c_uint32)]
+                ("chunks", C.c_uint32), ("sub_ranges", C.c_uint32), ("stage_ms", (C.c_float * 2) * 8), ("total_ms", C.c_float), ("halves", C.c_uint32)]
 
 
 SHARD_STAGES = ["partition_build", "partition_probe", "exchange_build", "exchange_probe", "ring_build", "ring_probe", "join", "status"]

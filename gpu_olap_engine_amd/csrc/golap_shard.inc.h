@@ -79,7 +79,7 @@ struct golap_comm {
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;          // the exchange runs here, beside the caller's compute stream
     static constexpr int MAX_CHUNKS = 8;
-    hipEvent_t ev_part[2][MAX_CHUNKS] = {}, ev_xchg[2] = {nullptr, nullptr}, ev_hdr = nullptr, ev_misc = nullptr;   // ordering only (no timing)
+    hipEvent_t ev_part[2][MAX_CHUNKS] = {}, ev_xchg[2] = {nullptr, nullptr}, ev_half[2] = {nullptr, nullptr}, ev_hdr = nullptr, ev_misc = nullptr;   // ordering only (no timing)
     hipEvent_t ev_t[2 * GOLAP_SHARD_STAGES + 1] = {};   // stage begin / end + call start (timing events; recorded only with profiling on)
     uint32_t* h_status = nullptr;          // pinned: status words / size matrices read back by the host
     uint64_t h_status_bytes = 0;
@@ -525,34 +525,47 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     stamp(2 * GOLAP_SHARD_ST_PART_PROBE + 1, st);
     // ---- exchange (communicator's stream): build chunks as they are produced, then ONE all-gather of both sides' cursors and
     //      failure words (the probe side is partitioned long before the build side's last message has left), then the probe chunks ----
-    auto exchange_chunk = [&](int side, uint32_t c) -> int32_t {
+    // The probe side's rows travel in H group halves (with peers: 2): the ring pass and the join of the first half of this rank's
+    // groups run while the second half is still on the wire -- the join of a group needs nothing from any other group, so the
+    // tail behind the last message is half a ring pass + half a join instead of whole ones.  (The build side is shipped by row
+    // chunks only: its ring pass hides behind the probe side's exchange anyway.)
+    uint32_t H = P > 1 && per % 2 == 0 ? 2u : 1u;
+    if (const char* e = knob("GOLAP_SHARD_HALVES")) { const int v = atoi(e); if ((v == 1 || v == 2) && per % (uint32_t)v == 0) H = (uint32_t)v; }
+    auto exchange_chunk = [&](int side, uint32_t c, uint32_t h, uint32_t nh) -> int32_t {
         GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side][c], 0));
-        if (c == 0) stamp(2 * (side ? GOLAP_SHARD_ST_XCHG_PROBE : GOLAP_SHARD_ST_XCHG_BUILD), cm->stream);
+        if (c == 0 && h == 0) stamp(2 * (side ? GOLAP_SHARD_ST_XCHG_PROBE : GOLAP_SHARD_ST_XCHG_BUILD), cm->stream);
         std::vector<golap_p2p_op> ops;
-        const uint64_t my_cap = sp.cap[side][(size_t)me * K + c];
+        const uint64_t my_cap = sp.cap[side][(size_t)me * K + c], g0 = (uint64_t)h * (per / nh), gc = per / nh;
         for (uint32_t r = 0; r < P; ++r) {
             if (r == me) continue;
-            const uint64_t sbytes = (uint64_t)per * nsub * my_cap * 8, rbytes = (uint64_t)per * nsub * sp.cap[side][(size_t)r * K + c] * 8;
-            split_message((int32_t)r, true, tuples[side] + (L.send_base[side][c] + (uint64_t)r * per * nsub * my_cap) * 8, sbytes, max_msg, ops);
-            split_message((int32_t)r, false, tuples[side] + L.recv_off[side][(size_t)r * K + c] * 8, rbytes, max_msg, ops);
+            const uint64_t r_cap = sp.cap[side][(size_t)r * K + c];
+            const uint64_t sbytes = gc * nsub * my_cap * 8, rbytes = gc * nsub * r_cap * 8;
+            split_message((int32_t)r, true, tuples[side] + (L.send_base[side][c] + ((uint64_t)r * per + g0) * nsub * my_cap) * 8, sbytes, max_msg, ops);
+            split_message((int32_t)r, false, tuples[side] + (L.recv_off[side][(size_t)r * K + c] + g0 * nsub * r_cap) * 8, rbytes, max_msg, ops);
             cm->info.bytes_sent[side] += sbytes;
         }
         GOLAP_TRY(comm_exchange(cm, ops, cm->stream));
         return GOLAP_OK;
     };
-    for (uint32_t c = 0; c < K; ++c) GOLAP_TRY(exchange_chunk(0, c));
+    for (uint32_t c = 0; c < K; ++c) GOLAP_TRY(exchange_chunk(0, c, 0, 1));
     stamp(2 * GOLAP_SHARD_ST_XCHG_BUILD + 1, cm->stream);
     GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[0], cm->stream));
     GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[1][K - 1], 0));
     GOLAP_TRY(comm_all_gather(cm, (uint64_t)hdr, (uint64_t)hdr_all, (uint64_t)L.hdr_stride * 4, cm->stream));
     GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_hdr, cm->stream));
-    for (uint32_t c = 0; c < K; ++c) GOLAP_TRY(exchange_chunk(1, c));
+    for (uint32_t h = 0; h < H; ++h) {
+        for (uint32_t c = 0; c < K; ++c) GOLAP_TRY(exchange_chunk(1, c, h, H));
+        GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_half[h], cm->stream));
+    }
     stamp(2 * GOLAP_SHARD_ST_XCHG_PROBE + 1, cm->stream);
-    GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[1], cm->stream));
-    // ---- ring pass per side, as soon as that side's rows (and the cursors) are in ----
+    // ---- ring pass: the build side as soon as its rows (and the cursors) are in, the probe side half by half; each half joined at once ----
     SideResult res[2];
+    const uint32_t n_src = P * K * nsub;
+    PassCfg cfg2 = sp.local.passes[0].cfg;
+    cfg2.S = 1;
+    cfg2.pre_hashed = p1n_variant() != 0 ? 1u : 0u;
+    GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_hdr, 0));   // (recorded behind ev_xchg[0]: the build rows and every rank's cursors)
     for (int side = 0; side < 2; ++side) {
-        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, side ? cm->ev_xchg[1] : cm->ev_hdr, 0));   // (ev_hdr is recorded behind ev_xchg[0])
         cm->info.rows_received[side] = L.recv_rows[side];
         for (uint32_t c = 0; c < K; ++c) cm->info.rows_received[side] += (uint64_t)per * nsub * sp.cap[side][(size_t)me * K + c];
         ShardSrcTable tab;
@@ -564,20 +577,10 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
             }
         uint32_t sigmas, pad;
         provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
-        stamp(2 * (side ? GOLAP_SHARD_ST_RING_PROBE : GOLAP_SHARD_ST_RING_BUILD), st);
+        if (side == 0) stamp(2 * GOLAP_SHARD_ST_RING_BUILD, st);
         hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)(hdr_all + (size_t)side * L.hdr_words), L.hdr_stride, F1, P, K, me, per,
                            nsub, tab, F2, sigmas, pad, A[side].seg_off, A[side].seg_len, A[side].slot_base, A[side].slot_cap, words,
                            (unsigned long long)L.final_rows_[side]);
-        FixedArgs fx{GroupSrc{}, A[side].slot_base, A[side].slot_cap, A[side].sub_start, A[side].sub_len, words, words};
-        PassCfg cfg = sp.local.passes[0].cfg;
-        cfg.S = 1;
-        cfg.pre_hashed = p1n_variant() != 0 ? 1u : 0u;
-        {
-            KernelTimer t(ctx, side ? "local_scatter_probe" : "local_scatter_build", st, 16 * cm->info.rows_received[side]);
-            launch_part2_ring(st, per, tuples[side], finals[side], cfg, fx, SegSrc{A[side].seg_off, A[side].seg_len, P * K * nsub});
-        }
-        GOLAP_HIP_TRY(ctx, hipGetLastError());
-        stamp(2 * (side ? GOLAP_SHARD_ST_RING_PROBE : GOLAP_SHARD_ST_RING_BUILD) + 1, st);
         res[side] = SideResult();
         res[side].keys = (const long long*)finals[side];
         res[side].alt_start = A[side].sub_start;
@@ -585,11 +588,30 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         res[side].flag = words + 1;
         res[side].positions = L.final_rows_[side];
     }
-    JoinPlan jp = sp.local;
-    jp.n_sub = (uint64_t)per * F2;
-    stamp(2 * GOLAP_SHARD_ST_JOIN, st);
-    GOLAP_TRY(launch_lds_join(ctx, st, jp, res[0], res[1], cm->info.rows_received[0], cm->info.rows_received[1], p->out_pairs_ptr, p->out_count_ptr,
-                              p->max_pairs, p->join_type, true, nullptr, words, probe_hit));
+    auto ring = [&](int side, uint32_t g0, uint32_t gc) -> int32_t {   // groups [g0, g0 + gc) of one side
+        FixedArgs fx{GroupSrc{}, A[side].slot_base + g0, A[side].slot_cap + g0, A[side].sub_start + (size_t)g0 * F2, A[side].sub_len + (size_t)g0 * F2, words, words};
+        KernelTimer t(ctx, side ? "local_scatter_probe" : "local_scatter_build", st, 16 * cm->info.rows_received[side] * gc / per);
+        launch_part2_ring(st, gc, tuples[side], finals[side], cfg2, fx, SegSrc{A[side].seg_off + (size_t)g0 * n_src, A[side].seg_len + (size_t)g0 * n_src, n_src});
+        GOLAP_HIP_TRY(ctx, hipGetLastError());
+        return GOLAP_OK;
+    };
+    GOLAP_TRY(ring(0, 0, per));
+    stamp(2 * GOLAP_SHARD_ST_RING_BUILD + 1, st);
+    for (uint32_t h = 0; h < H; ++h) {
+        const uint32_t g0 = h * (per / H), gc = per / H;
+        GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_half[h], 0));
+        if (h == 0) stamp(2 * GOLAP_SHARD_ST_RING_PROBE, st);
+        GOLAP_TRY(ring(1, g0, gc));
+        if (h + 1 == H) stamp(2 * GOLAP_SHARD_ST_RING_PROBE + 1, st);
+        SideResult hb = res[0], hp = res[1];
+        hb.alt_start += (size_t)g0 * F2; hb.alt_len += (size_t)g0 * F2;
+        hp.alt_start += (size_t)g0 * F2; hp.alt_len += (size_t)g0 * F2;
+        JoinPlan jp = sp.local;
+        jp.n_sub = (uint64_t)gc * F2;
+        if (h == 0) stamp(2 * GOLAP_SHARD_ST_JOIN, st);
+        GOLAP_TRY(launch_lds_join(ctx, st, jp, hb, hp, cm->info.rows_received[0] / H, cm->info.rows_received[1] / H, p->out_pairs_ptr, p->out_count_ptr,
+                                  p->max_pairs, p->join_type, true, nullptr, words, probe_hit));
+    }
     stamp(2 * GOLAP_SHARD_ST_JOIN + 1, st);
     // ---- did the narrow attempt hold on EVERY rank?  (all ranks must take the same path: the words are gathered) ----
     GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_misc, st));
@@ -607,6 +629,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     cm->info.host_syncs += 1;
     cm->info.chunks = K;
     cm->info.sub_ranges = nsub;
+    cm->info.halves = H;
     if (timing) {
         for (int sg = 0; sg < GOLAP_SHARD_STAGES; ++sg)
             for (int e = 0; e < 2; ++e) {
@@ -796,6 +819,7 @@ static int32_t comm_common(golap_ctx* ctx, int32_t world, int32_t rank, golap_co
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         for (int c = 0; c < golap_comm::MAX_CHUNKS && e == hipSuccess; ++c) e = hipEventCreateWithFlags(&cm->ev_part[i][c], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_xchg[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_half[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_misc, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_hdr, hipEventDisableTiming);
@@ -846,6 +870,7 @@ void golap_comm_destroy(golap_comm* cm) {
         for (int c = 0; c < golap_comm::MAX_CHUNKS; ++c)
             if (cm->ev_part[i][c]) (void)hipEventDestroy(cm->ev_part[i][c]);
         if (cm->ev_xchg[i]) (void)hipEventDestroy(cm->ev_xchg[i]);
+        if (cm->ev_half[i]) (void)hipEventDestroy(cm->ev_half[i]);
     }
     if (cm->ev_misc) (void)hipEventDestroy(cm->ev_misc);
     if (cm->ev_hdr) (void)hipEventDestroy(cm->ev_hdr);

@@ -550,7 +550,7 @@ class Comm:
         self.ctx._ck(self.ctx._lib.golap_sharded_join_info_get(self._h, C.byref(i)))
         return {"fast_path": bool(i.fast_path), "fast_path_abandoned": bool(i.fast_path_abandoned), "extra_bits": i.extra_bits,
                 "n_groups": i.n_groups, "local_bits": i.local_bits, "host_syncs": i.host_syncs,
-                "rows_received": list(i.rows_received), "bytes_sent": list(i.bytes_sent), "chunks": i.chunks, "sub_ranges": i.sub_ranges,
+                "rows_received": list(i.rows_received), "bytes_sent": list(i.bytes_sent), "chunks": i.chunks, "sub_ranges": i.sub_ranges, "halves": i.halves,
                 # device timestamps of the fast path's stages, ms since the call's first kernel: [begin, end] (profiling contexts only)
                 "stage_ms": {nm: [round(i.stage_ms[k][0], 4), round(i.stage_ms[k][1], 4)] for k, nm in enumerate(N.SHARD_STAGES)},
                 "total_ms": round(i.total_ms, 4)}

@@ -383,7 +383,8 @@ typedef struct golap_sharded_join_info {          /* what the last golap_sharded
     uint32_t sub_ranges;         /* fast path: per-XCD sub-ranges per bucket */
     float    stage_ms[GOLAP_SHARD_STAGES][2];   /* [stage][begin, end]; zeros without profiling or on the exact path */
     float    total_ms;           /* first kernel -> status words on the host's side of the last copy */
-    uint32_t reserved0;
+    uint32_t halves;             /* fast path: the probe side's rows travel in this many group halves (1 or 2); ring pass and join of a half run
+                                  * while the next one is on the wire */
 } golap_sharded_join_info;
 int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* comm, const golap_sharded_join_params* params, void* stream);
 int32_t golap_sharded_join_info_get(golap_comm* comm, golap_sharded_join_info* out);
