@@ -26,7 +26,7 @@ def main():
         rnd += 1
         nb = int(rng.integers(20_000_000, 70_000_000))
         npr = int(rng.integers(1_000_000, 70_000_000))
-        kind = str(rng.choice(["unique", "dups", "wide", "one_wide", "skew"]))
+        kind = str(rng.choice(["unique", "dups", "wide", "one_wide", "skew", "neg_pos", "halves", "many_halves", "halves_one_odd"]))
         dom = nb if kind != "dups" else nb // 3
         bt = ctx.generate(N.GEN_BUILD_KEYS if kind != "dups" else N.GEN_SM64_MOD_I64, nb, modulus=dom, seed=int(rng.integers(1, 1000)))
         pt = ctx.generate(N.GEN_SM64_MOD_I64, npr, modulus=int(dom * rng.choice([1.0, 1.3])), seed=int(rng.integers(1, 1000)))
@@ -36,6 +36,16 @@ def main():
         elif kind == "one_wide":
             i = int(rng.integers(0, nb)); j = int(rng.integers(0, npr))
             bt[i] = -11; pt[j] = -11
+        elif kind == "neg_pos":                                       # upper halves FFFFFFFF and 0: the dictionary form of the tuple pipeline
+            bt -= dom // 2; pt -= dom // 2
+        elif kind in ("halves", "halves_one_odd"):                    # 2 .. 4 upper halves; one_odd: plus a key whose upper half no sample can have seen
+            k = int(rng.integers(2, 5))
+            bt += (bt % k) << 40; pt += (pt % k) << 40
+            if kind == "halves_one_odd":
+                i = int(rng.integers(0, nb)); j = int(rng.integers(0, npr))
+                bt[i] = (9 << 40) + 5; pt[j] = (9 << 40) + 5
+        elif kind == "many_halves":                                   # the 64-bit-row pipeline
+            bt += ((bt * 0x9E3779B1) & 0xFF) << 36; pt += ((pt * 0x9E3779B1) & 0xFF) << 36
         elif kind == "skew":                                          # a hot key: 200k extra build rows, 50 probe rows
             bt[:200_000] = 4242
             pt[:50] = 4242
