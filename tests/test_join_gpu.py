@@ -818,3 +818,27 @@ def test_large_provision_sigmas_size_the_buffers_too(sigmas):
             pairs, cnt = c.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
             v = c.verify_pairs(pairs, n, bt, pt).cpu().numpy().view(np.uint64)
             assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2
+
+
+def test_wide_first_pass_forms_agree(ctx):
+    """The 64-bit pipeline's first pass in its three forms -- round 1's k_scatter_big (GOLAP_P1W=0), k_part1_narrow<.., WIDE> with hidden
+    loads / stores and counted waits (1, the default) and with compiler-visible ones (2) -- on a key column with 256 upper halves whose
+    fold lo ^ hi is still a bijection (no hash collisions: the no-histogram layouts hold), n not a multiple of any tile: every probe row
+    must come back with exactly its partner."""
+    n = 30_000_011
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    inv = torch.empty(n, dtype=torch.int64, device="cuda")
+    inv[bt] = torch.arange(n, dtype=torch.int64, device="cuda")
+    exp = inv[pt]
+    del inv
+    bt = bt + ((bt & 0xFF) << 36)
+    pt = pt + ((pt & 0xFF) << 36)
+    for form in ("1", "2", "0"):
+        ctx.stats_reset()
+        m, got = _pairs_by_probe(ctx, bt, pt, n, GOLAP_P1W=form)
+        st = ctx.stats()
+        assert st["join_build_probe_lds_wide"]["total_ms"] > st["join_build_probe_lds"]["total_ms"], f"GOLAP_P1W={form}: the 64-bit pipeline did not run"
+        assert st["radix_scatter_p1_wide"]["total_ms"] > 0.05 and "radix_hist_p2" not in st, f"GOLAP_P1W={form}: not the no-histogram flow"
+        bad = torch.nonzero(got != exp).flatten()
+        assert m == n and bad.numel() == 0, f"GOLAP_P1W={form}: {m} pairs for {n} probe rows; {bad.numel()} probe rows without exactly their partner"
