@@ -294,6 +294,61 @@ def test_sharded_join_rccl_world1(mode):
     assert info["fast_path"] == (mode == "fast")
 
 
+def test_rccl_world1_chunks_halves_composite_and_aggregate():
+    """The round-3 pieces over the built-in RCCL transport at world size 1 (the only RCCL a one-GPU box has): a fast-path join with row
+    chunks and group halves forced on (self-messages: every bucket is this rank's own), the composite / NULL-key pre-pass (its
+    all-gather of the value ranges), and golap_sharded_aggregate in both key modes (table all-gather, partition + self-exchange)."""
+    import oracle
+    from gpu_olap_engine_amd import _native as N
+    from np_twin import canonical
+    n = 25_000_000
+
+    def body(comm, c):
+        c.debug_set("GOLAP_SHARD_FAST", "1")
+        c.debug_set("GOLAP_SHARD_CHUNKS", "4")
+        c.debug_set("GOLAP_SHARD_HALVES", "2")
+        b = c.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+        p = c.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+        out = torch.empty((n + 16, 2), dtype=torch.int32, device="cuda")
+        pairs, cnt = comm.sharded_join(b, p, 0, 0, n, out_pairs=out)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        v = c.verify_pairs(pairs, m, b, p).cpu()
+        info = comm.info()
+        assert m == n and int(v[0]) == n and (int(v[2]) & (2**64 - 1)) == (n * (n - 1) // 2) & (2**64 - 1)
+        assert info["fast_path"] and info["chunks"] == 4 and info["halves"] == 2
+        # composite + NULL keys
+        bc, pc, bv, pv = _composite_rows(30_000)
+        cu = lambda a: None if a is None else torch.from_numpy(a).cuda()
+        out2 = torch.empty((3_000_000, 2), dtype=torch.int32, device="cuda")
+        pairs2, cnt2 = comm.sharded_join([cu(x) for x in bc], [cu(x) for x in pc], 0, 0, 30_000, out_pairs=out2, join_type=3,
+                                         build_valid=[cu(x) for x in bv], probe_valid=[cu(x) for x in pv])
+        torch.cuda.synchronize()
+        exp, me = oracle.hash_join_multi(bc, pc, 3, bv, pv)
+        got = canonical(pairs2[:int(cnt2.item())].cpu().numpy().view(np.uint32))
+        assert got.shape[0] == me and np.array_equal(got, exp)
+        # aggregates
+        for hashed in (False, True):
+            k, vals, vn = _agg_rows(400_000, 3000, hashed)
+            kt, vt = torch.from_numpy(k).cuda(), torch.from_numpy(vals).cuda()
+            res = comm.sharded_aggregate([(N.AGG_SUM, 0), (N.AGG_COUNT, 0)], [vt], group_keys=kt, n_groups=3000 + (8 if hashed else 0), hashed=hashed)
+            torch.cuda.synchronize()
+            uk, inv = np.unique(k, return_inverse=True)
+            s = np.zeros(uk.size); np.add.at(s, inv, vals)
+            cexp = np.bincount(inv, minlength=uk.size).astype(np.float64)
+            if hashed:
+                outp, okeys, ong = res
+                g = int(ong.item())
+                order = np.argsort(okeys[:g].cpu().numpy())
+                assert g == uk.size and np.array_equal(okeys[:g].cpu().numpy()[order], uk)
+                assert np.array_equal(outp[0, :g].cpu().numpy()[order], s) and np.array_equal(outp[1, :g].cpu().numpy()[order], cexp)
+            else:
+                assert np.array_equal(res[0].cpu().numpy()[uk], s) and np.array_equal(res[1].cpu().numpy()[uk], cexp)
+        return info
+
+    _rccl_world1(body)
+
+
 def test_rccl_message_size_boundary():
     """Where do large single RCCL messages stop arriving intact on this stack?  Round 1 saw an 8 GB self-message deliver wrong
     data (scripts/dbg_sharded.py CHECK_BIG).  golap_sharded_join never sends more than max_msg_bytes (default 512 MiB) in one
