@@ -11,6 +11,7 @@
 //              join_kernels.cuh:216-240 (slot = key % num_groups).
 //   widening   arrow-interop/src/record_batch_convert.rs:35-110.
 #include "golap_device.h"
+#include "golap_hidden.h"
 #include "golap_internal.h"
 
 #include <algorithm>
@@ -323,7 +324,8 @@ __device__ __forceinline__ uint32_t slot_of(KeyT key, uint32_t n_groups) {
 template <typename KeyT, bool VAL_F64, bool NEED_MM>
 __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n, uint32_t n_groups,
                                                     unsigned long long rows_per_block, double* __restrict__ slab /*[grid][4][n_groups]*/,
-                                                    const uint8_t* __restrict__ vv = nullptr /*validity of the value column, 0 = NULL: skipped*/) {
+                                                    const uint8_t* __restrict__ vv = nullptr /*validity of the value column, 0 = NULL: skipped*/,
+                                                    int vec = 0 /*16-byte loads: see the loop*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_sum = reinterpret_cast<double*>(s_raw);
     double* s_mn = s_sum + n_groups;
@@ -336,9 +338,56 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
     const unsigned long long lo = (unsigned long long)blockIdx.x * rows_per_block;
     unsigned long long hi = lo + rows_per_block;
     if (hi > n) hi = n;
-    // 8 rows per thread per round, loads unconditional on clamped indices so that all 16 are in flight together
+    // 8 rows per thread per round, loads unconditional on clamped indices so that all of them are in flight together
     // (a conditional load compiles to branch + s_waitcnt vmcnt(0) and serialises them)
     constexpr int GR = 8;
+    auto fold = [&](KeyT key, double xv) {
+        const uint32_t g = slot_of(key, n_groups);
+        atomicAdd(&s_sum[g], xv);
+        atomicAdd(&s_cnt[g], 1u);
+        if (NEED_MM) {   // MIN / MAX requested by some spec: two more LDS atomics per row
+            __hip_atomic_fetch_min(&s_mn[g], xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&s_mx[g], xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    if (vec) {
+        // 16-byte loads (round 3): a thread takes 4 consecutive rows -- one load for four int32 keys (two for int64 keys), two for
+        // their values -- instead of eight 4- and 8-byte loads per 8 rows.  Needs 16-byte aligned columns, no validity bytes and a
+        // block range that starts on a multiple of 4 (the host checks all three); the last < 4 rows of the range go one by one.
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const unsigned long long hi4 = lo + ((hi - lo) & ~3ull);
+        for (unsigned long long base = lo; base < hi4; base += (unsigned long long)blockDim.x * GR) {
+            u4 kq[GR / 4 * (sizeof(KeyT) / 4)], xq[GR / 4 * 2];
+#pragma unroll
+            for (int u = 0; u < GR / 4; ++u) {
+                unsigned long long i = base + ((unsigned long long)u * blockDim.x + threadIdx.x) * 4;
+                if (i >= hi4) i = hi4 - 4;
+                if (sizeof(KeyT) == 4) kq[u] = *reinterpret_cast<const u4*>(keys + i);
+                else { kq[2 * u] = *reinterpret_cast<const u4*>(keys + i); kq[2 * u + 1] = *reinterpret_cast<const u4*>(keys + i + 2); }
+                xq[2 * u] = *reinterpret_cast<const u4*>(vi + i);
+                xq[2 * u + 1] = *reinterpret_cast<const u4*>(vi + i + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < GR / 4; ++u) {
+                const unsigned long long i = base + ((unsigned long long)u * blockDim.x + threadIdx.x) * 4;
+                if (i < hi4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        KeyT key;
+                        if (sizeof(KeyT) == 4) key = (KeyT)(int)kq[u][j];
+                        else { const u4 q = kq[2 * u + (j >> 1)]; key = (KeyT)(((unsigned long long)q[2 * (j & 1) + 1] << 32) | q[2 * (j & 1)]); }
+                        const u4 q = xq[2 * u + (j >> 1)];
+                        const unsigned long long bits = ((unsigned long long)q[2 * (j & 1) + 1] << 32) | q[2 * (j & 1)];
+                        fold(key, VAL_F64 ? __longlong_as_double((long long)bits) : (double)(long long)bits);
+                    }
+                }
+            }
+        }
+        if (threadIdx.x < (uint32_t)(hi - hi4)) {
+            const unsigned long long i = hi4 + threadIdx.x;
+            fold(keys[i], VAL_F64 ? vf[i] : (double)vi[i]);
+        }
+    } else
     for (unsigned long long base = lo; base < hi; base += (unsigned long long)blockDim.x * GR) {
         KeyT k[GR];
         double x[GR];
@@ -354,15 +403,7 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
             const unsigned long long i = base + (unsigned long long)r * blockDim.x + threadIdx.x;
-            if (i < hi && ok[r]) {   // SQL aggregates skip NULL values (COUNT counts the non-NULL ones)
-                const uint32_t g = slot_of(k[r], n_groups);
-                atomicAdd(&s_sum[g], x[r]);
-                atomicAdd(&s_cnt[g], 1u);
-                if (NEED_MM) {   // MIN / MAX requested by some spec: two more LDS atomics per row
-                    __hip_atomic_fetch_min(&s_mn[g], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_max(&s_mx[g], x[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
+            if (i < hi && ok[r]) fold(k[r], x[r]);   // SQL aggregates skip NULL values (COUNT counts the non-NULL ones)
         }
     }
     __syncthreads();
@@ -429,8 +470,10 @@ constexpr uint32_t AG_NULL_MARK = 0x80000000u;   // partition path: top bit of t
 
 template <typename KeyT>
 __global__ __launch_bounds__(AG_THREADS) void k_agg_hist(const KeyT* __restrict__ keys, unsigned long long n, uint32_t n_groups, uint32_t chunk_rows,
-                                                         uint32_t S, uint32_t B, uint32_t* __restrict__ hist /*[B][S]*/, uint32_t gb_shift) {
+                                                         uint32_t S, uint32_t B, uint32_t* __restrict__ hist /*[B][S]*/, uint32_t gb_shift,
+                                                         const uint32_t* __restrict__ run_if = nullptr /*non-null: a no-op unless *run_if != 0*/) {
     __shared__ uint32_t s_cnt[AG_MAX_B];
+    if (run_if && *run_if == 0) return;
     const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
     if (lo >= n) return;
     const unsigned long long hi = lo + chunk_rows < n ? lo + chunk_rows : n;
@@ -664,7 +707,8 @@ template <typename KeyT, bool VAL_F64, int AGW_THREADS, int AGW_WIN>
 __global__ __launch_bounds__(AGW_THREADS) void k_agg_scatter_wc(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
                                                                 uint32_t n_groups, uint32_t gb_shift, uint32_t chunk_rows, uint32_t S, uint32_t B,
                                                                 const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
-                                                                double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr) {
+                                                                double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr,
+                                                                const uint32_t* __restrict__ run_if = nullptr /*non-null: a no-op unless *run_if != 0*/) {
     constexpr int AGW_TILE = AGW_THREADS * AGW_RPT;
     static_assert(AGW_WIN % AGW_THREADS == 0, "window rows per thread");
     static_assert(3 * AGW_WIN >= AGW_TILE + AGW_MAX_B * (AGW_CL - 1), "a tile and its carried rows pass the window in at most three rounds");
@@ -679,6 +723,7 @@ __global__ __launch_bounds__(AGW_THREADS) void k_agg_scatter_wc(const KeyT* __re
     uint32_t* s_carry = s_gpos + AGW_MAX_B;                               // [B] rows carried into this tile
     uint32_t* s_emit = s_carry + AGW_MAX_B;                               // [B] rows that leave in this tile (the rest is carried on)
     uint32_t* s_w = s_emit + AGW_MAX_B;                                   // [<= 16] wave totals, [16] rows staged in this tile
+    if (run_if && *run_if == 0) return;
     const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
     if (lo >= n) return;
     const unsigned long long hi = lo + chunk_rows < n ? lo + chunk_rows : n;
@@ -800,12 +845,231 @@ __global__ __launch_bounds__(AGW_THREADS) void k_agg_scatter_wc(const KeyT* __re
     }
 }
 
+// ---------------------------------------------------------------------------
+// Partition scatter WITHOUT a histogram pass (round 3): the shape of the join's first pass (k_part1_narrow, WIDE form) on
+// (slot32, value64) rows.  Bucket b owns AGR_NSUB sub-ranges of `cap` rows (one per XCD: work-groups b and b + 8 share an L2, so the
+// line at the boundary of two neighbouring runs is completed inside one L2); a tile reserves its run in every bucket with one
+// returning atomic per (tile, bucket) on cursor[b * AGR_NSUB + blockIdx.x % AGR_NSUB].  One 1024-thread work-group per CU, a
+// register-resident 12288-row tile that passes the LDS window in ONE round (12 bytes per row), the next tile's loads requested as soon
+// as the tile is staged, so that HBM reads run under the write-out; ASM: hidden 16-byte loads, hidden stores issued at wave-uniform
+// control flow and a counted vmcnt (golap_hidden.h) -- the compiler-visible form waits vmcnt(0), i.e. for every store of the
+// write-out, before it touches a prefetched key.
+// Against histogram + k_agg_scatter_wc: no second read of the key column (4 GB per 1B int32 keys), no scan, 3 barriers per tile
+// instead of 8.  Price: the ranges are provisioned (cap = mean * (1 + 1/8) + a tile), not exact -- a slot range that receives more
+// than that (skewed groups) raises flags[0]; every work-group that starts afterwards returns at once, and the histogram path,
+// enqueued behind with run_if = flags, redoes the pass exactly.  k_agg_sample raises the same word beforehand when a sample of the
+// key column already shows the skew, so that such inputs do not pay for the attempt.  Row order inside a bucket is arrival order:
+// as with every LDS-atomic fold here, only sums of exactly representable terms are order-independent.
+// Rows handled: a multiple of 4 (a thread takes 4 consecutive rows: one 16-byte load of int32 keys, two of int64 keys, two of
+// values); the column's last n % 4 rows are appended by k_agg_scatter_tail.
+// ---------------------------------------------------------------------------
+constexpr int AGR_THREADS = 1024;
+constexpr int AGR_RPT = 12;
+constexpr int AGR_TILE = AGR_THREADS * AGR_RPT;   // 12288 rows = the LDS window
+constexpr int AGR_NSUB = 8;
+static constexpr size_t agr_lds(uint32_t B) { return (size_t)AGR_TILE * 12 + (size_t)B * 12 + (AGR_THREADS / 64 + 2) * 4 + 16; }
+
+template <typename KeyT, bool VAL_F64, bool ASM>
+__global__ __launch_bounds__(AGR_THREADS) void k_agg_scatter_rsv(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n4 /*rows, a multiple of 4*/,
+                                                                 uint32_t n_groups, uint32_t gb_shift, uint32_t chunk_rows /*a multiple of 4*/, uint32_t B,
+                                                                 uint32_t* __restrict__ cursor /*[B * AGR_NSUB], zeroed*/, uint32_t cap,
+                                                                 uint32_t* __restrict__ flags /*[0]: a range overflowed (or will)*/,
+                                                                 uint32_t* __restrict__ out_slot, double* __restrict__ out_val) {
+    constexpr int NT = AGR_THREADS, NW = NT / 64, RPT = AGR_RPT, TILE = AGR_TILE, UNITS = RPT / 4, KQ = sizeof(KeyT) / 4;
+    constexpr int STORES = 2 * RPT;   // store instructions per wave behind the next tile's loads (ASM: all of them are issued)
+    static_assert(STORES <= 60, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    u32x2* s_val = reinterpret_cast<u32x2*>(s_raw);                          // [TILE] value bits
+    uint32_t* s_slot = reinterpret_cast<uint32_t*>(s_raw + (size_t)TILE * 8);   // [TILE] slot words
+    uint32_t* s_cnt = s_slot + TILE;                                          // [B] rows of the bucket in this tile
+    uint32_t* s_start = s_cnt + B;                                            // [B] tile-local position of the bucket's first row
+    uint32_t* s_delta = s_start + B;                                          // [B] output row - tile-local position
+    uint32_t* s_w = s_delta + B;                                              // [NW] wave totals
+    if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // work-group-uniform: the histogram path does the work
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk_rows;
+    if (lo >= n4) return;
+    const uint32_t len = (uint32_t)((lo + chunk_rows < n4 ? lo + chunk_rows : n4) - lo);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t sub = blockIdx.x % AGR_NSUB;
+    const unsigned long long* vals = (const unsigned long long*)val;
+    if (tid < B) s_cnt[tid] = 0;
+
+    u32x4 kq[UNITS * KQ], xq[UNITS * 2];
+    // rows of unit u: 4 * (u * NT + tid) + {0, 1, 2, 3}; units past the tile's end re-read its last one (unconditional loads)
+    auto load_tile = [&](uint32_t t0) {
+        const uint32_t tn = len - t0 < (uint32_t)TILE ? len - t0 : (uint32_t)TILE;   // a multiple of 4, >= 4
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            uint32_t ub = 4u * ((uint32_t)u * NT + tid);
+            if (ub >= tn) ub = tn - 4u;
+            const KeyT* kp = keys + lo + t0 + ub;
+            const unsigned long long* xp = vals + lo + t0 + ub;
+            if (ASM) {
+                ld16_hidden(kq[u * KQ], kp);
+                if (KQ == 2) ld16_hidden(kq[u * KQ + KQ - 1], kp + 2);
+                ld16_hidden(xq[2 * u], xp);
+                ld16_hidden(xq[2 * u + 1], xp + 2);
+            } else {
+                kq[u * KQ] = *reinterpret_cast<const u32x4*>(kp);
+                if (KQ == 2) kq[u * KQ + KQ - 1] = *reinterpret_cast<const u32x4*>(kp + 2);
+                xq[2 * u] = *reinterpret_cast<const u32x4*>(xp);
+                xq[2 * u + 1] = *reinterpret_cast<const u32x4*>(xp + 2);
+            }
+        }
+    };
+    load_tile(0);
+    for (uint32_t t0 = 0; t0 < len; t0 += TILE) {
+        const uint32_t tn = len - t0 < (uint32_t)TILE ? len - t0 : (uint32_t)TILE;
+        if (t0 == 0) lds_barrier();   // s_cnt zeroed (later tiles: re-zeroed by the scan below, two barriers ago)
+        if (ASM) {
+            // the tile was requested before the STORES stores of the previous write-out: it has landed once at most STORES operations
+            // are outstanding (first tile: nothing is younger)
+            if (t0 == 0) wait_vmcnt<0>(); else wait_vmcnt<STORES>();
+#pragma unroll
+            for (int q = 0; q < UNITS * KQ; ++q) pin(kq[q]);
+#pragma unroll
+            for (int q = 0; q < UNITS * 2; ++q) pin(xq[q]);
+        }
+        uint32_t slot[RPT], br[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int u = r >> 2, j = r & 3;
+            KeyT key;
+            if (KQ == 1) key = (KeyT)(int)kq[u][j];
+            else key = (KeyT)(((unsigned long long)kq[u * KQ + (j >> 1)][2 * (j & 1) + 1] << 32) | kq[u * KQ + (j >> 1)][2 * (j & 1)]);
+            slot[r] = slot_of(key, n_groups);
+            br[r] = 0xFFFFFFFFu;
+            if (4u * ((uint32_t)u * NT + tid) < tn) {
+                const uint32_t b = slot[r] >> gb_shift;
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 128, rank < 12288
+            }
+        }
+        lds_barrier();
+        uint32_t c = 0, rsv = 0, start;
+        if (tid < B) {
+            c = s_cnt[tid];
+            s_cnt[tid] = 0;   // for the next tile
+            if (c) {
+                if (ASM) atomic_add_rtn_hidden(rsv, cursor + tid * AGR_NSUB + sub, c);
+                else rsv = atomicAdd(&cursor[tid * AGR_NSUB + sub], c);
+            }
+        }
+        {
+            const uint32_t inc = wave_inclusive_scan(c);
+            if (lane == 63) s_w[wv] = inc;
+            lds_barrier();
+            uint32_t base = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) base += (uint32_t)i < wv ? s_w[i] : 0u;
+            start = base + inc - c;
+            if (tid < B) s_start[tid] = start;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            if (br[r] != 0xFFFFFFFFu) {
+                const int u = r >> 2, j = r & 3;
+                const uint32_t pos = s_start[br[r] >> 16] + (br[r] & 0xFFFFu);
+                const u32x4 q = xq[2 * u + (j >> 1)];
+                u32x2 bits{q[2 * (j & 1)], q[2 * (j & 1) + 1]};
+                if (!VAL_F64) {   // executor.rs:521 `as f64`
+                    const double d = (double)(long long)(((unsigned long long)bits.y << 32) | bits.x);
+                    const unsigned long long db = (unsigned long long)__double_as_longlong(d);
+                    bits = u32x2{(uint32_t)db, (uint32_t)(db >> 32)};
+                }
+                s_val[pos] = bits;
+                s_slot[pos] = slot[r];
+            }
+        }
+        if (ASM) {   // nothing hidden is younger than the reservation here (the next tile's loads follow below)
+            wait_vmcnt<0>();
+            asm volatile("" : "+v"(rsv));
+        }
+        if (tid < B) {   // the reservations have had the scan and the staging to come back
+            s_delta[tid] = (tid * AGR_NSUB + sub) * cap + rsv - start;
+            if (rsv + c > cap) atomicOr(flags, 1u);   // (rsv + c cannot wrap: both < 2^31)
+        }
+        if (t0 + TILE < len) load_tile(t0 + TILE);   // key and value registers are dead: the next tile streams in during the write-out
+        lds_barrier();
+#pragma unroll 4
+        for (int j = 0; j < RPT; ++j) {   // ASM: every store instruction is issued, whatever the data
+            const uint32_t i = (uint32_t)j * NT + tid;
+            const uint32_t sl = s_slot[i];
+            const u32x2 v = s_val[i];
+            uint32_t b = sl >> gb_shift;
+            b = b < B ? b : B - 1u;   // (rows beyond tn hold stale words)
+            const uint32_t gp = s_delta[b] + i;
+            const uint32_t ok = (i < tn && gp < (b * AGR_NSUB + sub + 1u) * cap) ? 1u : 0u;   // rows past a range are dropped (flags[0] raised above)
+            if (ASM) {
+                st8_hidden_if(out_val + gp, v, ok);
+                st4_hidden_if(out_slot + gp, sl, ok);
+            } else if (ok) {
+                reinterpret_cast<u32x2*>(out_val)[gp] = v;
+                out_slot[gp] = sl;
+            }
+        }
+        // (the next LDS writes that could collide -- s_start, s_delta, the window -- all sit behind the next tile's barriers)
+    }
+    if (ASM) wait_vmcnt<0>();
+}
+
+// the last n % 4 rows of the column (k_agg_scatter_rsv takes whole 16-byte units): appended to sub-range 0 of their buckets
+template <typename KeyT, bool VAL_F64>
+__global__ void k_agg_scatter_tail(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long first, unsigned long long n,
+                                   uint32_t n_groups, uint32_t gb_shift, uint32_t* __restrict__ cursor, uint32_t cap, uint32_t* __restrict__ flags,
+                                   uint32_t* __restrict__ out_slot, double* __restrict__ out_val) {
+    const unsigned long long i = first + threadIdx.x;
+    if (i >= n || *flags) return;
+    const uint32_t sl = slot_of(keys[i], n_groups), b = sl >> gb_shift;
+    const uint32_t pos = atomicAdd(&cursor[b * AGR_NSUB], 1u);
+    if (pos >= cap) { atomicOr(flags, 1u); return; }
+    out_slot[(size_t)b * AGR_NSUB * cap + pos] = sl;
+    out_val[(size_t)b * AGR_NSUB * cap + pos] = VAL_F64 ? ((const double*)val)[i] : (double)((const long long*)val)[i];
+}
+
+// Will the provisioned ranges hold?  A strided sample of the key column (16-row runs, `stride` rows apart: 2^20 rows at most) is
+// counted per bucket -- per work-group in LDS, then into tally[0 .. B) -- and the work-group that finishes last compares: a bucket
+// whose share of the sample exceeds the mean by more than 1/16 (half the slack of the provisioning; the sample's own sigma is ~1 % at
+// 2^20 rows and 128 buckets) raises flags[0], and the histogram path runs instead at no extra cost.
+constexpr int AGS_THREADS = 256;
+template <typename KeyT>
+__global__ __launch_bounds__(AGS_THREADS) void k_agg_sample(const KeyT* __restrict__ keys, unsigned long long n, uint32_t n_groups, uint32_t gb_shift, uint32_t B,
+                                                            uint32_t runs, unsigned long long stride,
+                                                            uint32_t* __restrict__ tally /*[B] counts, [B] rows sampled, [B + 1] work-groups done; zeroed*/,
+                                                            uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_cnt[AGW_MAX_B];
+    __shared__ uint32_t s_last;
+    if (threadIdx.x < AGW_MAX_B) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t r = blockIdx.x * (AGS_THREADS / 16) + (threadIdx.x >> 4); r < runs; r += gridDim.x * (AGS_THREADS / 16)) {
+        const unsigned long long i = (unsigned long long)r * stride + (threadIdx.x & 15);
+        if (i < n) { atomicAdd(&s_cnt[slot_of(keys[i], n_groups) >> gb_shift], 1u); ++mine; }
+    }
+    __syncthreads();
+    if (threadIdx.x < B && s_cnt[threadIdx.x]) atomicAdd(&tally[threadIdx.x], s_cnt[threadIdx.x]);
+    if (mine) atomicAdd(&tally[B], mine);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tally[B + 1], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < B) {
+        const unsigned long long c = __hip_atomic_load(&tally[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long tot = __hip_atomic_load(&tally[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c * B * 16ull > tot * 17ull + 64ull * B * 16ull) atomicOr(flags, 1u);   // c > (tot / B) * 17/16 + 64
+    }
+}
+
 // bucket b = slots [b*GB, (b+1)*GB); work-group (b, w) folds its share of the bucket's rows into an LDS table.  GB = AG_GB (2048
 // slots x 28 bytes: all four statistics) or, when no MIN / MAX is asked for, AG_GB_SUM (8192 slots x 12 bytes: sum + count).
 template <bool NEED_MM, int GB = AG_GB, int NT = AG_THREADS>
 __global__ __launch_bounds__(NT) void k_agg_bucket(const uint32_t* __restrict__ slot, const double* __restrict__ val,
                                                    const uint32_t* __restrict__ scanned, uint32_t S, uint32_t W,
-                                                   double* __restrict__ slab /*[B*W][4][GB]*/) {
+                                                   double* __restrict__ slab /*[B*W][4][GB]*/,
+                                                   const uint32_t* __restrict__ rsv_cursor = nullptr /*k_agg_scatter_rsv's layout (W sub-ranges of rsv_cap rows per bucket) ...*/,
+                                                   uint32_t rsv_cap = 0, const uint32_t* __restrict__ rsv_flags = nullptr /*... unless *rsv_flags != 0*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_sum = reinterpret_cast<double*>(s_raw);
     double* s_mn = s_sum + GB;                               // NEED_MM only
@@ -818,10 +1082,17 @@ __global__ __launch_bounds__(NT) void k_agg_bucket(const uint32_t* __restrict__ 
         if (NEED_MM) { s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; }
     }
     __syncthreads();
-    const uint32_t o0 = scanned[(size_t)b * S], o1 = scanned[(size_t)(b + 1) * S];
-    const uint32_t share = (o1 - o0 + W - 1) / W;
-    const uint32_t lo = o0 + w * share < o1 ? o0 + w * share : o1;
-    const uint32_t hi = lo + share < o1 ? lo + share : o1;
+    uint32_t lo, hi;
+    if (rsv_cursor && *rsv_flags == 0) {   // work-group (b, w) takes sub-range w
+        const uint32_t c = rsv_cursor[b * W + w];
+        lo = (b * W + w) * rsv_cap;
+        hi = lo + (c < rsv_cap ? c : rsv_cap);
+    } else {
+        const uint32_t o0 = scanned[(size_t)b * S], o1 = scanned[(size_t)(b + 1) * S];
+        const uint32_t share = (o1 - o0 + W - 1) / W;
+        lo = o0 + w * share < o1 ? o0 + w * share : o1;
+        hi = lo + share < o1 ? lo + share : o1;
+    }
     const uint32_t kbase = b * GB;
     for (uint32_t base = lo; base < hi; base += NT * 8) {
         uint32_t k[8];
@@ -1187,6 +1458,7 @@ namespace golap {
 static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs, uint32_t n_specs, const golap_aggregate_params* p, hipStream_t st) {
     const uint32_t G = p->n_groups;
     const bool grouped = p->group_key_ptr != 0;
+    ctx->prof.cur_gate_host = nullptr;
     // LDS path when the 28-byte-per-group table fits comfortably (2 work-groups per CU)
     const bool lds_path = grouped && (uint64_t)G * 28 <= 64 * 1024;
     // beyond one LDS table: partition by slot range, then LDS-aggregate (big inputs only; GOLAP_AGG_PART=0 -> global atomics)
@@ -1209,6 +1481,18 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     const uint32_t p_chunk = part_path ? (uint32_t)round_up(ceil_div(p->n_rows, pS), AG_TILE) : 0;
     const uint32_t pS2 = part_path ? (uint32_t)ceil_div(p->n_rows, p_chunk) : 0;   // chunks actually used
     const uint32_t pW = part_path ? std::max<uint32_t>(1, std::min<uint32_t>(8, (p_wc ? 1024u : 2048u) / pB)) : 0;
+    // no histogram pass: provisioned sub-ranges + reservations (k_agg_scatter_rsv), the histogram path standing by behind a device
+    // word.  Needs 16-byte aligned columns without validity bytes (checked per value column).  GOLAP_AGG_RSV=0: A/B hook; =plain: the
+    // compiler-visible form of the kernel.
+    const char* rsv_env = knob("GOLAP_AGG_RSV");
+    const uint64_t n4 = p->n_rows & ~3ull;
+    const uint64_t rsv_cap64 = p_wc ? round_up(ceil_div(p->n_rows, (uint64_t)pB * AGR_NSUB) * 9 / 8 + AGR_TILE, 32) : 0;
+    const bool p_rsv = p_wc && pW == (uint32_t)AGR_NSUB && (uint64_t)pB * AGR_NSUB * rsv_cap64 < 0xFFFFFFF0ull && (p->group_key_ptr & 15) == 0 &&
+                       !(rsv_env && !strcmp(rsv_env, "0"));
+    const uint32_t rsv_cap = (uint32_t)rsv_cap64;
+    const uint64_t part_rows = p_rsv ? (uint64_t)pB * AGR_NSUB * rsv_cap : p->n_rows;   // rows of the partition buffers
+    const uint32_t rsv_chunk = p_rsv ? (uint32_t)round_up(ceil_div(n4, 2048), AGR_TILE) : 0;
+    const uint32_t rsv_grid = p_rsv ? (uint32_t)ceil_div(n4, rsv_chunk) : 0;
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
     uint32_t lds_grid = 0;
     uint64_t rows_per_block = 0;
@@ -1216,25 +1500,30 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
         uint32_t per_cu = 2;
         if (const char* e = knob("GOLAP_AGG_WGS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));   // A/B hook
         lds_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * per_cu, ceil_div(std::max<uint64_t>(1, p->n_rows), 4096)));
-        rows_per_block = ceil_div(std::max<uint64_t>(1, p->n_rows), lds_grid);
+        rows_per_block = round_up(ceil_div(std::max<uint64_t>(1, p->n_rows), lds_grid), 4);   // (a multiple of 4: the 16-byte-load form)
     }
     const uint32_t red_grid = stream_grid(ctx, p->n_rows, OP_THREADS * 8);
     uint64_t ws = (uint64_t)G * 32 + 8192;
     ws += lds_path ? (uint64_t)lds_grid * 4 * G * 8 : 0;
     if (part_path)
-        ws += round_up(p->n_rows * 4, 256) + round_up(p->n_rows * 8, 256) + round_up(((uint64_t)pB * pS2 + 1) * 4, 256) +
-              round_up(ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4, 256) + round_up((uint64_t)pB * pW * 4 * pGB * 8, 256) + 4096;
+        ws += round_up(part_rows * 4, 256) + round_up(part_rows * 8, 256) + round_up(((uint64_t)pB * pS2 + 1) * 4, 256) +
+              round_up(ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4, 256) + round_up((uint64_t)pB * pW * 4 * pGB * 8, 256) + 4096 +
+              (p_rsv ? round_up(((uint64_t)pB * (AGR_NSUB + 1) + 16) * 4, 256) : 0);
     ws += grouped ? 0 : (uint64_t)red_grid * 32;
     GOLAP_TRY(ws_begin(ctx, ws + 4096, st));
     double* stats4 = (double*)ws_take(ctx, (uint64_t)G * 32);
     double* slab = lds_path ? (double*)ws_take(ctx, (uint64_t)lds_grid * 4 * G * 8) : nullptr;
     double* partials = grouped ? nullptr : (double*)ws_take(ctx, (uint64_t)red_grid * 32);
     if (!stats4 || (lds_path && !slab) || (!grouped && !partials)) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted");
-    uint32_t *p_slot = nullptr, *p_hist = nullptr, *p_bsums = nullptr;
+    uint32_t *p_slot = nullptr, *p_hist = nullptr, *p_bsums = nullptr, *p_rsvw = nullptr;
     double *p_val = nullptr, *p_slab = nullptr;
     if (part_path) {
-        p_slot = (uint32_t*)ws_take(ctx, p->n_rows * 4);
-        p_val = (double*)ws_take(ctx, p->n_rows * 8);
+        p_slot = (uint32_t*)ws_take(ctx, part_rows * 4);
+        p_val = (double*)ws_take(ctx, part_rows * 8);
+        if (p_rsv) {   // [0] flag, [1 .. 8) spare, [8 ..) cursors [B * NSUB], then the sample's tally [B + 2]
+            p_rsvw = (uint32_t*)ws_take(ctx, ((uint64_t)pB * (AGR_NSUB + 1) + 16) * 4);
+            if (!p_rsvw) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted (partition buffers)");
+        }
         p_hist = (uint32_t*)ws_take(ctx, ((uint64_t)pB * pS2 + 1) * 4);
         p_bsums = (uint32_t*)ws_take(ctx, ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4);
         p_slab = (double*)ws_take(ctx, (uint64_t)pB * pW * 4 * pGB * 8);
@@ -1252,6 +1541,11 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             const void* wcs2[] = {(const void*)k_agg_scatter_wc<int, true, 512, 3584>, (const void*)k_agg_scatter_wc<int, false, 512, 3584>,
                                   (const void*)k_agg_scatter_wc<long long, true, 512, 3584>, (const void*)k_agg_scatter_wc<long long, false, 512, 3584>};
             for (const void* f : wcs2) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)agw_lds(3584)));
+            const void* rsvs[] = {(const void*)k_agg_scatter_rsv<int, true, true>,        (const void*)k_agg_scatter_rsv<int, false, true>,
+                                  (const void*)k_agg_scatter_rsv<long long, true, true>,  (const void*)k_agg_scatter_rsv<long long, false, true>,
+                                  (const void*)k_agg_scatter_rsv<int, true, false>,       (const void*)k_agg_scatter_rsv<int, false, false>,
+                                  (const void*)k_agg_scatter_rsv<long long, true, false>, (const void*)k_agg_scatter_rsv<long long, false, false>};
+            for (const void* f : rsvs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)agr_lds(AGW_MAX_B)));
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<false, AG_GB_SUM, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB_SUM * 12 + 16));
             ctx->attr_done[1] = true;
         }
@@ -1293,11 +1587,13 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, red_grid, stats4);
         } else if (lds_path) {
             const size_t lds = (size_t)G * 28 + 16;
+            const char* vec_env = knob("GOLAP_AGG_VEC");   // "0": 4- / 8-byte loads (A/B hook)
+            const int lds_vec = !vv && ((p->group_key_ptr | (uint64_t)val) & 15) == 0 && !(vec_env && !strcmp(vec_env, "0")) ? 1 : 0;
             {
                 KernelTimer t(ctx, "hash_aggregate_lds", st, (key_bytes + 8) * p->n_rows + 12ull * G);
 #define GOLAP_LAUNCH_LDS(KT, VF, MM)                                                                                              \
     hipLaunchKernelGGL((k_group_lds<KT, VF, MM>), dim3(lds_grid), dim3(512), lds, st, (const KT*)p->group_key_ptr, val,          \
-                       (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab, vv)
+                       (unsigned long long)p->n_rows, G, (unsigned long long)rows_per_block, slab, vv, lds_vec)
                 if (p->key_dtype == GOLAP_DT_INT32) {
                     if (vf) { if (need_minmax) GOLAP_LAUNCH_LDS(int, true, true); else GOLAP_LAUNCH_LDS(int, true, false); }
                     else { if (need_minmax) GOLAP_LAUNCH_LDS(int, false, true); else GOLAP_LAUNCH_LDS(int, false, false); }
@@ -1313,19 +1609,55 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             }
         } else if (part_path) {
             const uint64_t L = (uint64_t)pB * pS2;
+            // the reserving scatter first (when this column allows it); everything of the histogram path below then runs only if the
+            // device word says so
+            const bool rsv = p_rsv && !vv && ((uint64_t)val & 15) == 0;
+            uint32_t *rsv_flags = nullptr, *rsv_cursor = nullptr;
+            if (rsv) {
+                rsv_flags = p_rsvw; rsv_cursor = p_rsvw + 8;
+                uint32_t* tally = rsv_cursor + (size_t)pB * AGR_NSUB;
+                GOLAP_TRY(zero_async(ctx, st, p_rsvw, ((uint64_t)pB * (AGR_NSUB + 1) + 16) * 4));
+                if (ctx->prof.enabled) {   // which of the two scatters did the work is read back (asynchronously) for the byte credits
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+                    ctx->prof.cur_gate_host = cs == hipStreamCaptureStatusNone ? ctx->prof.take_gate_slot() : nullptr;
+                }
+                const bool plain = rsv_env && !strcmp(rsv_env, "plain");
+                const uint32_t runs = (uint32_t)std::min<uint64_t>(65536, p->n_rows / 16);
+                const uint64_t stride = p->n_rows / runs;
+                KernelTimer t(ctx, "agg_partition_scatter", st, 0, (key_bytes + 8 + 12) * p->n_rows, false);
+#define GOLAP_AGG_RSV(KT, VF)                                                                                                         \
+    do {                                                                                                                              \
+        hipLaunchKernelGGL(k_agg_sample<KT>, dim3(256), dim3(AGS_THREADS), 0, st, (const KT*)p->group_key_ptr, (unsigned long long)p->n_rows, G, \
+                           gb_shift, pB, runs, (unsigned long long)stride, tally, rsv_flags);                                          \
+        if (plain)                                                                                                                    \
+            hipLaunchKernelGGL((k_agg_scatter_rsv<KT, VF, false>), dim3(rsv_grid), dim3(AGR_THREADS), agr_lds(pB), st, (const KT*)p->group_key_ptr, \
+                               val, (unsigned long long)n4, G, gb_shift, rsv_chunk, pB, rsv_cursor, rsv_cap, rsv_flags, p_slot, p_val); \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_agg_scatter_rsv<KT, VF, true>), dim3(rsv_grid), dim3(AGR_THREADS), agr_lds(pB), st, (const KT*)p->group_key_ptr, \
+                               val, (unsigned long long)n4, G, gb_shift, rsv_chunk, pB, rsv_cursor, rsv_cap, rsv_flags, p_slot, p_val); \
+        if (n4 != p->n_rows)                                                                                                          \
+            hipLaunchKernelGGL((k_agg_scatter_tail<KT, VF>), dim3(1), dim3(64), 0, st, (const KT*)p->group_key_ptr, val, (unsigned long long)n4, \
+                               (unsigned long long)p->n_rows, G, gb_shift, rsv_cursor, rsv_cap, rsv_flags, p_slot, p_val);             \
+    } while (0)
+                if (p->key_dtype == GOLAP_DT_INT32) { if (vf) GOLAP_AGG_RSV(int, true); else GOLAP_AGG_RSV(int, false); }
+                else { if (vf) GOLAP_AGG_RSV(long long, true); else GOLAP_AGG_RSV(long long, false); }
+#undef GOLAP_AGG_RSV
+            }
             GOLAP_TRY(zero_async(ctx, st, p_hist, (L + 1) * 4));
             {
-                KernelTimer t(ctx, "agg_partition_hist", st, key_bytes * p->n_rows);
+                KernelTimer t(ctx, rsv ? "agg_partition_hist_standby" : "agg_partition_hist", st, rsv ? 0 : key_bytes * p->n_rows, rsv ? key_bytes * p->n_rows : 0, true);
                 if (p->key_dtype == GOLAP_DT_INT32)
                     hipLaunchKernelGGL(k_agg_hist<int>, dim3(pS2), dim3(AG_THREADS), 0, st, (const int*)p->group_key_ptr, (unsigned long long)p->n_rows, G,
-                                       p_chunk, pS2, pB, p_hist, gb_shift);
+                                       p_chunk, pS2, pB, p_hist, gb_shift, (const uint32_t*)rsv_flags);
                 else
                     hipLaunchKernelGGL(k_agg_hist<long long>, dim3(pS2), dim3(AG_THREADS), 0, st, (const long long*)p->group_key_ptr,
-                                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, gb_shift);
+                                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, gb_shift, (const uint32_t*)rsv_flags);
             }
-            GOLAP_TRY(flat_scan(ctx, st, p_hist, (uint32_t)(L + 1), p_bsums));
+            GOLAP_TRY(flat_scan(ctx, st, p_hist, (uint32_t)(L + 1), p_bsums));   // (of zeros when the histogram did not run)
             {
-                KernelTimer t(ctx, "agg_partition_scatter", st, (key_bytes + 8 + 12) * p->n_rows);
+                KernelTimer t(ctx, rsv ? "agg_partition_scatter_standby" : "agg_partition_scatter", st, rsv ? 0 : (key_bytes + 8 + 12) * p->n_rows,
+                              rsv ? (key_bytes + 8 + 12) * p->n_rows : 0, true);
 #define GOLAP_AGG_SC(KT, VF)                                                                                                          \
     hipLaunchKernelGGL((k_agg_scatter<KT, VF>), dim3(pS2), dim3(AG_THREADS), 0, st, (const KT*)p->group_key_ptr, val,                 \
                        (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
@@ -1336,10 +1668,10 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     do {                                                                                                                              \
         if (wc_two)                                                                                                                   \
             hipLaunchKernelGGL((k_agg_scatter_wc<KT, VF, 512, 3584>), dim3(pS2), dim3(512), agw_lds(3584), st, (const KT*)p->group_key_ptr, val, \
-                               (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv);               \
+                               (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv, (const uint32_t*)rsv_flags); \
         else                                                                                                                          \
             hipLaunchKernelGGL((k_agg_scatter_wc<KT, VF, 1024, 9216>), dim3(pS2), dim3(1024), agw_lds(9216), st, (const KT*)p->group_key_ptr, val, \
-                               (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv);               \
+                               (unsigned long long)p->n_rows, G, gb_shift, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv, (const uint32_t*)rsv_flags); \
     } while (0)
                 // GOLAP_AGG_WC=512: the two-work-groups-per-CU shape (A/B hook).  Measured at 1B rows, 2^20 groups: 8.7 ms against 6.2 ms for
                 // the 1024-thread shape -- the per-tile fixed work (bucket scan, carry staging per window round) is paid twice as often
@@ -1362,13 +1694,18 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             {
                 KernelTimer t(ctx, "hash_aggregate_lds_buckets", st, 12 * p->n_rows + 12ull * G);
                 if (p_wc)
-                    hipLaunchKernelGGL((k_agg_bucket<false, AG_GB_SUM, 1024>), dim3(pB * pW), dim3(1024), AG_GB_SUM * 12 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
+                    hipLaunchKernelGGL((k_agg_bucket<false, AG_GB_SUM, 1024>), dim3(pB * pW), dim3(1024), AG_GB_SUM * 12 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab,
+                                       (const uint32_t*)rsv_cursor, rsv_cap, (const uint32_t*)rsv_flags);
                 else if (need_minmax)
                     hipLaunchKernelGGL(k_agg_bucket<true>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
                 else
                     hipLaunchKernelGGL(k_agg_bucket<false>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
                 hipLaunchKernelGGL(k_agg_bucket_fold, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, p_slab,
                                    pW, G, pGB, (int)(need_minmax && !p_wc), stats4);
+            }
+            if (rsv && ctx->prof.cur_gate_host) {
+                (void)hipMemcpyAsync((void*)ctx->prof.cur_gate_host, rsv_flags, 4, hipMemcpyDeviceToHost, st);
+                ctx->prof.cur_gate_host = nullptr;
             }
         } else {
             hipLaunchKernelGGL(k_group_init, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, stats4, G);

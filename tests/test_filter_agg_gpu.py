@@ -181,6 +181,57 @@ def test_grouped_aggregate_big_tile_partition(ctx, shape):
     assert np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
 
 
+RSV_CASES = ["uniform_i32_f64", "uniform_i64_i64", "hot_key", "hot_key_the_sample_cannot_see", "sequential", "unaligned", "plain_form"]
+
+
+@pytest.mark.parametrize("case", RSV_CASES)
+def test_grouped_aggregate_reserving_scatter(ctx, case):
+    """SUM / COUNT / AVG over > one LDS table of groups on >= 33.5M rows: the partition scatter without a histogram pass
+    (k_agg_scatter_rsv: provisioned sub-ranges + reservations) with the histogram path standing by.  Which of the two did the work is
+    read from the byte credits; the result must be the oracle's either way.
+      hot_key: half the rows in one group -- the key sample sees it, the attempt is not even started;
+      hot_key_the_sample_cannot_see: the same skew everywhere EXCEPT at the sampled positions -- a range overflows mid-way, the
+        histogram path redoes the pass;
+      sequential: sorted keys (every chunk feeds one bucket: the per-tile reservation is one long run);
+      unaligned: a key column that is not 16-byte aligned takes the histogram path;  plain_form: the compiler-visible kernel form."""
+    n, G = 40_000_123, 1_000_003   # n % 4 == 3: the last rows go through k_agg_scatter_tail
+    kd, vd = (np.int64, np.int64) if case == "uniform_i64_i64" else (np.int32, np.float64)
+    if case in ("hot_key", "hot_key_the_sample_cannot_see"):
+        keys = oracle.gen_sm64_mod(83, 0, n, G, kd)
+        hot = np.arange(n) % 2 == 0
+        if case == "hot_key_the_sample_cannot_see":   # k_agg_sample reads 16-row runs every n // 65536 rows
+            stride = n // 65536
+            hot &= (np.arange(n) % stride) >= 16
+        keys[hot] = 777_777
+    elif case == "sequential":
+        keys = ((np.arange(n, dtype=np.int64) * G) // n).astype(kd)
+    else:
+        keys = oracle.gen_sm64_mod(83, 0, n, G, kd)
+    vals = (oracle.gen_sm64_mod(84, 0, n, 4096, np.int64) - 2048).astype(vd)
+    ok, ost = oracle.group_aggregate(keys.astype(np.int64), vals.astype(np.float64))
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_AVG, 0)]
+    dk, dv = dev(keys), dev(vals)
+    if case == "unaligned":
+        dk = dev(np.concatenate([keys[:1], keys]))[1:]
+    ctx.stats_reset()
+    with ctx.knobs(GOLAP_AGG_RSV="plain" if case == "plain_form" else None):
+        out, counts = ctx.aggregate(specs, [dv], group_keys=dk, n_groups=G, want_counts=True)
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    st = ctx.stats()
+    present = counts > 0
+    assert np.array_equal(np.nonzero(present)[0], ok)
+    assert np.array_equal(out[0, present], ost[:, 0]) and np.array_equal(out[1, present], ost[:, 1]) and np.array_equal(out[2, present], ost[:, 4])
+    if case == "unaligned":
+        assert "agg_partition_scatter_standby" not in st and st["agg_partition_hist"]["bytes"] > 0
+    elif case in ("hot_key", "hot_key_the_sample_cannot_see"):
+        assert st["agg_partition_scatter"]["bytes"] == 0 and st["agg_partition_scatter_standby"]["bytes"] > 0
+        # (seen by the sample: the attempt returns at once; not seen: it runs into the overflow)
+        if case == "hot_key":
+            assert st["agg_partition_scatter"]["total_ms"] < 0.5 * st["agg_partition_scatter_standby"]["total_ms"]
+    elif case != "sequential":   # (sorted keys: whether every sub-range holds depends on how chunks fall on the XCDs -- either path is right)
+        assert st["agg_partition_scatter"]["bytes"] > 0 and st["agg_partition_scatter_standby"]["bytes"] == 0
+
+
 def test_grouped_two_value_columns_int_and_float(ctx):
     n, G = 200_000, 300
     keys = oracle.gen_sm64_mod(3, 0, n, G, np.int64)

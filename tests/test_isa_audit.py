@@ -1,11 +1,13 @@
-"""Static audit of the kernels that hide memory operations from hipcc (csrc/golap_part_narrow.h, ASM forms).
+"""Static audit of the kernels that hide memory operations from hipcc (csrc/golap_hidden.h: the ASM forms of csrc/golap_part_narrow.h
+and k_agg_scatter_rsv in csrc/golap_ops.hip).
 
 Those kernels issue their loads and stores in `asm volatile` statements and wait for them with hand-counted `s_waitcnt vmcnt(N)`
 (cdna_hip_programming.md 5.7).  That is only sound while the compiler (1) never spills -- a spilled or reloaded register may be the
 destination of a load that has not landed (wrong data, or a memory fault when it held an address: seen once on MI355X with a build
 that had 36 bytes of scratch), (2) never touches a hidden load's destination registers between the load and the counted wait, and
 (3) adds no `vmcnt` wait of its own inside the tile loop (it would drain the prefetch on every tile).  All three are properties of
-the generated code, so they are checked on the generated code: golap_join.hip is compiled to gfx950 assembly (no GPU needed)."""
+the generated code, so they are checked on the generated code: golap_join.hip and golap_ops.hip are compiled to gfx950 assembly (no
+GPU needed)."""
 import os
 import re
 import subprocess
@@ -19,10 +21,13 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # must be present; every OTHER instantiation with ASM = true found in the assembly is audited as well (discovered, not listed).
 EXPECTED = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi0ELi0EEE", "k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi1ELi0EEE",
             "k_part1_narrowILi12ELi12288ELb1ELb1ELi0ELi0ELi1EEE", "k_part2_ringILi4ELi32ELb1ELi0EEE",
-            "k_part2_ringILi4ELi64ELb1ELi0EEE", "k_part2_ringILi4ELi128ELb1ELi0EEE", "k_part2_ringILi4ELi256ELb1ELi0EEE"]
+            "k_part2_ringILi4ELi64ELb1ELi0EEE", "k_part2_ringILi4ELi128ELb1ELi0EEE", "k_part2_ringILi4ELi256ELb1ELi0EEE",
+            "k_agg_scatter_rsvIiLb1ELb1EEE", "k_agg_scatter_rsvIiLb0ELb1EEE", "k_agg_scatter_rsvIxLb1ELb1EEE", "k_agg_scatter_rsvIxLb0ELb1EEE"]
 # template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG, int DICT, int WIDE> k_part1_narrow / template <int RPT, int R, bool ASM, int DIAG> k_part2_ring
+# template <typename KeyT, bool VAL_F64, bool ASM> k_agg_scatter_rsv
 # (the whole template argument list is part of the key, up to the EEE that closes it: a new template parameter shows up as a new key)
-ASM_FORMS = re.compile(r"^_ZN5golap\d+(k_part1_narrowILi\d+ELi\d+ELb[01]ELb1E(?:Li\d+E)+EE|k_part2_ringILi\d+ELi\d+ELb1E(?:Li\d+E)+EE)\w*:", re.M)
+ASM_FORMS = re.compile(r"^_ZN5golap\d+(k_part1_narrowILi\d+ELi\d+ELb[01]ELb1E(?:Li\d+E)+EE|k_part2_ringILi\d+ELi\d+ELb1E(?:Li\d+E)+EE|"
+                       r"k_agg_scatter_rsvI[a-z]Lb[01]ELb1E(?:L[a-z]\d+E)*EE)\w*:", re.M)
 # The audit reads ONE compiler's output: the hand-counted waits and the fixed-register scheme were validated (on the GPU, row by row:
 # tests/test_join_gpu.py::test_hidden_forms_match_plain_forms) with exactly this hipcc.  A different compiler must be re-validated
 # there before this constant is changed.
@@ -32,11 +37,13 @@ VALIDATED_HIPCC = "7.2.26015"
 def _compile(tmp_path_factory, extra=()):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "golap_join.s"
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-inline-asm", "-Wno-pass-failed", *extra]   # the Makefile's flags
-    subprocess.check_call([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(CSRC, "golap_join.hip"), "-o", str(out)],
-                          stderr=subprocess.DEVNULL)
-    return open(out).read()
+    d, text = tmp_path_factory.mktemp("isa"), ""
+    for src in ("golap_join", "golap_ops"):
+        subprocess.check_call([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(CSRC, src + ".hip"), "-o", str(d / (src + ".s"))],
+                              stderr=subprocess.DEVNULL)
+        text += open(d / (src + ".s")).read()
+    return text
 
 
 @pytest.fixture(scope="module")
@@ -91,6 +98,22 @@ def test_hidden_memory_kernels_have_no_scratch_and_no_stray_waits(asm):
         _audit(asm, key)
 
 
+def test_the_audit_sees_a_planted_violation(asm):
+    """the control-flow scan must fail on a compiler-style read of a register with a hidden load in flight (here: planted right
+    behind the first prefetch of the tile loop, i.e. in front of the back edge that leads to the counted wait)"""
+    key = "k_agg_scatter_rsvIiLb1ELb1EEE"
+    name, lines = _body(asm, key)
+    loads = [i for i, l in enumerate(lines) if re.search(r"global_load_dwordx4 v\[\d+:\d+\]", l)]
+    at = loads[len(loads) // 2]   # the second group of loads is the prefetch inside the loop
+    reg = re.search(r"global_load_dwordx4 v\[(\d+):", lines[at]).group(1)
+    end = next(i for i in range(at, len(lines)) if "ASMEND" in lines[i])
+    bad = lines[:end + 1] + [f"\tv_mov_b32_e32 v1, v{reg}"] + lines[end + 1:]
+    start = asm.index("\n".join(lines))
+    planted = asm[:start] + "\n".join(bad) + asm[start + len("\n".join(lines)):]
+    with pytest.raises(AssertionError, match="hidden load"):
+        _audit(planted, key)
+
+
 def _audit(asm, key):
     name, lines = _body(asm, key)
     # (1) no spills, no scratch
@@ -102,33 +125,50 @@ def _audit(asm, key):
     # (2) between a hidden load (or returning atomic) and the next hand-counted wait, nothing outside the asm statements touches
     #     its destination registers: a copy placed there (e.g. a phi copy at a control-flow merge) reads data that has not
     #     landed, and the original registers -- free again in the compiler's eyes -- get overwritten by the late data while they
-    #     hold something else (seen on MI355X: a store address, i.e. a memory fault).  The scan is linear over the program text,
-    #     which covers every fall-through and forward path; it is conservative (code of a sibling branch counts too), so the
-    #     kernels keep their hidden loads in straight-line code.
-    in_asm, hidden, dirty = False, set(), {}
+    #     hold something else (seen on MI355X: a store address, i.e. a memory fault).  Checked along the control-flow graph of the
+    #     kernel text (labels, s_branch / s_cbranch_*, fall-through; loop back edges included): the set of registers with a load
+    #     possibly in flight is propagated to a fixed point, and every compiler-issued instruction is checked against the set that
+    #     reaches it on ANY path.
+    ins, labels, in_asm = [], {}, False   # ins: (text line number, instruction, inside an asm statement)
     for ln, l in enumerate(lines):
-        s = l.strip()
-        if "ASMSTART" in s:
+        t = l.split(";")[0].strip()
+        if "ASMSTART" in l:
             in_asm = True
-            continue
-        if "ASMEND" in s:
+        elif "ASMEND" in l:
             in_asm = False
-            continue
-        if not s or s.startswith(";") or s.startswith("."):
-            continue
-        if in_asm:
-            m = re.match(r"global_(?:load_dword(?:x[24])?|atomic_add) (v\[(\d+):(\d+)\]|v(\d+)),", s)
+        elif re.match(r"\.LBB\d+_\d+:", t):
+            labels[t[:-1]] = len(ins)
+        elif t and not t.startswith("."):
+            ins.append((ln, t, in_asm))
+    hidden, reach, work = set(), {0: frozenset()}, [0]
+    load_re = re.compile(r"global_(?:load_dword(?:x[24])?|atomic_add) (v\[(\d+):(\d+)\]|v(\d+)),")
+    while work:
+        i = work.pop()
+        dirty = set(reach[i])
+        ln, t, asm_stmt = ins[i]
+        if asm_stmt:
+            m = load_re.match(t)
             if m:
                 r = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
                 hidden |= r
-                for x in r:
-                    dirty[x] = ln
-            if s.startswith("s_waitcnt vmcnt"):
-                dirty = {}
-            continue
-        touched = _regs(s) & set(dirty)
-        assert not touched, (f"{key}: line {ln} `{s}` uses v{sorted(touched)} while a hidden load into them (line "
-                             f"{dirty[sorted(touched)[0]]}) may still be in flight")
+                dirty |= r
+            if t.startswith("s_waitcnt vmcnt"):
+                dirty = set()
+        else:
+            touched = _regs(t) & dirty
+            assert not touched, f"{key}: line {ln} `{t}` uses v{sorted(touched)} while a hidden load into them may still be in flight"
+        succ = []
+        op = t.split()[0]
+        if op == "s_branch":
+            succ = [labels[t.split()[1]]]
+        elif op.startswith("s_cbranch"):
+            succ = [labels[t.split()[1]], i + 1]
+        elif op not in ("s_endpgm", "s_setpc_b64"):
+            succ = [i + 1]
+        for j in succ:
+            if j < len(ins) and not (j in reach and dirty <= reach[j]):
+                reach[j] = frozenset(dirty | reach.get(j, frozenset()))
+                work.append(j)
     assert hidden, f"{key}: no hidden loads found (is this still the ASM form?)"
     # (4) a hidden store of more than 8 bytes keeps reading its data registers for two more cycles on gfx940+ (hipcc pads compiler-
     #     visible stores itself but does not look inside asm statements): every such store must carry its own wait states
@@ -137,9 +177,9 @@ def _audit(asm, key):
             nxt = [x.strip() for x in lines[i + 1:i + 3]]
             assert nxt and nxt[0].startswith("s_nop"), f"{key}: line {i} `{l.strip()}` is not followed by s_nop (store-data hazard)"
     if "k_part2_ring" in key:
-        # the ring pass loads into fixed registers outside hipcc's budget (golap_part_narrow.h, ld8_fixed): hipcc itself must
+        # the ring pass loads into fixed registers outside hipcc's budget (golap_hidden.h, ld8_fixed): hipcc itself must
         # never name them, and the kernel descriptor must cover them
-        src = open(os.path.join(CSRC, "golap_part_narrow.h")).read()
+        src = open(os.path.join(CSRC, "golap_hidden.h")).read()
         first = int(re.search(r"P2R_FIXED_FIRST = (\d+)", src).group(1))
         pairs = int(re.search(r"P2R_FIXED_PAIRS = (\d+)", src).group(1))
         fixed = set(range(first, first + 2 * pairs))
