@@ -585,7 +585,9 @@ template <typename KeyT, bool VAL_F64>
 __global__ __launch_bounds__(AGB_THREADS) void k_agg_scatter_big(const KeyT* __restrict__ keys, const void* __restrict__ val, unsigned long long n,
                                                                  uint32_t n_groups, uint32_t chunk_rows, uint32_t S, uint32_t B,
                                                                  const uint32_t* __restrict__ scanned, uint32_t* __restrict__ out_slot,
-                                                                 double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr) {
+                                                                 double* __restrict__ out_val, const uint8_t* __restrict__ vv = nullptr,
+                                                                 const uint32_t* __restrict__ run_if = nullptr /*non-null: a no-op unless *run_if != 0*/) {
+    if (run_if && *run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_val = reinterpret_cast<double*>(s_raw);                          // [AGB_WIN]
     uint32_t* s_slot = reinterpret_cast<uint32_t*>(s_raw + AGB_WIN * 8);       // [AGB_WIN]
@@ -867,6 +869,7 @@ constexpr int AGR_THREADS = 1024;
 constexpr int AGR_RPT = 12;
 constexpr int AGR_TILE = AGR_THREADS * AGR_RPT;   // 12288 rows = the LDS window
 constexpr int AGR_NSUB = 8;
+constexpr int AGR_MAX_B = 512;                    // buckets: a tile brings >= 24 rows per bucket (beyond that the histogram path's line-aligned runs win)
 static constexpr size_t agr_lds(uint32_t B) { return (size_t)AGR_TILE * 12 + (size_t)B * 12 + (AGR_THREADS / 64 + 2) * 4 + 16; }
 
 template <typename KeyT, bool VAL_F64, bool ASM>
@@ -941,7 +944,7 @@ __global__ __launch_bounds__(AGR_THREADS) void k_agg_scatter_rsv(const KeyT* __r
             br[r] = 0xFFFFFFFFu;
             if (4u * ((uint32_t)u * NT + tid) < tn) {
                 const uint32_t b = slot[r] >> gb_shift;
-                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 128, rank < 12288
+                br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);   // b < 512, rank < 12288
             }
         }
         lds_barrier();
@@ -1029,17 +1032,18 @@ __global__ void k_agg_scatter_tail(const KeyT* __restrict__ keys, const void* __
 
 // Will the provisioned ranges hold?  A strided sample of the key column (16-row runs, `stride` rows apart: 2^20 rows at most) is
 // counted per bucket -- per work-group in LDS, then into tally[0 .. B) -- and the work-group that finishes last compares: a bucket
-// whose share of the sample exceeds the mean by more than 1/16 (half the slack of the provisioning; the sample's own sigma is ~1 % at
-// 2^20 rows and 128 buckets) raises flags[0], and the histogram path runs instead at no extra cost.
+// whose share of the sample exceeds what a full bucket gets from uniformly spread keys (bucket_slots / n_groups: the provisioning's
+// basis) by more than 1/16 (half the provisioning's slack; the sample's own sigma is ~1 % at 2^20 rows and 128 buckets) raises
+// flags[0], and the histogram path runs instead at no extra cost.
 constexpr int AGS_THREADS = 256;
 template <typename KeyT>
 __global__ __launch_bounds__(AGS_THREADS) void k_agg_sample(const KeyT* __restrict__ keys, unsigned long long n, uint32_t n_groups, uint32_t gb_shift, uint32_t B,
-                                                            uint32_t runs, unsigned long long stride,
+                                                            uint32_t runs, unsigned long long stride, uint32_t bucket_slots /*min(slots per bucket, n_groups)*/,
                                                             uint32_t* __restrict__ tally /*[B] counts, [B] rows sampled, [B + 1] work-groups done; zeroed*/,
                                                             uint32_t* __restrict__ flags) {
-    __shared__ uint32_t s_cnt[AGW_MAX_B];
+    __shared__ uint32_t s_cnt[AGR_MAX_B];
     __shared__ uint32_t s_last;
-    if (threadIdx.x < AGW_MAX_B) s_cnt[threadIdx.x] = 0;
+    for (uint32_t b = threadIdx.x; b < B; b += AGS_THREADS) s_cnt[b] = 0;
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t r = blockIdx.x * (AGS_THREADS / 16) + (threadIdx.x >> 4); r < runs; r += gridDim.x * (AGS_THREADS / 16)) {
@@ -1047,7 +1051,8 @@ __global__ __launch_bounds__(AGS_THREADS) void k_agg_sample(const KeyT* __restri
         if (i < n) { atomicAdd(&s_cnt[slot_of(keys[i], n_groups) >> gb_shift], 1u); ++mine; }
     }
     __syncthreads();
-    if (threadIdx.x < B && s_cnt[threadIdx.x]) atomicAdd(&tally[threadIdx.x], s_cnt[threadIdx.x]);
+    for (uint32_t b = threadIdx.x; b < B; b += AGS_THREADS)
+        if (s_cnt[b]) atomicAdd(&tally[b], s_cnt[b]);
     if (mine) atomicAdd(&tally[B], mine);
     __threadfence();
     __syncthreads();
@@ -1055,10 +1060,11 @@ __global__ __launch_bounds__(AGS_THREADS) void k_agg_sample(const KeyT* __restri
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (threadIdx.x < B) {
-        const unsigned long long c = __hip_atomic_load(&tally[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t b = threadIdx.x; b < B; b += AGS_THREADS) {
+        const unsigned long long c = __hip_atomic_load(&tally[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long tot = __hip_atomic_load(&tally[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c * B * 16ull > tot * 17ull + 64ull * B * 16ull) atomicOr(flags, 1u);   // c > (tot / B) * 17/16 + 64
+        // c > tot * (bucket_slots / n_groups) * 17/16 + 64: more than a full bucket's share of uniformly spread keys, plus 1/16
+        if (c * n_groups * 16ull > tot * bucket_slots * 17ull + 64ull * n_groups * 16ull) atomicOr(flags, 1u);
     }
 }
 
@@ -1082,18 +1088,24 @@ __global__ __launch_bounds__(NT) void k_agg_bucket(const uint32_t* __restrict__ 
         if (NEED_MM) { s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; }
     }
     __syncthreads();
+    // reserved layout: W < AGR_NSUB -- work-group (b, w) takes the bucket's sub-ranges w, w + W, ...; W = P * AGR_NSUB -- it takes slice
+    // w / AGR_NSUB (of P) of sub-range w % AGR_NSUB
+    const bool rsv = rsv_cursor && *rsv_flags == 0;
+    const uint32_t kbase = b * GB;
+    const uint32_t sub_step = W < (uint32_t)AGR_NSUB ? W : (uint32_t)AGR_NSUB, parts = W < (uint32_t)AGR_NSUB ? 1u : W / AGR_NSUB;
+    for (uint32_t sub = w % AGR_NSUB; sub < (rsv ? (uint32_t)AGR_NSUB : w % AGR_NSUB + 1u); sub += sub_step) {
     uint32_t lo, hi;
-    if (rsv_cursor && *rsv_flags == 0) {   // work-group (b, w) takes sub-range w
-        const uint32_t c = rsv_cursor[b * W + w];
-        lo = (b * W + w) * rsv_cap;
-        hi = lo + (c < rsv_cap ? c : rsv_cap);
+    if (rsv) {
+        const uint32_t c = rsv_cursor[b * AGR_NSUB + sub], len = c < rsv_cap ? c : rsv_cap;
+        const uint32_t share = (len + parts - 1) / parts, first = (w / AGR_NSUB) * share;
+        lo = (b * AGR_NSUB + sub) * rsv_cap + (first < len ? first : len);
+        hi = (b * AGR_NSUB + sub) * rsv_cap + (first + share < len ? first + share : len);
     } else {
         const uint32_t o0 = scanned[(size_t)b * S], o1 = scanned[(size_t)(b + 1) * S];
         const uint32_t share = (o1 - o0 + W - 1) / W;
         lo = o0 + w * share < o1 ? o0 + w * share : o1;
         hi = lo + share < o1 ? lo + share : o1;
     }
-    const uint32_t kbase = b * GB;
     for (uint32_t base = lo; base < hi; base += NT * 8) {
         uint32_t k[8];
         double x[8];
@@ -1117,6 +1129,7 @@ __global__ __launch_bounds__(NT) void k_agg_bucket(const uint32_t* __restrict__ 
                 }
             }
         }
+    }
     }
     __syncthreads();
     double* row = slab + (size_t)blockIdx.x * 4 * GB;
@@ -1480,15 +1493,20 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     const uint32_t pS = part_path ? (uint32_t)std::min<uint64_t>(2048, p_big ? p->n_rows / (4 * AGB_TILE) : ceil_div(p->n_rows, AG_TILE)) : 0;
     const uint32_t p_chunk = part_path ? (uint32_t)round_up(ceil_div(p->n_rows, pS), AG_TILE) : 0;
     const uint32_t pS2 = part_path ? (uint32_t)ceil_div(p->n_rows, p_chunk) : 0;   // chunks actually used
-    const uint32_t pW = part_path ? std::max<uint32_t>(1, std::min<uint32_t>(8, (p_wc ? 1024u : 2048u) / pB)) : 0;
+    // work-groups per bucket in the fold: >= 512 (sums only: one 96 KiB table per CU) / 1024 (all four statistics: 56 KiB) work-groups
+    // in all, 8 .. 256 per bucket in multiples of 8 (the reserved layout's sub-ranges); fan-outs beyond 128: min(8, 2048 / B)
+    const uint32_t pW = !part_path ? 0 : pB > 128 ? std::max<uint32_t>(1, std::min<uint32_t>(8, 2048u / pB))
+                                                  : 8u * (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, ceil_div(p_wc ? 512 : 1024, 8ull * pB)));
     // no histogram pass: provisioned sub-ranges + reservations (k_agg_scatter_rsv), the histogram path standing by behind a device
     // word.  Needs 16-byte aligned columns without validity bytes (checked per value column).  GOLAP_AGG_RSV=0: A/B hook; =plain: the
     // compiler-visible form of the kernel.
     const char* rsv_env = knob("GOLAP_AGG_RSV");
     const uint64_t n4 = p->n_rows & ~3ull;
-    const uint64_t rsv_cap64 = p_wc ? round_up(ceil_div(p->n_rows, (uint64_t)pB * AGR_NSUB) * 9 / 8 + AGR_TILE, 32) : 0;
-    const bool p_rsv = p_wc && pW == (uint32_t)AGR_NSUB && (uint64_t)pB * AGR_NSUB * rsv_cap64 < 0xFFFFFFF0ull && (p->group_key_ptr & 15) == 0 &&
-                       !(rsv_env && !strcmp(rsv_env, "0"));
+    // (provisioned for a FULL bucket's share of uniformly spread keys -- the last bucket may be narrower -- plus 1/8 and a tile)
+    const uint32_t bucket_slots = std::min<uint32_t>(pGB, G);
+    const uint64_t rsv_cap64 = p_big ? round_up(ceil_div(ceil_div(p->n_rows * bucket_slots, G), AGR_NSUB) * 9 / 8 + AGR_TILE, 32) : 0;
+    const bool p_rsv = p_big && pB <= (uint32_t)AGR_MAX_B && (AGR_NSUB % pW == 0 || pW % AGR_NSUB == 0) && (uint64_t)pB * AGR_NSUB * rsv_cap64 < 0xFFFFFFF0ull &&
+                       (p->group_key_ptr & 15) == 0 && !(rsv_env && !strcmp(rsv_env, "0"));
     const uint32_t rsv_cap = (uint32_t)rsv_cap64;
     const uint64_t part_rows = p_rsv ? (uint64_t)pB * AGR_NSUB * rsv_cap : p->n_rows;   // rows of the partition buffers
     const uint32_t rsv_chunk = p_rsv ? (uint32_t)round_up(ceil_div(n4, 2048), AGR_TILE) : 0;
@@ -1545,7 +1563,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                                   (const void*)k_agg_scatter_rsv<long long, true, true>,  (const void*)k_agg_scatter_rsv<long long, false, true>,
                                   (const void*)k_agg_scatter_rsv<int, true, false>,       (const void*)k_agg_scatter_rsv<int, false, false>,
                                   (const void*)k_agg_scatter_rsv<long long, true, false>, (const void*)k_agg_scatter_rsv<long long, false, false>};
-            for (const void* f : rsvs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)agr_lds(AGW_MAX_B)));
+            for (const void* f : rsvs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)agr_lds(AGR_MAX_B)));
             GOLAP_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_agg_bucket<false, AG_GB_SUM, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, AG_GB_SUM * 12 + 16));
             ctx->attr_done[1] = true;
         }
@@ -1629,7 +1647,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
 #define GOLAP_AGG_RSV(KT, VF)                                                                                                         \
     do {                                                                                                                              \
         hipLaunchKernelGGL(k_agg_sample<KT>, dim3(256), dim3(AGS_THREADS), 0, st, (const KT*)p->group_key_ptr, (unsigned long long)p->n_rows, G, \
-                           gb_shift, pB, runs, (unsigned long long)stride, tally, rsv_flags);                                          \
+                           gb_shift, pB, runs, (unsigned long long)stride, bucket_slots, tally, rsv_flags);                                          \
         if (plain)                                                                                                                    \
             hipLaunchKernelGGL((k_agg_scatter_rsv<KT, VF, false>), dim3(rsv_grid), dim3(AGR_THREADS), agr_lds(pB), st, (const KT*)p->group_key_ptr, \
                                val, (unsigned long long)n4, G, gb_shift, rsv_chunk, pB, rsv_cursor, rsv_cap, rsv_flags, p_slot, p_val); \
@@ -1663,7 +1681,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                        (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
 #define GOLAP_AGG_SCB(KT, VF)                                                                                                         \
     hipLaunchKernelGGL((k_agg_scatter_big<KT, VF>), dim3(pS2), dim3(AGB_THREADS), AGB_LDS, st, (const KT*)p->group_key_ptr, val,      \
-                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv)
+                       (unsigned long long)p->n_rows, G, p_chunk, pS2, pB, p_hist, p_slot, p_val, vv, (const uint32_t*)rsv_flags)
 #define GOLAP_AGG_SCW(KT, VF)                                                                                                         \
     do {                                                                                                                              \
         if (wc_two)                                                                                                                   \
@@ -1697,9 +1715,11 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                     hipLaunchKernelGGL((k_agg_bucket<false, AG_GB_SUM, 1024>), dim3(pB * pW), dim3(1024), AG_GB_SUM * 12 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab,
                                        (const uint32_t*)rsv_cursor, rsv_cap, (const uint32_t*)rsv_flags);
                 else if (need_minmax)
-                    hipLaunchKernelGGL(k_agg_bucket<true>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
+                    hipLaunchKernelGGL(k_agg_bucket<true>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab,
+                                       (const uint32_t*)rsv_cursor, rsv_cap, (const uint32_t*)rsv_flags);
                 else
-                    hipLaunchKernelGGL(k_agg_bucket<false>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab);
+                    hipLaunchKernelGGL(k_agg_bucket<false>, dim3(pB * pW), dim3(AG_THREADS), AG_GB * 28 + 16, st, p_slot, p_val, p_hist, pS2, pW, p_slab,
+                                       (const uint32_t*)rsv_cursor, rsv_cap, (const uint32_t*)rsv_flags);
                 hipLaunchKernelGGL(k_agg_bucket_fold, dim3((uint32_t)std::min<uint64_t>(cus * 8, ceil_div(G, OP_THREADS))), dim3(OP_THREADS), 0, st, p_slab,
                                    pW, G, pGB, (int)(need_minmax && !p_wc), stats4);
             }
@@ -1763,28 +1783,51 @@ __device__ __forceinline__ uint32_t hk_hash(long long key, uint32_t mask) {
 
 template <typename KeyT>
 __global__ __launch_bounds__(OP_THREADS) void k_hk_insert(const KeyT* __restrict__ keys, unsigned long long n, long long* __restrict__ table, uint32_t mask,
-                                                          uint32_t* __restrict__ flags /*[0] INT64_MIN seen, [1] table full*/) {
+                                                          uint32_t* __restrict__ flags /*[0] INT64_MIN seen, [1] table (nearly) full, [2] keys in the table*/) {
     __shared__ long long s_seen[HK_CACHE];
     for (uint32_t i = threadIdx.x; i < HK_CACHE; i += OP_THREADS) s_seen[i] = HK_EMPTY;
     __syncthreads();
+    // The table has >= 2 * n_groups entries; once 7/8 of them are taken the caller's bound is wrong by a wide margin and probe chains
+    // grow without limit (a FULL table made every further row scan all of it: minutes for a 2^23-entry table and 40M rows).  The
+    // kernel counts the keys it adds (one atomic per wave and row round), raises flags[1] at 7/8 and every thread gives up soon after:
+    // out_n_groups then reads 0xFFFFFFFF, as before.  Below 7/8 the count of distinct keys stays exact, also above n_groups.
+    const uint32_t limit = mask - (mask >> 3);
+    uint32_t round = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * OP_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * OP_THREADS) {
         const long long key = (long long)keys[i];
-        if (key == HK_EMPTY) { flags[0] = 1u; continue; }   // (same value from every writer)
-        const uint32_t h = hk_hash(key, mask);
-        const uint32_t c = h & (HK_CACHE - 1);
-        if (s_seen[c] == key) continue;                      // this work-group already made sure the key is in the table
-        uint32_t s = h, probes = 0;
-        for (;;) {
-            const long long cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == key) break;
-            if (cur == HK_EMPTY) {
-                long long expected = HK_EMPTY;
-                if (__hip_atomic_compare_exchange_strong(&table[s], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || expected == key) break;
+        bool added = false;
+        if (key == HK_EMPTY) {
+            flags[0] = 1u;   // (same value from every writer)
+        } else {
+            const uint32_t h = hk_hash(key, mask);
+            const uint32_t c = h & (HK_CACHE - 1);
+            if (s_seen[c] != key) {                              // (else: this work-group already made sure the key is in the table)
+                uint32_t s = h, probes = 0;
+                bool there = false;
+                for (;;) {
+                    const long long cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == key) { there = true; break; }
+                    if (cur == HK_EMPTY) {
+                        long long expected = HK_EMPTY;
+                        if (__hip_atomic_compare_exchange_strong(&table[s], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            there = added = true;
+                            break;
+                        }
+                        if (expected == key) { there = true; break; }
+                    }
+                    s = (s + 1) & mask;
+                    if (++probes > mask) { flags[1] = 1u; break; }   // every entry holds another key
+                    if ((probes & 63u) == 0u && __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                }
+                if (there) s_seen[c] = key;   // (an aligned 8-byte LDS store: readers see the old or the new key, never a mix)
             }
-            s = (s + 1) & mask;
-            if (++probes > mask) { flags[1] = 1u; break; }   // every entry holds another key: n_groups was far too small
         }
-        s_seen[c] = key;   // (an aligned 8-byte LDS store: readers see the old or the new key, never a mix)
+        const unsigned long long m = __ballot(added);
+        if (m && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) {
+            const uint32_t k = (uint32_t)__popcll(m);
+            if (atomicAdd(&flags[2], k) + k > limit) flags[1] = 1u;
+        }
+        if ((++round & 7u) == 0u && __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
 }
 
@@ -1810,7 +1853,7 @@ __global__ __launch_bounds__(OP_THREADS) void k_hk_keys(const long long* __restr
 template <typename KeyT>
 __global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict__ keys, unsigned long long n, const long long* __restrict__ table,
                                                           const uint32_t* __restrict__ ids, uint32_t mask, uint32_t cap, uint32_t n_groups,
-                                                          uint32_t* __restrict__ slot_out) {
+                                                          uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ flags) {
     // direct-mapped cache of (key, id) in LDS.  An entry is two words, so it carries a version (a seqlock): a writer takes the
     // entry by moving the version from even to odd with ONE compare-and-swap (lanes of one wave that want the same entry are
     // serialised by the LDS atomic: one wins, the others go without caching), stores key and id, and releases it with version + 2;
@@ -1822,6 +1865,10 @@ __global__ __launch_bounds__(OP_THREADS) void k_hk_lookup(const KeyT* __restrict
     __shared__ uint32_t s_ver[HK_CACHE];
     for (uint32_t i = threadIdx.x; i < HK_CACHE; i += OP_THREADS) { s_key[i] = HK_EMPTY; s_ver[i] = 0; }
     __syncthreads();
+    if (flags[1]) {   // the table overflowed (k_hk_insert): keys may be missing from it, the call's outputs are undefined -- no probing
+        for (unsigned long long i = (unsigned long long)blockIdx.x * OP_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * OP_THREADS) slot_out[i] = 0;
+        return;
+    }
     const uint32_t used = ids[cap];
     for (unsigned long long i = (unsigned long long)blockIdx.x * OP_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * OP_THREADS) {
         const long long key = (long long)keys[i];
@@ -1869,13 +1916,13 @@ static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* spec
     uint32_t* ids = (uint32_t*)aux_take(ctx, ((uint64_t)cap + 1) * 4);
     uint32_t* bsums = (uint32_t*)aux_take(ctx, flat_scan_scratch_words((uint64_t)cap + 1) * 4);
     uint32_t* slots = (uint32_t*)aux_take(ctx, std::max<uint64_t>(n, 1) * 4);
-    uint32_t* flags = (uint32_t*)aux_take(ctx, 8);
+    uint32_t* flags = (uint32_t*)aux_take(ctx, 16);
     if (!table || !ids || !bsums || !slots || !flags) return fail(ctx, GOLAP_ERR_OOM, "aggregate scratch exhausted (key table)");
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
     const uint32_t tgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, ceil_div((uint64_t)cap + 1, OP_THREADS)));
     const uint32_t rgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * 8, ceil_div(std::max<uint64_t>(n, 1), OP_THREADS * 8)));
     const uint64_t key_bytes = p->key_dtype == GOLAP_DT_INT32 ? 4 : 8;
-    GOLAP_HIP_TRY(ctx, hipMemsetAsync(flags, 0, 8, st));
+    GOLAP_HIP_TRY(ctx, hipMemsetAsync(flags, 0, 16, st));
     {   // every entry = HK_EMPTY (0x80 in the top byte only: a kernel, not a byte memset)
         KernelTimer t(ctx, "hash_keys_insert", st, key_bytes * n);
         hipLaunchKernelGGL(k_fill_i64, dim3(tgrid), dim3(OP_THREADS), 0, st, table, (unsigned long long)cap, HK_EMPTY);
@@ -1894,10 +1941,10 @@ static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* spec
         KernelTimer t(ctx, "hash_keys_lookup", st, (key_bytes + 4) * n);
         if (p->key_dtype == GOLAP_DT_INT32)
             hipLaunchKernelGGL(k_hk_lookup<int>, dim3(rgrid), dim3(OP_THREADS), 0, st, (const int*)p->group_key_ptr, (unsigned long long)n, (const long long*)table,
-                               (const uint32_t*)ids, mask, cap, p->n_groups, slots);
+                               (const uint32_t*)ids, mask, cap, p->n_groups, slots, (const uint32_t*)flags);
         else
             hipLaunchKernelGGL(k_hk_lookup<long long>, dim3(rgrid), dim3(OP_THREADS), 0, st, (const long long*)p->group_key_ptr, (unsigned long long)n,
-                               (const long long*)table, (const uint32_t*)ids, mask, cap, p->n_groups, slots);
+                               (const long long*)table, (const uint32_t*)ids, mask, cap, p->n_groups, slots, (const uint32_t*)flags);
     }
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     golap_aggregate_params q = *p;

@@ -1,4 +1,5 @@
-"""A/B of env-selected variants of the grouped aggregate inside ONE process.  usage: python scripts/ab_agg.py N G ENVVAR v1 v2 ..."""
+"""A/B of env-selected variants of the grouped aggregate inside ONE process.  usage: [AB_AGG_MM=1] python scripts/ab_agg.py N G ENVVAR v1 v2 ...
+(AB_AGG_MM=1: SUM + MAX, i.e. the 28-byte table entries and the 2048-slot buckets)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +14,7 @@ for rnd in range(6):
     for x in vals:
         ctx.debug_set(var, x)
         ctx.stats_reset()
-        ctx.aggregate([(N.AGG_SUM, 0)], [v], group_keys=k, n_groups=G)
+        ctx.aggregate([(N.AGG_SUM, 0), (N.AGG_MAX, 0)] if os.environ.get("AB_AGG_MM") else [(N.AGG_SUM, 0)], [v], group_keys=k, n_groups=G)
         torch.cuda.synchronize()
         if rnd:
             res[x].append({kk: s["total_ms"] for kk, s in ctx.stats().items()})

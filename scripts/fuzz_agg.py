@@ -18,6 +18,7 @@ from gpu_olap_engine_amd import _native as N
 from gpu_olap_engine_amd.engine import Context
 
 SPECS = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_MIN, 0), (N.AGG_MAX, 0), (N.AGG_AVG, 0)]
+SPECS_SUM = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_AVG, 0)]   # no MIN / MAX: 12-byte table entries, the write-combining / reserving partition scatters
 
 
 def main():
@@ -56,11 +57,15 @@ def main():
         vvalid = (rng.random(n) > 0.2).astype(np.uint8) if rng.random() < 0.3 else None      # NULL values: skipped by every aggregate
         live = np.ones(n, bool) if vvalid is None else vvalid != 0
         ok, ost = oracle.group_aggregate(slots[live], vals.astype(np.float64)[live])
-        out, counts = ctx.aggregate(SPECS, [torch.from_numpy(vals).cuda()], group_keys=torch.from_numpy(keys).cuda(), n_groups=G, want_counts=True,
-                                    value_valid=None if vvalid is None else [torch.from_numpy(vvalid).cuda()])
+        sums_only = rng.random() < 0.5
+        if sums_only and rng.random() < 0.3:
+            env["GOLAP_AGG_RSV"] = str(rng.choice(["0", "plain"]))
+        ctx.debug_set("GOLAP_AGG_RSV", env.get("GOLAP_AGG_RSV"))
+        out, counts = ctx.aggregate(SPECS_SUM if sums_only else SPECS, [torch.from_numpy(vals).cuda()], group_keys=torch.from_numpy(keys).cuda(), n_groups=G,
+                                    want_counts=True, value_valid=None if vvalid is None else [torch.from_numpy(vvalid).cuda()])
         out, counts = out.cpu().numpy(), counts.cpu().numpy()
         present = counts > 0
-        good = np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
+        good = np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost[:, [0, 1, 4]] if sums_only else ost)
         why = why or (None if good else "dense")
         # the same rows through the key table (GOLAP_KEYS_HASHED): arbitrary keys, one slot per distinct key
         if rng.random() < 0.4 and G <= 3_000_000:

@@ -181,7 +181,8 @@ def test_grouped_aggregate_big_tile_partition(ctx, shape):
     assert np.array_equal(np.nonzero(present)[0], ok) and np.array_equal(out[:, present].T, ost)
 
 
-RSV_CASES = ["uniform_i32_f64", "uniform_i64_i64", "hot_key", "hot_key_the_sample_cannot_see", "sequential", "unaligned", "plain_form"]
+RSV_CASES = ["uniform_i32_f64", "uniform_i64_i64", "hot_key", "hot_key_the_sample_cannot_see", "sequential", "unaligned", "plain_form",
+             "min_max_tables", "three_buckets", "narrow_last_bucket"]
 
 
 @pytest.mark.parametrize("case", RSV_CASES)
@@ -193,8 +194,12 @@ def test_grouped_aggregate_reserving_scatter(ctx, case):
       hot_key_the_sample_cannot_see: the same skew everywhere EXCEPT at the sampled positions -- a range overflows mid-way, the
         histogram path redoes the pass;
       sequential: sorted keys (every chunk feeds one bucket: the per-tile reservation is one long run);
-      unaligned: a key column that is not 16-byte aligned takes the histogram path;  plain_form: the compiler-visible kernel form."""
+      unaligned: a key column that is not 16-byte aligned takes the histogram path;  plain_form: the compiler-visible kernel form;
+      min_max_tables: MIN / MAX asked for too -- 28-byte table entries, 2048 slots per bucket, 489 buckets;
+      three_buckets / narrow_last_bucket: small fan-outs (the fold then runs 40+ work-groups per bucket: slices of the sub-ranges), the
+        last bucket much narrower than the others (provisioning and sample go by a FULL bucket's share)."""
     n, G = 40_000_123, 1_000_003   # n % 4 == 3: the last rows go through k_agg_scatter_tail
+    G = {"three_buckets": 20_000, "narrow_last_bucket": 100_000}.get(case, G)
     kd, vd = (np.int64, np.int64) if case == "uniform_i64_i64" else (np.int32, np.float64)
     if case in ("hot_key", "hot_key_the_sample_cannot_see"):
         keys = oracle.gen_sm64_mod(83, 0, n, G, kd)
@@ -209,7 +214,7 @@ def test_grouped_aggregate_reserving_scatter(ctx, case):
         keys = oracle.gen_sm64_mod(83, 0, n, G, kd)
     vals = (oracle.gen_sm64_mod(84, 0, n, 4096, np.int64) - 2048).astype(vd)
     ok, ost = oracle.group_aggregate(keys.astype(np.int64), vals.astype(np.float64))
-    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_AVG, 0)]
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_AVG, 0)] + ([(N.AGG_MIN, 0), (N.AGG_MAX, 0)] if case == "min_max_tables" else [])
     dk, dv = dev(keys), dev(vals)
     if case == "unaligned":
         dk = dev(np.concatenate([keys[:1], keys]))[1:]
@@ -221,6 +226,8 @@ def test_grouped_aggregate_reserving_scatter(ctx, case):
     present = counts > 0
     assert np.array_equal(np.nonzero(present)[0], ok)
     assert np.array_equal(out[0, present], ost[:, 0]) and np.array_equal(out[1, present], ost[:, 1]) and np.array_equal(out[2, present], ost[:, 4])
+    if case == "min_max_tables":
+        assert np.array_equal(out[3, present], ost[:, 2]) and np.array_equal(out[4, present], ost[:, 3])
     if case == "unaligned":
         assert "agg_partition_scatter_standby" not in st and st["agg_partition_hist"]["bytes"] > 0
     elif case in ("hot_key", "hot_key_the_sample_cannot_see"):
@@ -324,6 +331,24 @@ def test_hashed_group_by_reports_a_bound_that_is_too_small(ctx):
     out, skeys, nd = ctx.aggregate([(N.AGG_SUM, 0)], [dev(vals)], group_keys=dev(keys), n_groups=1000, hashed=True)
     assert (int(nd.item()) & 0xFFFFFFFF) > 1000                  # (2^32-1 when even the table overflowed): the caller must retry with a larger bound
     _hashed_check(ctx, keys, vals, bound=n)
+
+
+def test_hashed_group_by_with_a_hopeless_bound_returns_quickly(ctx):
+    """12M distinct keys in 40M rows against a bound of 1M (a 2M-entry key table): the table fills up.  Every further row used to scan
+    the WHOLE table before giving up -- minutes of GPU time; now the insert pass counts its keys, stops at 7/8 full, and the call
+    reports 0xFFFFFFFF at once.  Just above the bound (1.5 x) the distinct count is still exact."""
+    import time
+    n = 40_000_000
+    keys = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=12_000_000, seed=5)
+    vals = torch.ones(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out, skeys, nd = ctx.aggregate([(N.AGG_SUM, 0)], [vals], group_keys=keys, n_groups=1_000_000, hashed=True)
+    got = int(nd.item()) & 0xFFFFFFFF
+    assert got == 0xFFFFFFFF and time.time() - t0 < 5.0
+    keys = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=1_500_000, seed=5)
+    out, skeys, nd = ctx.aggregate([(N.AGG_SUM, 0)], [vals], group_keys=keys, n_groups=1_000_000, hashed=True)
+    assert (int(nd.item()) & 0xFFFFFFFF) == 1_500_000
 
 
 def test_hashed_group_by_empty_and_int64_min(ctx):

@@ -89,7 +89,7 @@ def test_c4_1b_group_by_sum_and_count(n_groups):
     from gpu_olap_engine_amd import _native as N
     from gpu_olap_engine_amd.engine import Context
     n = 1_000_000_000
-    c = Context(max_gpu_memory=0)
+    c = Context(max_gpu_memory=0, profiling=True)
     try:
         keys = c.generate(N.GEN_SM64_MOD_I32, n, modulus=n_groups, seed=7)
         vals = c.generate(N.GEN_SM64_MOD_F64, n, modulus=1000, seed=8)
@@ -105,6 +105,16 @@ def test_c4_1b_group_by_sum_and_count(n_groups):
         assert torch.equal(out[0], want_sum)                                # exact: integer-valued doubles
         want_max = torch.full((n_groups,), -1.0, dtype=torch.float64, device="cuda").scatter_reduce_(0, k64, vals, "amax")
         assert torch.equal(out[2], want_max)
+        del want_max, k64
+        # the bench's own call (SUM only: at G = 2^20 the partition scatter without a histogram pass, k_agg_scatter_rsv)
+        keys = c.generate(N.GEN_SM64_MOD_I32, n, modulus=n_groups, seed=7)
+        c.stats_reset()
+        out2 = c.aggregate([(N.AGG_SUM, 0)], [vals], group_keys=keys, n_groups=n_groups)
+        torch.cuda.synchronize()
+        assert torch.equal(out2[0], want_sum)
+        if n_groups > 4096:
+            st = c.stats()
+            assert st["agg_partition_scatter"]["bytes"] > 0 and st["agg_partition_scatter_standby"]["bytes"] == 0
     finally:
         c.close()
         torch.cuda.empty_cache()
