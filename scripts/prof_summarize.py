@@ -68,7 +68,7 @@ NAMES = [("k_part1_narrow<12, 12288", "radix_scatter_p1_wide"), ("k_part1_narrow
          ("k_join_lds<0, true", "join_build_probe_lds"),
          ("k_scatter_big<1", "radix_scatter_p1_wide"), ("k_scatter_wc<2, true", "radix_scatter_p2_wide"), ("k_join_lds<0, false", "join_build_probe_lds_wide"),
          ("k_hist<1", "radix_hist_p1"),
-         ("k_group_lds<", "hash_aggregate_lds"), ("k_agg_scatter_wc<", "agg_partition_scatter"), ("k_agg_scatter_big<", "agg_partition_scatter"),
+         ("k_group_lds<", "hash_aggregate_lds"), ("k_agg_scatter_rsv<", "agg_partition_scatter"), ("k_agg_scatter_wc<", "agg_partition_scatter"), ("k_agg_scatter_big<", "agg_partition_scatter"),
          ("k_agg_scatter<", "agg_partition_scatter"),
          ("k_agg_hist<", "agg_partition_hist"), ("k_agg_bucket<", "hash_aggregate_lds_buckets"), ("k_agg_bucket(", "hash_aggregate_lds_buckets"),
          ("k_filter_mask", "filter_mask"), ("k_filter_count", "filter_count"), ("k_filter_write", "filter_compact"),
