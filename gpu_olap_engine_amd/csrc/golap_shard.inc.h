@@ -378,7 +378,7 @@ struct ShardFastLayout {   // everything the fast path derives from the plan alo
     uint64_t send_rows[2], recv_rows[2], final_rows_[2];
     uint64_t send_base[2][golap_comm::MAX_CHUNKS];          // [side][chunk] first row of my chunk's partitioned region
     std::vector<uint64_t> recv_off[2];                       // [side][r * K + c] first row of (source r, chunk c)'s rows bound for me
-    uint32_t hdr_words, hdr_stride;                          // per side: K * F1 * nsub cursors + 4 words; both sides gathered at once
+    uint32_t hdr_words, hdr_stride;                          // per side: K * F1 * nsub cursors + one line (32 words); both sides gathered at once
     uint64_t need;
 };
 
@@ -409,7 +409,10 @@ static int32_t shard_fast_layout(golap_ctx* ctx, const golap_sharded_join_params
         if (L.send_rows[side] + L.recv_rows[side] >= 0xFFFFFFF0ull || L.final_rows_[side] >= 0xFFFFFFF0ull)
             return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: positions exceed u32");
     }
-    L.hdr_words = K * F1 * nsub + 4;
+    // (+ one whole 128-byte line for the failure word: k_part1_narrow polls it every tile, and in a line of its own it does not wait
+    //  behind the reservation atomics on neighbouring cursors -- with "+ 4" the probe side's word shared its line with the last four
+    //  cursors of that side and the probe partition ran 8 % slower than the build partition)
+    L.hdr_words = K * F1 * nsub + 32;
     L.hdr_stride = 2 * L.hdr_words;
     uint64_t small = 0;
     small += round_up((uint64_t)L.hdr_stride * 4, 256) + round_up((uint64_t)P * L.hdr_stride * 4, 256);                                   // cursors + gathered
@@ -421,8 +424,25 @@ static int32_t shard_fast_layout(golap_ctx* ctx, const golap_sharded_join_params
     return GOLAP_OK;
 }
 
+// host timeline of one call (GOLAP_SHARD_TRACE=1: printed to stderr at the end of the fast path; developer aid for the gap between calls)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    std::vector<std::pair<const char*, double>> pts;
+    HostTrace() : on(knob("GOLAP_SHARD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) { if (on) pts.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+    void print() {
+        if (!on) return;
+        std::string line = "[golap_sharded_join host us]";
+        char buf[96];
+        for (auto& q : pts) { snprintf(buf, sizeof buf, " %s=%.0f", q.first, q.second); line += buf; }
+        fprintf(stderr, "%s\n", line.c_str());
+    }
+};
+
 static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, bool* failed,
                                  int32_t arg_err) {
+    HostTrace ht;
     const uint32_t P = sp.world, me = (uint32_t)cm->rank, F1 = sp.F1, per = sp.per, F2 = sp.F2, nsub = sp.nsub, K = sp.K;
     const uint64_t max_msg = shard_max_msg(cm, p->max_msg_bytes);
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
@@ -482,6 +502,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         return GOLAP_OK;
     };
     const int32_t prep = prepare();
+    ht.mark("prepared");
     // ---- partition: `K` chunks per side on the compute stream.  The first chunk is enqueued BEFORE the agreement round so that
     //      the round's host synchronisation is hidden behind it; nothing is exchanged until every rank is known to be ready. ----
     PassCfg cfg1;
@@ -517,7 +538,9 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         stamp(2 * GOLAP_SHARD_ST_PART_BUILD, st);
         if (launch_err == GOLAP_OK) launch_err = partition_chunk(0, 0);
     }
+    ht.mark("first_chunk_enqueued");
     GOLAP_TRY(shard_agree(ctx, cm, launch_err));   // (on failure `drain` empties both streams and closes the workspace)
+    ht.mark("agreed");
     for (uint32_t c = 1; c < K; ++c) GOLAP_TRY(partition_chunk(0, c));
     stamp(2 * GOLAP_SHARD_ST_PART_BUILD + 1, st);
     stamp(2 * GOLAP_SHARD_ST_PART_PROBE, st);
@@ -624,7 +647,9 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     drain.ws_open = false;
     ws_end(ctx, st);
     GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_misc, 0));   // the caller's stream also orders behind the communicator's
+    ht.mark("all_enqueued");
     GOLAP_HIP_TRY(ctx, hipEventSynchronize(cm->ev_misc));         // the host synchronisation at the end of the fast path
+    ht.mark("synchronised");
     drain.armed = false;
     cm->info.host_syncs += 1;
     cm->info.chunks = K;
@@ -642,6 +667,8 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     uint32_t any = 0;
     for (uint32_t r = 0; r < P; ++r) any |= cm->h_status[r];
     *failed = any != 0;
+    ht.mark("done");
+    ht.print();
     return GOLAP_OK;
 }
 
