@@ -1526,7 +1526,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     if (part_path)
         ws += round_up(part_rows * 4, 256) + round_up(part_rows * 8, 256) + round_up(((uint64_t)pB * pS2 + 1) * 4, 256) +
               round_up(ceil_div((uint64_t)pB * pS2 + 1, FLAT_SCAN_BLOCK) * 4 + 4, 256) + round_up((uint64_t)pB * pW * 4 * pGB * 8, 256) + 4096 +
-              (p_rsv ? round_up(((uint64_t)pB * (AGR_NSUB + 1) + 16) * 4, 256) : 0);
+              (p_rsv ? round_up(((uint64_t)pB * (AGR_NSUB + 1) + 48) * 4, 256) : 0);
     ws += grouped ? 0 : (uint64_t)red_grid * 32;
     GOLAP_TRY(ws_begin(ctx, ws + 4096, st));
     double* stats4 = (double*)ws_take(ctx, (uint64_t)G * 32);
@@ -1538,8 +1538,8 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     if (part_path) {
         p_slot = (uint32_t*)ws_take(ctx, part_rows * 4);
         p_val = (double*)ws_take(ctx, part_rows * 8);
-        if (p_rsv) {   // [0] flag, [1 .. 8) spare, [8 ..) cursors [B * NSUB], then the sample's tally [B + 2]
-            p_rsvw = (uint32_t*)ws_take(ctx, ((uint64_t)pB * (AGR_NSUB + 1) + 16) * 4);
+        if (p_rsv) {   // [0] flag, [1 .. 32) spare, [32 ..) cursors [B * NSUB], then the sample's tally [B + 2]
+            p_rsvw = (uint32_t*)ws_take(ctx, ((uint64_t)pB * (AGR_NSUB + 1) + 48) * 4);
             if (!p_rsvw) return fail(ctx, GOLAP_ERR_OOM, "aggregate workspace exhausted (partition buffers)");
         }
         p_hist = (uint32_t*)ws_take(ctx, ((uint64_t)pB * pS2 + 1) * 4);
@@ -1632,9 +1632,9 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
             const bool rsv = p_rsv && !vv && ((uint64_t)val & 15) == 0;
             uint32_t *rsv_flags = nullptr, *rsv_cursor = nullptr;
             if (rsv) {
-                rsv_flags = p_rsvw; rsv_cursor = p_rsvw + 8;
+                rsv_flags = p_rsvw; rsv_cursor = p_rsvw + 32;   // (the gate word in a 128-byte line of its own, away from the reservation atomics)
                 uint32_t* tally = rsv_cursor + (size_t)pB * AGR_NSUB;
-                GOLAP_TRY(zero_async(ctx, st, p_rsvw, ((uint64_t)pB * (AGR_NSUB + 1) + 16) * 4));
+                GOLAP_TRY(zero_async(ctx, st, p_rsvw, ((uint64_t)pB * (AGR_NSUB + 1) + 48) * 4));
                 if (ctx->prof.enabled) {   // which of the two scatters did the work is read back (asynchronously) for the byte credits
                     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                     if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
