@@ -328,7 +328,10 @@ def bench_group_by(args, n, groups, label):
     import torch
 
     from gpu_olap_engine_amd import _native as N
-    from gpu_olap_engine_amd.engine import Context
+    from gpu_olap_engine_amd.engine import Context, shard_range
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.sharded:
+        return bench_group_by_sharded(args, n, groups, label)
     torch.cuda.set_device(0)
     ctx = Context(profiling=True, max_gpu_memory=0)
     info = ctx.device_info()
@@ -370,6 +373,78 @@ def bench_group_by(args, n, groups, label):
                                           f"(executor.rs:313-327 extended by the group key); {t1 - t0:.2f} s"}
     ctx.close()
     return line
+
+
+def bench_group_by_sharded(args, n, groups, label):
+    """the same GROUP BY over a ROW-SHARDED table (rank r holds rows [r n / P, (r + 1) n / P)) through golap_sharded_aggregate: every
+    rank aggregates its rows, the dense tables are all-gathered in chunks and folded in rank order, the result is replicated.  Strong
+    scaling: the table's size is fixed.  One rank per GPU under torch.distributed.run; --sharded alone = the same entry point at world
+    size 1; --rehearse = all ranks on GPU 0 over the staged (gloo) transport (functional rehearsal, not a measurement)."""
+    import torch
+    import torch.distributed as dist
+
+    from gpu_olap_engine_amd import _native as N
+    from gpu_olap_engine_amd.engine import Context, comm_unique_id, shard_range
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    ctx = Context(profiling=True, max_gpu_memory=0)
+    info = ctx.device_info()
+    if world > 1:
+        from gpu_olap_engine_amd.distributed import NativeShardedJoin
+        comm = NativeShardedJoin(ctx, transport="staged" if args.rehearse else "rccl").comm
+    else:
+        comm = ctx.comm_create_rccl(comm_unique_id(), 1, 0)
+    lo, hi = shard_range(n, rank, world)
+    keys = ctx.generate(N.GEN_SM64_MOD_I32, hi - lo, modulus=groups, seed=7, first=lo)
+    vals = ctx.generate(N.GEN_SM64_MOD_F64, hi - lo, modulus=1024, seed=8, first=lo)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return comm.sharded_aggregate([(N.AGG_SUM, 0)], [vals], group_keys=keys, n_groups=groups)
+
+    out, dt = timed(step, args.steps, args.warmup, barrier, ctx)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    stats = ctx.stats()
+    verify = {}
+    if not args.no_verify:   # the replicated result against this rank's own rows summed over ranks (exact: integer-valued doubles)
+        exp = torch.zeros(groups, dtype=torch.float64, device=dev)
+        exp.index_add_(0, keys.to(torch.int64), vals)
+        if world > 1:
+            dist.all_reduce(exp, op=dist.ReduceOp.SUM)
+        assert torch.equal(out[0], exp), "group sums differ from torch.index_add_ (+ all-reduce)"
+        verify = {"groups_equal_index_add": True, "sum_of_sums": float(out[0].sum().item())}
+    alg = n * (4 + 8) + groups * 12 * world
+    line = {"metric": f"group-by rows/sec, 1B-row GROUP BY int32 key SUM(float64), {groups} groups", "value": round(n / (ms * 1e-3), 1), "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{label} GROUP BY int32 key SUM(float64), {n} rows row-sharded over {world} rank(s), {groups} groups (dense keys)",
+                       "parallelism": f"row-sharded x{world}: local aggregate + all-gather of the dense tables + rank-order fold (golap_sharded_aggregate)"},
+            "agg_alg_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "agg_roofline_frac": round(alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
+            "roofline": roofline_of(stats, n // world, world, False), "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in stats.items()},
+            "verify": verify, "device": device_block(info)}
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return line if rank == 0 else None
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -510,6 +510,20 @@ def test_bench_sharded_path_single_rank():
     assert d["verify"]["matches"] == 20_000_000 and d["verify"]["probe_id_sum_ok"] and d["verify"]["equal_key_pairs"] == 20_000_000
 
 
+def test_bench_sharded_group_by_two_ranks_rehearsed():
+    """bench.py --config C4L --gpus 2 --rehearse: the row-sharded GROUP BY through golap_sharded_aggregate, two ranks on this GPU over
+    the staged transport (the launch line the driver would use with RCCL, minus --rehearse); the line must verify its own result."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C4L", "--rows", "50000000", "--rehearse", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["verify"]["groups_equal_index_add"] and d["scaling"] == "strong"
+
+
 def test_join_partitioned_two_sources(ctx):
     """post-exchange path: 2 sources x 128 slots on one device must equal the plain join."""
     n = 600_000
