@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--rehearse", action="store_true",
                     help="developer: run the N > 1 code path on ONE GPU (all ranks on device 0, gloo + host-staged transport instead of RCCL); "
                          "the numbers mean nothing, the line is marked")
-    ap.add_argument("--keys", default="narrow", choices=["narrow", "offset", "two", "random"],
+    ap.add_argument("--keys", default="narrow", choices=["narrow", "offset", "two", "window", "random"],
                     help="C5/C3 main leg: key columns as generated (below 2^32) | + 2^40 | two upper halves | 2^16 key-dependent upper halves (the 64-bit-row "
                          "pipeline): what the profiles of the wide kernels are taken on")
     ap.add_argument("--no-others", action="store_true", help="C5 default run: skip the other_configs block (C3, C4, C4L, C1)")
@@ -173,6 +173,8 @@ def bench_join(args, n_total, label):
                 t += 1 << 40
             if args.keys == "two":
                 t += (t & 1) << 41
+            if args.keys == "window":
+                t += (1 << 40) + (((t & 511) % 300) << 32)
             if args.keys == "random":
                 t += ((t * 0x9E3779B1) & 0xFFFF) << 44
     torch.cuda.synchronize()
@@ -298,6 +300,13 @@ def bench_join(args, n_total, label):
         bkeys += 1 << 40
         pkeys += 1 << 40
         wk = leg("offset_2p40", "the same generators + 2^40 on both key columns: every key outside [0, 2^32), one common upper half")
+        for t in (bkeys, pkeys):
+            t += ((t & 511) % 300) << 32
+        wk["window_of_300_upper_halves"] = leg("window_of_300_upper_halves", "as above + (low 9 key bits mod 300) in the upper half: 300 consecutive upper halves "
+                                               "(ids with a tenant / shard prefix) -> still 8-byte tuples, the offset of the upper half inside a window as wide as "
+                                               "the first pass's fan-out rides in the tuple (before: the 64-bit-row pipeline)")
+        for t in (bkeys, pkeys):
+            t -= ((t & 511) % 300) << 32
         bkeys += (bkeys & 1) << 41
         pkeys += (pkeys & 1) << 41
         wk["two_upper_halves"] = leg("two_upper_halves", "as above, odd keys moved by another 2^41: two upper halves -> still 8-byte tuples, a dictionary "

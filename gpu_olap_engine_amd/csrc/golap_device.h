@@ -130,10 +130,20 @@ struct PassCfg {
                               // small positive keys: 0xFFFFFFFF and 0): the tuples' first word is (hash >> b1) | (dictionary index << (32 - b1)),
                               // b1 = hash bits the first pass consumed -- those bits are implied by the bucket from then on, so equality of
                               // the word inside a sub-partition is still equality of the 64-bit key, and the rows stay 8 bytes.
+                              // More than 4 upper halves inside a window of F consecutive values (ids with a tenant / shard / epoch prefix:
+                              // 0 .. 299, or -1 .. 40): key_hi[4] = D > 4, key_hi[KEY_DICT_BASE_AT] = the window's first value; the index is
+                              // (upper half - base), no dictionary is needed, and the hash is mixed per index AFTER fmix32
+                              // (k_part1_narrow, DICT = 2).
 };
 constexpr uint32_t KEY_DICT_MAX = 4;
+constexpr uint32_t KEY_DICT_BASE_AT = 8;     // key_hi[8]: first value of the window of upper halves (offset form)
+constexpr uint32_t KEY_DICT_WORDS = 12;
 __device__ __forceinline__ uint32_t key_hi_of(const PassCfg& c) { return c.key_hi ? *c.key_hi : 0u; }
-__device__ __forceinline__ bool key_dict_mode(const PassCfg& c) { return c.key_hi && c.key_hi[KEY_DICT_MAX] > 1u; }
+// 0: one upper half (or none given), 1: 2 .. 4 of them (dictionary, scalar compares), 2: more, inside a window of F values (offset)
+__device__ __forceinline__ int key_dict_mode(const PassCfg& c) {
+    const uint32_t d = c.key_hi ? c.key_hi[KEY_DICT_MAX] : 1u;
+    return d <= 1u ? 0 : d <= KEY_DICT_MAX ? 1 : 2;
+}
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t h, const PassCfg& c) {
     if (c.mode == 0) return (h >> c.shift) & (c.F - 1u);

@@ -1983,6 +1983,7 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
         for (const void* f : wcs) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wc_lds_bytes(WC_MAX_F)));
         {
             const void* p1[] = {(const void*)k_part1_narrow<18, 18432, true, true>, (const void*)k_part1_narrow<18, 18432, true, true, 0, 1>,
+                                (const void*)k_part1_narrow<14, 14336, true, true, 0, 2>,
                                 (const void*)k_part1_narrow<18, 18432, true, false>,
                                 (const void*)k_part1_narrow<18, 18432, false, false>, (const void*)k_part1_narrow<16, 16384, true, true>,
                                 (const void*)k_part1_narrow<16, 16384, true, false>, (const void*)k_part1_narrow<16, 16384, false, false>,
@@ -2102,45 +2103,69 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
 // than KEY_DICT_MAX raise *wide.  (Round 3: a column with 2 .. 4 upper halves -- small negative next to small positive keys, two id
 // ranges -- keeps its 8-byte tuples, PassCfg::key_hi; before, a second upper half meant the 64-bit pipeline: 31 instead of 18 ms.)
 __global__ __launch_bounds__(1024) void k_key_dict(const long long* __restrict__ bkeys, unsigned long long nb, const long long* __restrict__ pkeys,
-                                                  unsigned long long np, uint32_t* __restrict__ out, uint32_t* __restrict__ wide, uint32_t max_d) {
-    __shared__ uint32_t s_dict[KEY_DICT_MAX], s_n, s_val, s_has, s_over;   // max_d: entries the first-pass form that will run can use (1 or KEY_DICT_MAX)
+                                                  unsigned long long np, uint32_t* __restrict__ out, uint32_t* __restrict__ wide, uint32_t max_d,
+                                                  uint32_t window) {
+    // max_d: entries the dictionary form of the first pass can use (1 or KEY_DICT_MAX); window: upper halves its offset form can tell
+    // apart (the first pass's fan-out; 0: form not available).  The sampled upper halves go into a small LDS hash set until more than
+    // KEY_DICT_MAX distinct ones are known (from then on only their signed minimum and maximum matter).
+    constexpr uint32_t SLOTS = 2048;              // (every thread may insert once before it sees that enough values are known)
+    __shared__ unsigned long long s_set[SLOTS];   // 1 << 32 | value, 0 = empty
+    __shared__ uint32_t s_vals[KEY_DICT_MAX + 1], s_n;
+    __shared__ int s_min, s_max;
     const uint32_t tid = threadIdx.x;
-    uint32_t smp[16];
     const uint32_t hi0 = (uint32_t)((unsigned long long)bkeys[0] >> 32);
+    uint32_t smp[16];
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
         const unsigned long long s = (unsigned long long)j * 1024 + tid;   // sample s of 8192
         smp[2 * j] = nb ? (uint32_t)((unsigned long long)bkeys[(s * nb) >> 13] >> 32) : hi0;
         smp[2 * j + 1] = np ? (uint32_t)((unsigned long long)pkeys[(s * np) >> 13] >> 32) : hi0;
     }
-    if (tid == 0) { s_dict[0] = hi0; s_n = 1; s_over = 0; }
+    for (uint32_t i = tid; i < SLOTS; i += 1024) s_set[i] = 0ull;
+    if (tid == 0) { s_n = 0; s_min = (int)hi0; s_max = (int)hi0; }
     __syncthreads();
-    for (uint32_t round = 0; round <= KEY_DICT_MAX; ++round) {   // one new entry per round (the smallest missing upper half)
-        if (tid == 0) { s_val = 0xFFFFFFFFu; s_has = 0; }
-        __syncthreads();
-        const uint32_t n = s_n;
-        uint32_t cand = 0;
-        bool has = false;
+    int mn = (int)smp[0], mx = (int)smp[0];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            bool known = false;
-            for (uint32_t d = 0; d < n; ++d) known = known || smp[j] == s_dict[d];
-            if (!known && (!has || smp[j] < cand)) { cand = smp[j]; has = true; }
+    for (int j = 0; j < 16; ++j) {
+        mn = (int)smp[j] < mn ? (int)smp[j] : mn;
+        mx = (int)smp[j] > mx ? (int)smp[j] : mx;
+        if (j && smp[j] == smp[j - 1]) continue;   // (the common case: one value everywhere)
+        const unsigned long long e = (1ull << 32) | smp[j];
+        uint32_t s = (smp[j] * 0x9E3779B1u) >> 21;
+        for (uint32_t probes = 0; probes < SLOTS && __hip_atomic_load(&s_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= KEY_DICT_MAX; ++probes) {
+            // (more than KEY_DICT_MAX values known: the set is no longer needed)
+            const unsigned long long old = atomicCAS(&s_set[s], 0ull, e);
+            if (old == e) break;
+            if (old == 0ull) {   // a new value
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at <= KEY_DICT_MAX) s_vals[at] = smp[j];
+                break;
+            }
+            s = (s + 1u) & (SLOTS - 1u);
         }
-        if (has) { atomicMin(&s_val, cand); s_has = 1; }
-        __syncthreads();
-        if (!s_has) break;   // (work-group-uniform)
-        if (tid == 0) {
-            if (n < max_d) { s_dict[n] = s_val; s_n = n + 1; } else s_over = 1;
-        }
-        __syncthreads();
-        if (s_over) break;
+    }
+    if (mn != (int)hi0) atomicMin(&s_min, mn);
+    if (mx != (int)hi0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint32_t n = s_n <= KEY_DICT_MAX ? s_n : KEY_DICT_MAX + 1;   // distinct sampled upper halves, or "more than the dictionary holds"
+    // several halves inside a window of `window` consecutive values (signed: -1 and 0 are neighbours): the offset form, which also
+    // takes halves the sample has missed; else up to max_d arbitrary values: the dictionary form; else 64-bit rows
+    const bool offs = n > 1 && max_d > 1 && window && (uint32_t)(s_max - s_min) < window;
+    const bool small = !offs && n <= max_d;
+    if (small && tid < n) {   // the dictionary: entry 0 = the first build key's upper half, the others ascending behind it
+        const uint32_t v = s_vals[tid];
+        uint32_t rank = 0, below0 = 0;   // (hi0 is among the samples: sample 0 of the build side, or every sample when that side is empty)
+        for (uint32_t i = 0; i < n; ++i) { rank += s_vals[i] < v ? 1u : 0u; below0 += s_vals[i] < hi0 ? 1u : 0u; }
+        out[v == hi0 ? 0u : (rank < below0 ? rank + 1u : rank)] = v;
     }
     __syncthreads();
-    if (tid < KEY_DICT_MAX) out[tid] = tid < s_n ? s_dict[tid] : s_dict[0];
+    if (tid < KEY_DICT_MAX && (!small || tid >= n)) out[tid] = small ? out[0] : hi0;   // unused entries repeat entry 0
     if (tid == 0) {
-        out[KEY_DICT_MAX] = s_n;
-        if (s_over) atomicOr(wide, 1u);
+        out[KEY_DICT_MAX] = small ? n : (offs ? KEY_DICT_MAX + 1 : 1u);
+        // the window starts below the smallest value seen by as much as the values seen leave free on both sides: halves the sample
+        // missed are still inside if they are near
+        out[KEY_DICT_BASE_AT] = offs ? (uint32_t)s_min - (window - 1u - (uint32_t)(s_max - s_min)) / 2u : 0u;
+        if (!small && !offs) atomicOr(wide, 1u);
     }
 }
 
@@ -2154,6 +2179,13 @@ static uint32_t part1_narrow_tile() {
     if (v1 == 16 || v1 == 116) return 16 * P1N_THREADS;
     if (v1 == 24 || v1 == 124 || v1 == 0) return 24 * P1N_THREADS;
     return 18 * P1N_THREADS;
+}
+
+// the offset form (k_part1_narrow<.., DICT = 2>: more than 4 upper halves inside a window of F values) exists for the default kernel choice on
+// 16-byte aligned columns.  GOLAP_DICT_OFFSET=0: A/B and test hook (such columns then take the 64-bit pipeline, as before).
+static bool part1_offset_form_ok(uint64_t key_ptrs_ored) {
+    const char* e = knob("GOLAP_DICT_OFFSET");
+    return p1n_variant() == 118 && (key_ptrs_ored & 15) == 0 && !(e && !strcmp(e, "0"));
 }
 
 // first pass of the narrow pipeline (also the exchange-time partition of the multi-GPU fast path)
@@ -2173,6 +2205,7 @@ static void launch_part1_narrow(hipStream_t st, uint64_t in_keys, uint32_t rid_b
     if (v1 == 118 && al16) {
         GOLAP_P1N(18, 18432, true, true);
         if (cfg.key_hi && cfg.pre_hashed) GOLAP_P1N(18, 18432, true, true, 0, 1);   // the dictionary form: runs instead when the column has 2 .. 4 upper halves
+        if (cfg.key_hi && cfg.pre_hashed && part1_offset_form_ok(in_keys)) GOLAP_P1N(14, 14336, true, true, 0, 2);   // ... and the offset form: more of them, inside a window of F values
     } else if (v1 == 116 && al16) GOLAP_P1N(16, 16384, true, true);
     else if (v1 == 24 || v1 == 124) GOLAP_P1N(24, 12288, false, false);
     else if ((v1 == 18 || v1 == 118) && al16) GOLAP_P1N(18, 18432, true, false);
@@ -2323,9 +2356,11 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     uint32_t* probe_hit = nullptr;
     if (use_narrow_keys(plan, p->n_build, p->n_probe)) {
         // optimistic 32-bit pipeline first (its big buffers alias the 64-bit pipeline's: only one of the two does any work)
-        uint32_t* words = (uint32_t*)ws_take(ctx, 32);   // [0] wide flag, [1] constant 0, [2 .. 5] the dictionary of upper key halves, [6] its size
+        // [0] wide flag, [1] constant 0, [2 ..) PassCfg::key_hi: the dictionary of upper key halves ([2 .. 5] the scalar form's, [6] its size, [10 ..) the big one)
+        const uint64_t words_bytes = (2 + (uint64_t)KEY_DICT_WORDS) * 4;
+        uint32_t* words = (uint32_t*)ws_take(ctx, words_bytes);
         if (!words) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
-        GOLAP_TRY(zero_async(ctx, st, (void*)words, 32));
+        GOLAP_TRY(zero_async(ctx, st, (void*)words, words_bytes));
         if (ctx->prof.enabled) {   // profiling: which of the two pipelines did the work is read back (asynchronously) for the byte credits
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
@@ -2338,7 +2373,8 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
         if (p1n_variant() != 0 && p2r_variant() != 0 && plan.passes[1].cfg.F <= (uint32_t)P2R_MAX_F) {
             hipLaunchKernelGGL(k_key_dict, dim3(1), dim3(1024), 0, st, (const long long*)p->build_key_ptr, (unsigned long long)p->n_build,
                                (const long long*)p->probe_key_ptr, (unsigned long long)p->n_probe, words + 2, words,
-                               (p1n_variant() == 118 && ((p->build_key_ptr | p->probe_key_ptr) & 15) == 0) ? KEY_DICT_MAX : 1u);   // (launch_part1_narrow's dictionary form)
+                               (p1n_variant() == 118 && ((p->build_key_ptr | p->probe_key_ptr) & 15) == 0) ? KEY_DICT_MAX : 1u,   // (launch_part1_narrow's dictionary forms)
+                               part1_offset_form_ok(p->build_key_ptr | p->probe_key_ptr) ? plan.passes[0].cfg.F : 0u);
             key_hi = words + 2;
         }
         if (p->join_type & 2) {

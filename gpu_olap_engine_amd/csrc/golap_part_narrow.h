@@ -47,6 +47,14 @@ static inline size_t part1_narrow_lds_bytes(uint32_t F, uint32_t win, bool wide 
 // DICT != 0: the form for key columns with 2 .. 4 distinct upper halves (PassCfg::key_hi): every key's upper half is looked up in the
 // dictionary (scalar registers), the tuple's first word is (hash >> b1) | (index << (32 - b1)).  Both forms are enqueued; each
 // returns at once unless the dictionary size on the device says it is the one to run.
+// DICT == 2: more than 4 upper halves, all inside a window of F consecutive values (ids with a tenant / shard / epoch prefix).  The
+// index is (upper half - key_hi[KEY_DICT_BASE_AT]) -- no dictionary, and halves the sample has not seen are fine as long as they fall
+// into the window -- and the hash is fmix32(lower half ^ index * 0x9E3779B1).  With the reference's fold (lower ^ upper half) the rows
+// (t1, l) and (t2, l ^ t1 ^ t2) share every hash bit, and a table of D tenants with dense local ids makes D-fold collisions the rule
+// (bucket sizes with sqrt(D) times the spread): small upper halves flip LOW bits of the lower half, which lands on another valid id.
+// A full-width constant per index flips high bits too: the partner l ^ c1 ^ c2 is a valid local id with probability 2^(k - 32) for
+// k-bit local ids, i.e. a row expects (rows / 2^32) such partners -- the rate of a random hash.  Still a bijection of the lower half
+// per index, which is all the tuple (hash >> b1 | index << (32 - b1)) needs.
 // WIDE != 0 (round 3): the first pass of the 64-bit-row pipeline in the same shape -- whole 64-bit keys and row ids out as two arrays
 // (out_rows = the key array, out_rids), 12 bytes per row through the LDS window, so a 12288-row tile; no key check and no abandon
 // word (the launch is gated by rs.run_if instead), two hidden stores per row.  Replaces k_scatter_big<.., RESERVE>, which loaded a
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     // the attempt may be over before it starts (k_key_hi's sample found two upper key halves): ~2000 work-groups that each load and
     // rank one tile before they notice cost 0.45 ms per side; asking first costs the good case one L2 round trip per work-group
     if (!WIDE && __hip_atomic_load(rs.wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    if (!WIDE && key_dict_mode(cfg) != (DICT != 0)) return;   // (work-group-uniform: the other form of this pass does the work)
+    if (!WIDE && key_dict_mode(cfg) != DICT) return;   // (work-group-uniform: the other form of this pass does the work)
     const uint32_t chunk = blockIdx.x;
     const uint32_t len = chunk_len[chunk];
     if (len == 0) return;
@@ -88,9 +96,10 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
     const uint32_t khi = WIDE ? 0u : __builtin_amdgcn_readfirstlane(key_hi_of(cfg));   // the upper key half this attempt stands on (see PassCfg::key_hi)
     const bool emit_hash = cfg.pre_hashed != 0;
     // DICT: the dictionary's other entries and the position of the index in the tuple's first word
-    const uint32_t kd1 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[1]) : 0u, kd2 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[2]) : 0u,
-                   kd3 = DICT ? __builtin_amdgcn_readfirstlane(cfg.key_hi[3]) : 0u;
+    const uint32_t kd1 = DICT == 1 ? __builtin_amdgcn_readfirstlane(cfg.key_hi[1]) : 0u, kd2 = DICT == 1 ? __builtin_amdgcn_readfirstlane(cfg.key_hi[2]) : 0u,
+                   kd3 = DICT == 1 ? __builtin_amdgcn_readfirstlane(cfg.key_hi[3]) : 0u;
     const uint32_t b1 = 31u - (uint32_t)__builtin_clz(F);   // hash bits this pass consumes (F = 256 << e1: the low 8 + e1 bits, bucket_of)
+    const uint32_t kbase = DICT == 2 ? __builtin_amdgcn_readfirstlane(cfg.key_hi[KEY_DICT_BASE_AT]) : 0u;   // first upper half of the window (offset form)
 
     // keys of the tile: kv[h] = (lo, hi) of key 2h, (lo, hi) of key 2h + 1
     u32x4 kv[(RPT + 1) / 2];
@@ -160,6 +169,11 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
             uint32_t h;
             if (WIDE) {
                 h = hash_int32((int32_t)(k32[r] ^ khi_r));                                // == hash_int64 of the whole key (join_kernels.cuh:37-41)
+            } else if (DICT == 2) {
+                const uint32_t id = khi_r - kbase;
+                hi = id > hi ? id : hi;                                                   // (the largest index of the tile: checked against the window below)
+                h = hash_int32((int32_t)(k32[r] ^ (id * 0x9E3779B1u)));                   // (see the template's comment: a full-width constant per index)
+                k32[r] = (h >> b1) | (id << (32u - b1));
             } else if (DICT) {
                 const uint32_t m0 = khi_r ^ khi, m1 = khi_r ^ kd1, m2 = khi_r ^ kd2, m3 = khi_r ^ kd3;
                 const uint32_t ma = m0 < m1 ? m0 : m1, mb = m2 < m3 ? m2 : m3;
@@ -177,6 +191,7 @@ __global__ __launch_bounds__(P1N_THREADS) void k_part1_narrow(const long long* _
                 br[r] = (b << 16) | atomicAdd(&s_cnt[b], 1u);                    // b < 1024, rank < 32768
             }
         }
+        if (DICT == 2) hi >>= b1;   // an upper half outside the window of F values: the attempt is over
         if (!WIDE && hi) atomicOr(rs.wide, 1u);
         lds_barrier();
         if (s_w[NW]) return;   // work-group-uniform: some key somewhere does not fit 32 bits, the 64-bit pipeline takes over

@@ -26,7 +26,7 @@ def main():
         rnd += 1
         nb = int(rng.integers(20_000_000, 70_000_000))
         npr = int(rng.integers(1_000_000, 70_000_000))
-        kind = str(rng.choice(["unique", "dups", "wide", "one_wide", "skew", "neg_pos", "halves", "many_halves", "halves_one_odd"]))
+        kind = str(rng.choice(["unique", "dups", "wide", "one_wide", "skew", "neg_pos", "halves", "many_halves", "halves_one_odd", "window_of_halves", "window_one_far"]))
         dom = nb if kind != "dups" else nb // 3
         bt = ctx.generate(N.GEN_BUILD_KEYS if kind != "dups" else N.GEN_SM64_MOD_I64, nb, modulus=dom, seed=int(rng.integers(1, 1000)))
         pt = ctx.generate(N.GEN_SM64_MOD_I64, npr, modulus=int(dom * rng.choice([1.0, 1.3])), seed=int(rng.integers(1, 1000)))
@@ -44,6 +44,12 @@ def main():
             if kind == "halves_one_odd":
                 i = int(rng.integers(0, nb)); j = int(rng.integers(0, npr))
                 bt[i] = (9 << 40) + 5; pt[j] = (9 << 40) + 5
+        elif kind in ("window_of_halves", "window_one_far"):          # 5 .. 120 consecutive upper halves from a random (also negative) start: the offset form
+            k = int(rng.integers(5, 121)); lo = int(rng.integers(-60, 1000))
+            bt += ((bt % k) + lo) << 32; pt += ((pt % k) + lo) << 32
+            if kind == "window_one_far":                              # ... and one key far outside the window, in a row no sample sees
+                i = int(rng.integers(0, nb)); j = int(rng.integers(0, npr))
+                bt[i] = (123_456 << 32) + 5; pt[j] = (123_456 << 32) + 5
         elif kind == "many_halves":                                   # the 64-bit-row pipeline
             bt += ((bt * 0x9E3779B1) & 0xFF) << 36; pt += ((pt * 0x9E3779B1) & 0xFF) << 36
         elif kind == "skew":                                          # a hot key: 200k extra build rows, 50 probe rows

@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "gpu_olap_engine_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 # The instantiations the product is known to launch by default (k_part1_narrow<18, 18432, VEC2, ASM> and the four ring lengths): they
 # must be present; every OTHER instantiation with ASM = true found in the assembly is audited as well (discovered, not listed).
-EXPECTED = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi0ELi0EEE", "k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi1ELi0EEE",
+EXPECTED = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi0ELi0EEE", "k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi1ELi0EEE", "k_part1_narrowILi14ELi14336ELb1ELb1ELi0ELi2ELi0EEE",
             "k_part1_narrowILi12ELi12288ELb1ELb1ELi0ELi0ELi1EEE", "k_part2_ringILi4ELi32ELb1ELi0EEE",
             "k_part2_ringILi4ELi64ELb1ELi0EEE", "k_part2_ringILi4ELi128ELb1ELi0EEE", "k_part2_ringILi4ELi256ELb1ELi0EEE",
             "k_agg_scatter_rsvIiLb1ELb1EEE", "k_agg_scatter_rsvIiLb0ELb1EEE", "k_agg_scatter_rsvIxLb1ELb1EEE", "k_agg_scatter_rsvIxLb0ELb1EEE"]

@@ -292,13 +292,15 @@ def test_asymmetric_sides_mix_first_pass_forms(ctx, nb, npr):
 
 
 @pytest.mark.parametrize("shape", ["narrow", "common_upper_half", "negative_small", "two_upper_halves", "negative_and_positive", "four_upper_halves",
-                                   "five_upper_halves", "many_upper_halves", "one_wide_key_last", "negative_key_first", "two_halves_and_one_odd_key_last"])
+                                   "five_upper_halves", "many_upper_halves", "one_wide_key_last", "negative_key_first", "two_halves_and_one_odd_key_last",
+                                   "hundred_consecutive_halves", "halves_minus_three_to_forty", "hundred_consecutive_halves_and_one_far_key_last"])
 def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
     """Large joins first try 8-byte (key32, row id) tuples, which stand while the keys of both sides have at most four different
     upper halves (one: 0 for small ids, but also keys offset by 2^40, or small negative keys; two to four: a dictionary index rides
-    in the tuple, e.g. small negative NEXT TO small positive keys); a fifth upper half -- in the sample, in the first tile or in the
-    very last row -- must hand the whole join over to the 64-bit pipeline on the device, with identical results (checked on the
-    device: every pair key-equal, probe ids a permutation)."""
+    in the tuple, e.g. small negative NEXT TO small positive keys; any number inside a window of consecutive values as wide as the
+    first pass's fan-out -- ids with a tenant / shard prefix: the offset (upper half - window start) rides instead); a fifth upper half
+    far from the others -- in the sample, in the first tile or in the very last row -- must hand the whole join over to the 64-bit
+    pipeline on the device, with identical results (checked on the device: every pair key-equal, probe ids a permutation)."""
     n = 60_000_000
     bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
     pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
@@ -322,6 +324,17 @@ def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
     elif shape == "many_upper_halves":
         bt += ((bt * 0x9E3779B1) & 0xFFFF) << 32
         pt += ((pt * 0x9E3779B1) & 0xFFFF) << 32
+    elif shape.startswith("hundred_consecutive_halves"):
+        bt += (bt % 100) << 32
+        pt += (pt % 100) << 32
+        if shape.endswith("far_key_last"):
+            old = int(bt[n - 1].item())
+            bt[n - 1] = (70_000 << 32) + 11
+            pt[n - 1] = (70_000 << 32) + 11                             # far outside the window of upper halves
+            orphans = int((pt == old).sum().item())
+    elif shape == "halves_minus_three_to_forty":
+        bt += ((bt % 44) - 3) << 32
+        pt += ((pt % 44) - 3) << 32
     elif shape == "two_halves_and_one_odd_key_last":
         bt += (bt & 1) << 40
         pt += (pt & 1) << 40
@@ -347,7 +360,8 @@ def test_narrow_key_pipeline_and_its_64bit_fallback(ctx, shape):
     wide_ms, narrow_ms = st["join_build_probe_lds_wide"]["total_ms"], st["join_build_probe_lds"]["total_ms"]
     # (negative_key_first: the first build key is the dictionary's first entry, every other key's upper half its second -- tuples;
     #  one_wide_key_last: no sample sees the odd key, the first pass meets it in its last tile and hands over)
-    tuples = shape in ("narrow", "common_upper_half", "negative_small", "two_upper_halves", "negative_and_positive", "four_upper_halves", "negative_key_first")
+    tuples = shape in ("narrow", "common_upper_half", "negative_small", "two_upper_halves", "negative_and_positive", "four_upper_halves", "negative_key_first",
+                       "hundred_consecutive_halves", "halves_minus_three_to_forty")
     assert (wide_ms < narrow_ms) if tuples else (wide_ms > narrow_ms)   # which pipeline did the work (the other returns at once)
 
 
