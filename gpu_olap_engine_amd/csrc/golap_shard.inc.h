@@ -80,11 +80,16 @@ struct golap_comm {
     hipStream_t stream = nullptr;          // the exchange runs here, beside the caller's compute stream
     static constexpr int MAX_CHUNKS = 8;
     hipEvent_t ev_part[2][MAX_CHUNKS] = {}, ev_xchg[2] = {nullptr, nullptr}, ev_half[2] = {nullptr, nullptr}, ev_hdr = nullptr, ev_misc = nullptr;   // ordering only (no timing)
+    hipEvent_t ev_keys = nullptr, ev_agree = nullptr;   // payload of the agreement round written / agreement words (and payload) gathered
     hipEvent_t ev_t[2 * GOLAP_SHARD_STAGES + 1] = {};   // stage begin / end + call start (timing events; recorded only with profiling on)
     uint32_t* h_status = nullptr;          // pinned: status words / size matrices read back by the host
     uint64_t h_status_bytes = 0;
-    uint32_t* d_agree = nullptr;           // device: [0] this rank's agreement word, [16 ..) every rank's (all-gathered); never in the workspace
-    uint32_t* h_agree = nullptr;           // pinned: [0] word to send, [16 ..) words received
+    // agreement round: one 16-word unit per rank -- [0] the agreement word, [1 .. 16) payload written on the device (the fast path's summary
+    // of its upper key halves).  d_agree: [0 .. 16) this rank's unit, [16 + 16 r ..) rank r's (all-gathered); never in the workspace.
+    // h_agree: [0] word to send, [16 + 16 r] words received, [AGREE_SCRATCH ..) small host-to-device staging of the callers.
+    static constexpr uint32_t AGREE_UNIT = 16, AGREE_MAX_WORLD = 128, AGREE_SCRATCH = 16 + 16 * 128, AGREE_WORDS = 16 + 16 * 128 + 256;
+    uint32_t* d_agree = nullptr;
+    uint32_t* h_agree = nullptr;
     golap_sharded_join_info info{};
 };
 
@@ -259,6 +264,99 @@ static void make_shard_plan(uint32_t world, uint64_t n_build_total, uint64_t n_p
 // ---------------------------------------------------------------------------
 // device helpers of the fast path
 // ---------------------------------------------------------------------------
+// Upper key halves across ranks.  The tuple pipeline needs ONE frame of reference on every rank (PassCfg::key_hi): each rank summarises
+// a sample of its shard (k_key_summary -> the payload of its agreement unit), the units are all-gathered with the agreement words, and
+// every rank derives the same words from the same P summaries (k_key_combine): one upper half everywhere -- D = 1, any value -- or
+// several inside a window as wide as the partition's fan-out -- the offset form of the first pass (golap_part_narrow.h, DICT = 2), also
+// when every rank holds ONE half of its own (a table sharded by tenant) -- or up to four halves far apart: the dictionary form.  Anything
+// else raises the build side's failure word: the
+// partition kernels return at once and the call takes the exact path, as it did for every key beyond 2^32 before.
+//   summary (agreement unit words 1 .. 7): [1] distinct sampled halves (1 .. 4; 5 = more), [2 .. 5] the first four, [6] signed min, [7] signed max
+__global__ __launch_bounds__(1024) void k_key_summary(const long long* __restrict__ bkeys, unsigned long long nb, const long long* __restrict__ pkeys,
+                                                     unsigned long long np, uint32_t* __restrict__ unit) {
+    constexpr uint32_t SLOTS = 2048;
+    __shared__ unsigned long long s_set[SLOTS];
+    __shared__ uint32_t s_vals[KEY_DICT_MAX + 1], s_n;
+    __shared__ int s_min, s_max;
+    const uint32_t tid = threadIdx.x;
+    if (nb == 0 && np == 0) {   // an empty shard has nothing to say
+        if (tid == 0) { unit[1] = 0; unit[6] = 0; unit[7] = 0; }
+        return;
+    }
+    const uint32_t hi0 = (uint32_t)((unsigned long long)(nb ? bkeys[0] : pkeys[0]) >> 32);
+    uint32_t smp[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const unsigned long long s = (unsigned long long)j * 1024 + tid;   // sample s of 8192 per side
+        smp[2 * j] = nb ? (uint32_t)((unsigned long long)bkeys[(s * nb) >> 13] >> 32) : hi0;
+        smp[2 * j + 1] = np ? (uint32_t)((unsigned long long)pkeys[(s * np) >> 13] >> 32) : hi0;
+    }
+    for (uint32_t i = tid; i < SLOTS; i += 1024) s_set[i] = 0ull;
+    if (tid == 0) { s_n = 0; s_min = (int)hi0; s_max = (int)hi0; }
+    __syncthreads();
+    int mn = (int)smp[0], mx = (int)smp[0];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        mn = (int)smp[j] < mn ? (int)smp[j] : mn;
+        mx = (int)smp[j] > mx ? (int)smp[j] : mx;
+        if (j && smp[j] == smp[j - 1]) continue;
+        const unsigned long long e = (1ull << 32) | smp[j];
+        uint32_t s = (smp[j] * 0x9E3779B1u) >> 21;
+        for (uint32_t probes = 0; probes < SLOTS && __hip_atomic_load(&s_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= KEY_DICT_MAX; ++probes) {
+            const unsigned long long old = atomicCAS(&s_set[s], 0ull, e);
+            if (old == e) break;
+            if (old == 0ull) {
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at <= KEY_DICT_MAX) s_vals[at] = smp[j];
+                break;
+            }
+            s = (s + 1u) & (SLOTS - 1u);
+        }
+    }
+    if (mn != (int)hi0) atomicMin(&s_min, mn);
+    if (mx != (int)hi0) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t n = s_n <= KEY_DICT_MAX ? s_n : KEY_DICT_MAX + 1;
+        unit[1] = n;
+        for (uint32_t i = 0; i < KEY_DICT_MAX; ++i) unit[2 + i] = i < n ? s_vals[i] : s_vals[0];
+        unit[6] = (uint32_t)s_min;
+        unit[7] = (uint32_t)s_max;
+    }
+}
+
+// gathered: [world][AGREE_UNIT] (words as above); out = PassCfg::key_hi words (KEY_DICT_WORDS); window: the partition's fan-out, 0 = the offset
+// form is not available (then only one common upper half is accepted)
+__global__ void k_key_combine(const uint32_t* __restrict__ gathered, uint32_t world, uint32_t unit_words, uint32_t window, uint32_t max_d,
+                              uint32_t* __restrict__ out, uint32_t* __restrict__ fail_word) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t vals[KEY_DICT_MAX + 1], n = 0;
+    int mn = 0, mx = 0;
+    bool any = false, many = false;
+    for (uint32_t r = 0; r < world; ++r) {
+        const uint32_t* u = gathered + (size_t)r * unit_words;
+        const uint32_t k = u[1];
+        if (k == 0) continue;   // (an empty shard)
+        if (!any) { mn = (int)u[6]; mx = (int)u[7]; any = true; }
+        mn = (int)u[6] < mn ? (int)u[6] : mn;
+        mx = (int)u[7] > mx ? (int)u[7] : mx;
+        if (k > KEY_DICT_MAX) many = true;
+        for (uint32_t i = 0; i < (k < KEY_DICT_MAX ? k : KEY_DICT_MAX); ++i) {
+            bool known = false;
+            for (uint32_t j = 0; j < n; ++j) known = known || vals[j] == u[2 + i];
+            if (!known) { if (n <= KEY_DICT_MAX) vals[n] = u[2 + i]; n = n < KEY_DICT_MAX + 1 ? n + 1 : n; }
+        }
+    }
+    if (!any) { n = 1; vals[0] = 0; }
+    const bool one = n == 1 && !many;
+    const bool offs = !one && window && (uint32_t)(mx - mn) < window;
+    const bool dict = !one && !offs && !many && n <= max_d;   // 2 .. 4 values far apart: the dictionary form (the order of the gathered units: the same on every rank)
+    for (uint32_t i = 0; i < KEY_DICT_MAX; ++i) out[i] = dict && i < n ? vals[i] : vals[0];
+    out[KEY_DICT_MAX] = dict ? n : (offs ? KEY_DICT_MAX + 1 : 1u);
+    out[KEY_DICT_BASE_AT] = offs ? (uint32_t)mn - (window - 1u - (uint32_t)(mx - mn)) / 2u : 0u;
+    if (!one && !offs && !dict) atomicOr(fail_word, 1u);
+}
+
 struct ShardSrcTable {
     uint32_t cap[P2R_MAX_SRC];    // [source r * K + chunk c] rows provisioned per (bucket, sub-range)
     uint32_t base[P2R_MAX_SRC];   // row offset (relative to the tuple base pointer) of that (source, chunk)'s group 0
@@ -269,7 +367,8 @@ struct ShardSrcTable {
 //   my buckets are [me * per, (me + 1) * per)),  hdr[r * hdr_stride + K * F1 * nsub] = source r's "narrow attempt failed" word.
 __global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restrict__ hdr, uint32_t hdr_stride, uint32_t F1, uint32_t world, uint32_t K,
                                                         uint32_t me, uint32_t per, uint32_t nsub, ShardSrcTable src, uint32_t F2, uint32_t sigmas,
-                                                        uint32_t pad, uint32_t* __restrict__ seg_off, uint32_t* __restrict__ seg_len,
+                                                        uint32_t pad, const uint32_t* __restrict__ key_dict /*PassCfg::key_hi words, may be null*/, uint32_t dict_mul,
+                                                        uint32_t* __restrict__ seg_off, uint32_t* __restrict__ seg_len,
                                                         uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap, uint32_t* __restrict__ status,
                                                         unsigned long long limit_rows) {
     __shared__ uint32_t s_w[16];
@@ -291,7 +390,8 @@ __global__ __launch_bounds__(1024) void k_shard_segments(const uint32_t* __restr
                 }
             }
         const uint32_t avg = (n_g + F2 - 1) / F2;
-        const uint32_t cap = (avg + sigmas * isqrt_u32(avg) + pad + 15u) & ~15u;
+        const uint32_t sg = key_dict && key_dict[KEY_DICT_MAX] > 1u ? sigmas * dict_mul : sigmas;   // several upper key halves: wider slots (reserve_cap's comment)
+        const uint32_t cap = (avg + sg * isqrt_u32(avg) + pad + 15u) & ~15u;
         slot_cap[g] = cap;
         total = cap * F2;
     }
@@ -335,23 +435,42 @@ static int32_t ensure_host_words(golap_comm* cm, uint64_t bytes) {
 // (which waits for nothing at that point) and ends in a host synchronisation; the fast path hides it behind its first partition
 // kernel.  Returns GOLAP_OK when every rank is ready, this rank's own error if it has one, GOLAP_ERR_PEER otherwise.
 // ---------------------------------------------------------------------------
-static int32_t shard_agree(golap_ctx* ctx, golap_comm* cm, int32_t my_err) {
+// Two halves, so that a caller can enqueue work that depends on the gathered payload between them (the host blocks in the second):
+//   shard_agree_post   h_agree[0] -> d_agree[0], all-gather of the 16-word units, ev_agree, read-back; `payload_ready` (may be null): the
+//                      communicator's stream first waits for it (the event behind the kernel that wrote d_agree[1 .. 16))
+//   shard_agree_wait   host synchronisation + verdict
+static int32_t shard_agree_post(golap_ctx* ctx, golap_comm* cm, int32_t my_err, hipEvent_t payload_ready) {
+    const uint32_t P = (uint32_t)cm->world;
+    cm->h_agree[0] = (uint32_t)my_err;
+    hipError_t e = hipSuccess;
+    if (payload_ready) e = hipStreamWaitEvent(cm->stream, payload_ready, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(cm->d_agree, cm->h_agree, 4, hipMemcpyHostToDevice, cm->stream);
+    int32_t st = e == hipSuccess ? comm_all_gather(cm, (uint64_t)cm->d_agree, (uint64_t)(cm->d_agree + 16), golap_comm::AGREE_UNIT * 4, cm->stream) : GOLAP_ERR_HIP;
+    if (st == GOLAP_OK) e = hipEventRecord(cm->ev_agree, cm->stream);
+    if (st == GOLAP_OK && e == hipSuccess)
+        e = hipMemcpyAsync(cm->h_agree + 16, cm->d_agree + 16, (size_t)P * golap_comm::AGREE_UNIT * 4, hipMemcpyDeviceToHost, cm->stream);
+    if (st == GOLAP_OK && e != hipSuccess) st = fail(ctx, GOLAP_ERR_HIP, "agreement round failed: %s", hipGetErrorString(e));
+    return st;
+}
+static int32_t shard_agree_wait(golap_ctx* ctx, golap_comm* cm, int32_t my_err, int32_t post_status) {
     const uint32_t P = (uint32_t)cm->world;
     std::string my_msg = my_err != GOLAP_OK ? ctx->err : std::string();
-    cm->h_agree[0] = (uint32_t)my_err;
-    hipError_t e = hipMemcpyAsync(cm->d_agree, cm->h_agree, 4, hipMemcpyHostToDevice, cm->stream);
-    int32_t st = e == hipSuccess ? comm_all_gather(cm, (uint64_t)cm->d_agree, (uint64_t)(cm->d_agree + 16), 4, cm->stream) : GOLAP_ERR_HIP;
-    if (st == GOLAP_OK) e = hipMemcpyAsync(cm->h_agree + 16, cm->d_agree + 16, (size_t)P * 4, hipMemcpyDeviceToHost, cm->stream);
-    if (st == GOLAP_OK && e == hipSuccess) e = hipStreamSynchronize(cm->stream);
+    hipError_t e = post_status == GOLAP_OK ? hipStreamSynchronize(cm->stream) : hipSuccess;
     cm->info.host_syncs += 1;
     if (my_err != GOLAP_OK) { ctx->err = my_msg; set_thread_error(my_msg.c_str()); return my_err; }
-    if (st != GOLAP_OK) return st;
+    if (post_status != GOLAP_OK) return post_status;
     if (e != hipSuccess) return fail(ctx, GOLAP_ERR_HIP, "agreement round failed: %s", hipGetErrorString(e));
     for (uint32_t r = 0; r < P; ++r)
-        if (cm->h_agree[16 + r] != 0u)
+        if (cm->h_agree[16 + golap_comm::AGREE_UNIT * r] != 0u)
             return fail(ctx, GOLAP_ERR_PEER, "golap_sharded_join: rank %u failed before the exchange (its error code %u); no rank exchanged anything", r,
-                        cm->h_agree[16 + r]);
+                        cm->h_agree[16 + golap_comm::AGREE_UNIT * r]);
     return GOLAP_OK;
+}
+static int32_t shard_agree(golap_ctx* ctx, golap_comm* cm, int32_t my_err) {
+    std::string my_msg = my_err != GOLAP_OK ? ctx->err : std::string();
+    const int32_t posted = shard_agree_post(ctx, cm, my_err, nullptr);
+    if (my_err != GOLAP_OK) ctx->err = my_msg;   // (a failing post must not replace this rank's own message)
+    return shard_agree_wait(ctx, cm, my_err, posted);
 }
 
 // Leaves a collective call on an error path with nothing in flight: kernels and transfers still queued on either stream may
@@ -405,6 +524,7 @@ static int32_t shard_fast_layout(golap_ctx* ctx, const golap_sharded_join_params
         const uint64_t avg = ceil_div(n_g_max, F2);
         uint32_t sg, pd;
         provision_of("GOLAP_SLOT_SIGMAS", sg, pd);   // the same head-room k_shard_segments lays the slots out with
+        sg *= DICT_SIGMA_MUL;   // (a column with several upper halves gets wider slots, as in golap_join: slot_rows_bound)
         L.final_rows_[side] = (uint64_t)per * F2 * round_up(avg + (uint64_t)sg * isqrt_host(avg) + pd + 15, 16);
         if (L.send_rows[side] + L.recv_rows[side] >= 0xFFFFFFF0ull || L.final_rows_[side] >= 0xFFFFFFF0ull)
             return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: positions exceed u32");
@@ -457,7 +577,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     struct SideArrays { uint32_t *c_off[golap_comm::MAX_CHUNKS], *c_len[golap_comm::MAX_CHUNKS], *seg_off, *seg_len, *slot_base, *slot_cap, *sub_start, *sub_len; };
     SideArrays A[2];
     uint64_t tuples[2] = {0, 0}, finals[2] = {0, 0};
-    uint32_t *words = nullptr, *status_all = nullptr, *probe_hit = nullptr, *hdr = nullptr, *hdr_all = nullptr;
+    uint32_t *words = nullptr, *key_words = nullptr, *status_all = nullptr, *probe_hit = nullptr, *hdr = nullptr, *hdr_all = nullptr;
     uint32_t nc[2][golap_comm::MAX_CHUNKS], ccr[2][golap_comm::MAX_CHUNKS];
     auto prepare = [&]() -> int32_t {
         if (arg_err != GOLAP_OK) return arg_err;
@@ -475,10 +595,11 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
             if (!tuples[side] || !finals[side]) return fail(ctx, GOLAP_ERR_OOM, oom);
         }
         words = (uint32_t*)ws_take(ctx, 16);            // [0] local status (any rank's failure ORed in), [1] constant 0
+        key_words = (uint32_t*)ws_take(ctx, (uint64_t)KEY_DICT_WORDS * 4);   // PassCfg::key_hi, the same on every rank (k_key_combine)
         status_all = (uint32_t*)ws_take(ctx, (uint64_t)P * 4);
         hdr = (uint32_t*)ws_take(ctx, (uint64_t)L.hdr_stride * 4);          // [side][K][F1 * nsub] reservation cursors, [side] failure word
         hdr_all = (uint32_t*)ws_take(ctx, (uint64_t)P * L.hdr_stride * 4);
-        if (!words || !status_all || !hdr || !hdr_all) return fail(ctx, GOLAP_ERR_OOM, oom);
+        if (!words || !key_words || !status_all || !hdr || !hdr_all) return fail(ctx, GOLAP_ERR_OOM, oom);
         if (p->join_type & 2) {
             probe_hit = (uint32_t*)ws_take(ctx, (ceil_div(L.final_rows_[1], 32) + 1) * 4);
             if (!probe_hit) return fail(ctx, GOLAP_ERR_OOM, "sharded join workspace exhausted (probe bitmap)");
@@ -530,16 +651,40 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         return GOLAP_OK;
     };
     int32_t launch_err = prep;
+    const bool key_frames = prep == GOLAP_OK && p1n_variant() != 0;   // (the tuple kernels know about PassCfg::key_hi; GOLAP_P1N=0 selects round 1's)
     if (prep == GOLAP_OK) {
         stamp(16, st);
         launch_err = zero_async(ctx, st, words, 16);
         if (launch_err == GOLAP_OK) launch_err = zero_async(ctx, st, hdr, (uint64_t)L.hdr_stride * 4);
+        if (launch_err == GOLAP_OK) launch_err = zero_async(ctx, st, key_words, (uint64_t)KEY_DICT_WORDS * 4);
         if (launch_err == GOLAP_OK && probe_hit) launch_err = zero_async(ctx, st, probe_hit, (ceil_div(L.final_rows_[1], 32) + 1) * 4);
+        if (launch_err == GOLAP_OK && key_frames) {   // this rank's upper key halves: the payload of its agreement unit
+            hipLaunchKernelGGL(k_key_summary, dim3(1), dim3(1024), 0, st, (const long long*)keys_in[0], (unsigned long long)n_local[0], (const long long*)keys_in[1],
+                               (unsigned long long)n_local[1], cm->d_agree);
+            if (hipEventRecord(cm->ev_keys, st) != hipSuccess) launch_err = fail(ctx, GOLAP_ERR_HIP, "event record failed");
+        }
+    }
+    // The agreement round is posted -- its all-gather also carries every rank's summary --, the first partition chunk is enqueued behind
+    // it, and only then the host waits for the verdict: the synchronisation hides behind that kernel.  Nothing is exchanged until
+    // every rank is known to be ready.
+    const int32_t posted = shard_agree_post(ctx, cm, launch_err, launch_err == GOLAP_OK && key_frames ? cm->ev_keys : nullptr);
+    if (launch_err == GOLAP_OK && posted == GOLAP_OK) {
+        if (key_frames) {
+            GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_agree, 0));
+            hipLaunchKernelGGL(k_key_combine, dim3(1), dim3(64), 0, st, (const uint32_t*)(cm->d_agree + 16), P, golap_comm::AGREE_UNIT,
+                               part1_offset_form_ok(keys_in[0] | keys_in[1]) ? F1 : 0u,
+                               (p1n_variant() == 118 && ((keys_in[0] | keys_in[1]) & 15) == 0) ? KEY_DICT_MAX : 1u, key_words, hdr + (size_t)K * F1 * nsub);
+            cfg1.key_hi = key_words;
+        }
         stamp(2 * GOLAP_SHARD_ST_PART_BUILD, st);
-        if (launch_err == GOLAP_OK) launch_err = partition_chunk(0, 0);
+        launch_err = partition_chunk(0, 0);
     }
     ht.mark("first_chunk_enqueued");
-    GOLAP_TRY(shard_agree(ctx, cm, launch_err));   // (on failure `drain` empties both streams and closes the workspace)
+    {
+        const int32_t agreed = shard_agree_wait(ctx, cm, prep, posted);   // (on failure `drain` empties both streams and closes the workspace)
+        if (agreed != GOLAP_OK) return agreed;
+        if (launch_err != GOLAP_OK) return launch_err;   // (a launch failure behind the agreement: as fatal as a HIP error in the middle of the exchange)
+    }
     ht.mark("agreed");
     for (uint32_t c = 1; c < K; ++c) GOLAP_TRY(partition_chunk(0, c));
     stamp(2 * GOLAP_SHARD_ST_PART_BUILD + 1, st);
@@ -587,6 +732,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     PassCfg cfg2 = sp.local.passes[0].cfg;
     cfg2.S = 1;
     cfg2.pre_hashed = p1n_variant() != 0 ? 1u : 0u;
+    cfg2.key_hi = cfg1.key_hi;
     GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_hdr, 0));   // (recorded behind ev_xchg[0]: the build rows and every rank's cursors)
     for (int side = 0; side < 2; ++side) {
         cm->info.rows_received[side] = L.recv_rows[side];
@@ -602,7 +748,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
         if (side == 0) stamp(2 * GOLAP_SHARD_ST_RING_BUILD, st);
         hipLaunchKernelGGL(k_shard_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)(hdr_all + (size_t)side * L.hdr_words), L.hdr_stride, F1, P, K, me, per,
-                           nsub, tab, F2, sigmas, pad, A[side].seg_off, A[side].seg_len, A[side].slot_base, A[side].slot_cap, words,
+                           nsub, tab, F2, sigmas, pad, cfg1.key_hi, DICT_SIGMA_MUL, A[side].seg_off, A[side].seg_len, A[side].slot_base, A[side].slot_cap, words,
                            (unsigned long long)L.final_rows_[side]);
         res[side] = SideResult();
         res[side].keys = (const long long*)finals[side];
@@ -851,8 +997,11 @@ static int32_t comm_common(golap_ctx* ctx, int32_t world, int32_t rank, golap_co
     if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_misc, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_hdr, hipEventDisableTiming);
     for (int i = 0; i < 2 * GOLAP_SHARD_STAGES + 1 && e == hipSuccess; ++i) e = hipEventCreate(&cm->ev_t[i]);
-    if (e == hipSuccess) e = hipMalloc((void**)&cm->d_agree, (16 + P2R_MAX_SRC) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&cm->h_agree, (16 + P2R_MAX_SRC) * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_keys, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_agree, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&cm->d_agree, golap_comm::AGREE_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(cm->d_agree, 0, golap_comm::AGREE_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&cm->h_agree, golap_comm::AGREE_WORDS * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) { golap_comm_destroy(cm); return fail(ctx, GOLAP_ERR_HIP, "communicator setup failed: %s", hipGetErrorString(e)); }
     *made = cm;
     return GOLAP_OK;
@@ -901,6 +1050,8 @@ void golap_comm_destroy(golap_comm* cm) {
     }
     if (cm->ev_misc) (void)hipEventDestroy(cm->ev_misc);
     if (cm->ev_hdr) (void)hipEventDestroy(cm->ev_hdr);
+    if (cm->ev_keys) (void)hipEventDestroy(cm->ev_keys);
+    if (cm->ev_agree) (void)hipEventDestroy(cm->ev_agree);
     for (int i = 0; i < 2 * GOLAP_SHARD_STAGES + 1; ++i)
         if (cm->ev_t[i]) (void)hipEventDestroy(cm->ev_t[i]);
     if (cm->d_agree) (void)hipFree(cm->d_agree);

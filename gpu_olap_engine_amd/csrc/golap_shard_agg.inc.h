@@ -183,8 +183,8 @@ extern "C" int32_t golap_sharded_aggregate(golap_ctx* ctx, golap_comm* cm, const
         GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     // sizes: every rank's per-owner counts, all-gathered and read back
-    for (uint32_t r = 0; r < P; ++r) cm->h_agree[32 + r] = send_cnt[r];
-    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)cnt_all, cm->h_agree + 32, (size_t)P * 4, hipMemcpyHostToDevice, cm->stream));
+    for (uint32_t r = 0; r < P; ++r) cm->h_agree[golap_comm::AGREE_SCRATCH + r] = send_cnt[r];
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)cnt_all, cm->h_agree + golap_comm::AGREE_SCRATCH, (size_t)P * 4, hipMemcpyHostToDevice, cm->stream));
     GOLAP_TRY(comm_all_gather(cm, cnt_all, cnt_all + 256, (uint64_t)P * 4, cm->stream));
     uint32_t* h_cnt = cm->h_status + 512;
     GOLAP_HIP_TRY(ctx, hipMemcpyAsync(h_cnt, (const void*)(cnt_all + 256), (size_t)P * P * 4, hipMemcpyDeviceToHost, cm->stream));

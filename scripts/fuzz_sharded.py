@@ -31,6 +31,10 @@ def draw(rng, n, kind, domain):
         return k
     if kind == "offset":                                   # one common upper half: the tuple pipeline on the low halves
         return rng.integers(0, domain, n) + (5 << 32)
+    if kind == "tenants":                                  # consecutive upper halves (a tenant prefix) from a random, also negative, start:
+        k = rng.integers(0, domain, n)                     # the window form on every rank -- or the exact path when the window is too small
+        t, lo = int(rng.integers(2, 200)), int(rng.integers(-50, 300))
+        return k + (((k % t) + lo) << 32)
     if kind == "wide":
         return rng.integers(-2**62, 2**62, n)
     raise ValueError(kind)
@@ -68,7 +72,7 @@ def worker(rank, world, port, budget, seed, q):
         big = rng.random() < 0.3
         nb = int(rng.integers(0, 4_000_000 if big else 100_000))
         npr = int(rng.integers(0, 4_000_000 if big else 100_000))
-        kind = str(rng.choice(["uniform", "unique", "hot", "offset", "wide"]))
+        kind = str(rng.choice(["uniform", "unique", "hot", "offset", "tenants", "wide"]))
         domain = int(max(1, rng.choice([nb // 4 + 1, nb + 1, 4 * nb + 1, 97])))
         jt = int(rng.choice([0, 0, 1, 2, 3]))
         mode = str(rng.choice(["fast", "exact"]))

@@ -35,7 +35,22 @@ def _keys(variant, n, lo, cnt):
     return oracle.gen_sm64_mod(11, lo, cnt, n // 2), oracle.gen_sm64_mod(12, lo, cnt, n // 2)
 
 
-def _worker(rank, world, port, n, variant, mode, join_type, wide_rank, max_msg, q):
+def _shape_keys(k, shape):
+    """upper key halves as a function of the key VALUE (equal keys stay equal on both sides and on every rank)"""
+    if shape == "common_offset":
+        return k + (1 << 40)
+    if shape == "five_tenants":
+        return k + ((k % 5) << 32)
+    if shape == "tenants_minus_two_to_sixty":
+        return k + (((k % 63) - 2) << 32)
+    if shape == "far_halves":
+        return k + ((k % 5) << 44)
+    if shape == "three_far_halves":
+        return k + ((k % 3) << 44)
+    return k
+
+
+def _worker(rank, world, port, n, variant, mode, join_type, wide_rank, max_msg, q, shape=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if mode == "fast":
@@ -51,6 +66,7 @@ def _worker(rank, world, port, n, variant, mode, join_type, wide_rank, max_msg, 
         c = Context(max_gpu_memory=0)
         lo, hi = shard_range(n, rank, world)
         b, p = _keys(variant, n, lo, hi - lo)
+        b, p = _shape_keys(b, shape), _shape_keys(p, shape)
         if wide_rank == rank:
             b[-1] = -3                                  # ONE key outside [0, 2^32) on ONE rank: every rank must leave the fast path together
         sj = NativeShardedJoin(c, transport="staged", max_msg_bytes=max_msg)
@@ -67,12 +83,12 @@ def _worker(rank, world, port, n, variant, mode, join_type, wide_rank, max_msg, 
         dist.destroy_process_group()
 
 
-def _run(world, n, variant, mode, join_type=0, wide_rank=-1, max_msg=0):
+def _run(world, n, variant, mode, join_type=0, wide_rank=-1, max_msg=0, shape=None):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, n, variant, mode, join_type, wide_rank, max_msg, q)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n, variant, mode, join_type, wide_rank, max_msg, q, shape)) for r in range(world)]
     for pr in procs:
         pr.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -82,9 +98,10 @@ def _run(world, n, variant, mode, join_type=0, wide_rank=-1, max_msg=0):
     return sorted(res, key=lambda r: r[0])
 
 
-def _expected(n, variant, join_type, world, wide_rank):
+def _expected(n, variant, join_type, world, wide_rank, shape=None):
     import oracle
     b, p = _keys(variant, n, 0, n)
+    b, p = _shape_keys(b, shape), _shape_keys(p, shape)
     if wide_rank >= 0:
         from gpu_olap_engine_amd.engine import shard_range
         b[shard_range(n, wide_rank, world)[1] - 1] = -3
@@ -173,6 +190,25 @@ def test_sharded_join_one_wide_key_sends_every_rank_to_the_exact_path():
     got = canonical(np.concatenate([r[1] for r in res]))
     assert got.shape[0] == me and np.array_equal(got, exp)
     assert all(r[2]["fast_path_abandoned"] and not r[2]["fast_path"] for r in res)
+
+
+@pytest.mark.parametrize("world,shape", [(2, "common_offset"), (4, "five_tenants"), (2, "tenants_minus_two_to_sixty"), (2, "three_far_halves"), (2, "far_halves")])
+def test_sharded_join_upper_key_halves(world, shape):
+    """Keys beyond 2^32 on the partition-exchange path: every rank summarises the upper halves of its shard, the summaries travel with
+    the agreement words, and all ranks derive the same frame of reference -- one common upper half, or a window of consecutive ones
+    (ids with a tenant prefix: the offset form of the first pass), or up to four far-apart ones (the dictionary form) -- and stay on the
+    fast path; five halves too far apart for a window send every rank to the exact path together.  Bit-exact against the oracle either way."""
+    from np_twin import canonical
+    n = 3_000_000
+    res = _run(world, n, "dups", "fast", shape=shape)
+    exp, me = _expected(n, "dups", 0, world, -1, shape=shape)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+    for _, _, info in res:
+        if shape == "far_halves":
+            assert info["fast_path_abandoned"] and not info["fast_path"]
+        else:
+            assert info["fast_path"] and not info["fast_path_abandoned"] and info["host_syncs"] == 2
 
 
 @pytest.mark.parametrize("mode,join_type", [("fast", 3), ("exact", 1), ("exact", 2)])
