@@ -316,12 +316,14 @@ int32_t golap_join_partitioned_abort(golap_ctx* ctx);
  * golap_comm binds a context to a communicator: the built-in RCCL one (librccl is dlopen'ed; the host distributes the
  * 128-byte unique id any way it likes) or host-supplied transport callbacks (other fabrics; the tests' gloo rehearsal).
  * golap_sharded_join is collective: every rank of the communicator calls it with the same totals.  Fast path (large
- * joins whose keys all lie in [0, 2^32)): no histogram and no size exchange -- every bucket owns a fixed, provisioned
+ * joins whose keys fit 8-byte (hash, row id) tuples: all in [0, 2^32), or -- agreed on across the ranks from samples that ride in the
+ * agreement round -- one common upper half, a window of consecutive upper halves as wide as the partition's fan-out, or up to four
+ * far-apart ones): no histogram and no size exchange -- every bucket owns a fixed, provisioned
  * range, messages have sizes both ends can compute, the per-bucket row counts travel device-to-device (all-gather) and
  * only reach the kernels; the host synchronises twice per join: on the agreement word (did every rank get through its argument
  * checks and allocations? -- read while the first partition kernel runs) and on the status words at the end.  A rank's rows are
- * partitioned and shipped in chunks, so the exchange runs beside the partition pass from the first chunk on.  Anything else (a key outside
- * [0, 2^32), a skewed bucket, small inputs) takes the exact path: histogram partition, size all-gather read back by the
+ * partitioned and shipped in chunks, so the exchange runs beside the partition pass from the first chunk on.  Anything else (upper key
+ * halves beyond that, a skewed bucket, small inputs) takes the exact path: histogram partition, size all-gather read back by the
  * host, variable-size exchange, segment-fed local passes.  All ranks take the same path (the status word is gathered).
  * Failures: whatever can fail on the host before the exchange (arguments, plan, workspace) is agreed on first -- if any rank
  * failed, the failing rank returns its error and every other rank GOLAP_ERR_PEER, nobody waits in a collective.  A HIP error in
