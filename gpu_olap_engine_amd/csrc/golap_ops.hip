@@ -328,10 +328,14 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
                                                     int vec = 0 /*16-byte loads: see the loop*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     double* s_sum = reinterpret_cast<double*>(s_raw);
-    double* s_mn = s_sum + n_groups;
+    double* s_mn = s_sum + n_groups;   // NEED_MM only: without MIN / MAX an entry is 12 bytes (sum + count) and 12.9k groups fit one table
     double* s_mx = s_mn + n_groups;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mx + n_groups);
-    for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) { s_sum[g] = 0.0; s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; s_cnt[g] = 0; }
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(NEED_MM ? s_mx + n_groups : s_sum + n_groups);
+    for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        s_sum[g] = 0.0;
+        s_cnt[g] = 0;
+        if (NEED_MM) { s_mn[g] = GOLAP_F64_MAX; s_mx[g] = -GOLAP_F64_MAX; }
+    }
     __syncthreads();
     const long long* vi = (const long long*)val;
     const double* vf = (const double*)val;
@@ -411,8 +415,8 @@ __global__ __launch_bounds__(512) void k_group_lds(const KeyT* __restrict__ keys
     for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
         row[g] = s_sum[g];
         row[n_groups + g] = (double)s_cnt[g];
-        row[2 * n_groups + g] = s_mn[g];
-        row[3 * n_groups + g] = s_mx[g];
+        row[2 * n_groups + g] = NEED_MM ? s_mn[g] : GOLAP_F64_MAX;    // (the fold reads all four planes: identities when nobody asked)
+        row[3 * n_groups + g] = NEED_MM ? s_mx[g] : -GOLAP_F64_MAX;
     }
 }
 
@@ -1472,8 +1476,13 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     const uint32_t G = p->n_groups;
     const bool grouped = p->group_key_ptr != 0;
     ctx->prof.cur_gate_host = nullptr;
-    // LDS path when the 28-byte-per-group table fits comfortably (2 work-groups per CU)
-    const bool lds_path = grouped && (uint64_t)G * 28 <= 64 * 1024;
+    // LDS path while ONE table per CU fits: 28 bytes per group with MIN / MAX (5558 groups), 12 without (12 969 groups) in 152 KiB of the
+    // CU's 160 KiB.  (Round 2 stopped at 64 KiB for two work-groups per CU; one per CU is the faster shape anyway, see per_cu below, and
+    // group counts up to there are 3.5 x faster here than through the partition path.)
+    bool any_mm_ = false;
+    for (uint32_t i = 0; i < n_specs; ++i) any_mm_ = any_mm_ || specs[i].func == GOLAP_AGG_MIN || specs[i].func == GOLAP_AGG_MAX;
+    constexpr uint64_t LDS_TABLE_BYTES = 152 * 1024;
+    const bool lds_path = grouped && (uint64_t)G * (any_mm_ ? 28 : 12) + 16 <= LDS_TABLE_BYTES;
     // beyond one LDS table: partition by slot range, then LDS-aggregate (big inputs only; GOLAP_AGG_PART=0 -> global atomics)
     const char* part_env = knob("GOLAP_AGG_PART");
     const bool part_path = grouped && !lds_path && G <= (uint32_t)AG_GB * AG_MAX_B && p->n_rows >= (1ull << 22) && p->n_rows < 0xFFFFFFF0ull &&
@@ -1515,7 +1524,10 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     uint32_t lds_grid = 0;
     uint64_t rows_per_block = 0;
     if (lds_path) {
-        uint32_t per_cu = 2;
+        // ONE 512-thread work-group per CU: with the 16-byte loads a second one only adds bytes in flight (96 KB per CU and round), and
+        // this chip's HBM delivers less the more a CU keeps in flight (DESIGN.md 4.1 "HBM ceiling"): 1B rows, 1024 groups 2.05 -> 1.93 ms,
+        // 2340 groups 2.10 -> 1.90 ms, the same with MIN / MAX (scripts/ab_agg.py).  Half as many partial tables to fold, too.
+        uint32_t per_cu = 1;
         if (const char* e = knob("GOLAP_AGG_WGS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));   // A/B hook
         lds_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * per_cu, ceil_div(std::max<uint64_t>(1, p->n_rows), 4096)));
         rows_per_block = round_up(ceil_div(std::max<uint64_t>(1, p->n_rows), lds_grid), 4);   // (a multiple of 4: the 16-byte-load form)
@@ -1575,7 +1587,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                                  (const void*)k_group_lds<int, false, true>,       (const void*)k_group_lds<int, false, false>,
                                  (const void*)k_group_lds<long long, true, true>,  (const void*)k_group_lds<long long, true, false>,
                                  (const void*)k_group_lds<long long, false, true>, (const void*)k_group_lds<long long, false, false>};
-            for (const void* f : fns) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            for (const void* f : fns) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
             ctx->attr_done[2] = true;
         }
     }
@@ -1604,7 +1616,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                                     (unsigned long long)p->n_rows, 0, 0ll, partials, (const uint8_t*)nullptr, vv);
             hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(OP_THREADS), 0, st, partials, red_grid, stats4);
         } else if (lds_path) {
-            const size_t lds = (size_t)G * 28 + 16;
+            const size_t lds = (size_t)G * (need_minmax ? 28 : 12) + 16;
             const char* vec_env = knob("GOLAP_AGG_VEC");   // "0": 4- / 8-byte loads (A/B hook)
             const int lds_vec = !vv && ((p->group_key_ptr | (uint64_t)val) & 15) == 0 && !(vec_env && !strcmp(vec_env, "0")) ? 1 : 0;
             {

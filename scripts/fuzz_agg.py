@@ -34,7 +34,7 @@ def main():
         why = None
         size = rng.random()
         n = int(rng.integers(1, 50_000)) if size < 0.4 else int(rng.integers(50_000, 8_000_000)) if size < 0.9 else int(rng.integers(34_000_000, 45_000_000))
-        G = int(rng.choice([1, 7, 300, 1024, 2340, 2341, 5000, 100_000, 1_000_003, 2_097_152, 3_000_000]))
+        G = int(rng.choice([1, 7, 300, 1024, 2340, 2341, 5000, 5558, 5559, 12_969, 12_970, 100_000, 1_000_003, 2_097_152, 3_000_000]))   # (5558 / 12969: the last group counts of ONE LDS table with / without MIN / MAX)
         kd = rng.choice([np.int32, np.int64])
         shape = str(rng.choice(["dense", "skewed", "sparse", "fold"]))
         if shape == "dense":

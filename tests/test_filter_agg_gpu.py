@@ -138,8 +138,29 @@ def test_grouped_aggregate(ctx, key_dtype, G):
         assert (a[0] == 0).all() and (a[1] == 0).all() and (a[2] == np.finfo(np.float64).max).all() and (a[3] == -np.finfo(np.float64).max).all() and (a[4] == 0).all()
 
 
+@pytest.mark.parametrize("G,with_min_max", [(5558, True), (5559, True), (12_969, False), (12_970, False)])
+def test_grouped_aggregate_one_full_cu_table(ctx, G, with_min_max):
+    """The LDS pre-aggregation takes ONE table per CU of up to 152 KiB: 5558 groups of 28 bytes with MIN / MAX, 12 969 groups of 12 bytes
+    without; one group more goes through the partition path (big inputs) -- the same result on both sides of each boundary."""
+    n = 5_000_000
+    keys = oracle.gen_sm64_mod(91, 0, n, G, np.int32)
+    vals = oracle.gen_sm64_mod(92, 0, n, 4096, np.float64) - 2048.0
+    ok, ost = oracle.group_aggregate(keys.astype(np.int64), vals)
+    specs = [(N.AGG_SUM, 0), (N.AGG_COUNT, 0), (N.AGG_AVG, 0)] + ([(N.AGG_MIN, 0), (N.AGG_MAX, 0)] if with_min_max else [])
+    ctx.stats_reset()
+    out, counts = ctx.aggregate(specs, [dev(vals)], group_keys=dev(keys), n_groups=G, want_counts=True)
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    present = counts > 0
+    assert np.array_equal(np.nonzero(present)[0], ok)
+    assert np.array_equal(out[0, present], ost[:, 0]) and np.array_equal(out[1, present], ost[:, 1]) and np.array_equal(out[2, present], ost[:, 4])
+    if with_min_max:
+        assert np.array_equal(out[3, present], ost[:, 2]) and np.array_equal(out[4, present], ost[:, 3])
+    st = ctx.stats()
+    assert ("hash_aggregate_lds" in st) == (G in (5558, 12_969)) and ("agg_partition_scatter" in st) == (G in (5559, 12_970))
+
+
 @pytest.mark.parametrize("key_dtype", [np.int32, np.int64])
-@pytest.mark.parametrize("G", [3000, 100_000, 1_000_003])
+@pytest.mark.parametrize("G", [6000, 100_000, 1_000_003])
 def test_grouped_aggregate_partitioned_path(ctx, key_dtype, G):
     """group counts beyond one LDS table on a big input: partition by slot range, then LDS-aggregate (no global atomics);
     must equal the oracle and the global-atomic path (GOLAP_AGG_PART=0)."""
