@@ -1263,9 +1263,16 @@ __global__ void k_fill_i64(long long* __restrict__ a, unsigned long long n, long
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) a[i] = v;
 }
 
-static uint32_t stream_grid(golap_ctx* ctx, uint64_t n, uint32_t per_block) {
+// SEQ_WGS: work-groups per CU for the purely sequential scans (filter mask, filter + sum, ungrouped reduction).  The more a CU keeps in
+// flight the less this chip's HBM delivers (DESIGN.md 4.1 "HBM ceiling"): at 1B rows two 256-thread work-groups per CU beat eight --
+// filter + sum 2.82 -> 2.54 ms (6.3 TB/s), mask 1.89 -> 1.74, ungrouped SUM / MAX 1.49 -> 1.41 (scripts/dev/stream_ab.py); one per CU
+// starves it (3.48 ms).  Gathers and generators keep eight.
+constexpr uint32_t SEQ_WGS = 2;
+static uint32_t stream_grid(golap_ctx* ctx, uint64_t n, uint32_t per_block, uint64_t per_cu = 8) {
     uint64_t want = ceil_div(std::max<uint64_t>(1, n), per_block);
-    uint64_t cap = (uint64_t)ctx->prop.multiProcessorCount * 8;   // guideline 11: cap at ~2048 blocks, grid-stride the rest
+    // guideline 11: cap the grid (8 per CU = ~2048 blocks), grid-stride the rest
+    if (const char* e = knob("GOLAP_STREAM_WGS")) per_cu = (uint64_t)std::max(1, std::min(32, atoi(e)));   // A/B hook
+    uint64_t cap = (uint64_t)ctx->prop.multiProcessorCount * per_cu;
     return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
 }
 
@@ -1288,17 +1295,17 @@ int32_t golap_filter_launch(golap_ctx* ctx, const golap_filter_predicate* pred, 
     const bool aligned = (p->column_ptr % 16 == 0) && (p->out_mask_ptr % 4 == 0);
     uint64_t done = 0;
     if (p->validity_ptr) {   // NULL-aware form: one row per lane
-        hipLaunchKernelGGL(k_filter_mask1, dim3(stream_grid(ctx, p->n_rows, OP_THREADS)), dim3(OP_THREADS), 0, st, (const long long*)p->column_ptr,
+        hipLaunchKernelGGL(k_filter_mask1, dim3(stream_grid(ctx, p->n_rows, OP_THREADS, SEQ_WGS)), dim3(OP_THREADS), 0, st, (const long long*)p->column_ptr,
                            0ull, (unsigned long long)p->n_rows, pred->op, (long long)pred->literal, (uint8_t*)p->out_mask_ptr, (const uint8_t*)p->validity_ptr);
         done = p->n_rows;
     } else if (aligned && p->n_rows >= 4) {
         const uint64_t n4 = p->n_rows / 4;
-        hipLaunchKernelGGL(k_filter_mask4, dim3(stream_grid(ctx, n4, OP_THREADS)), dim3(OP_THREADS), 0, st, (const longlong2*)p->column_ptr,
+        hipLaunchKernelGGL(k_filter_mask4, dim3(stream_grid(ctx, n4, OP_THREADS, SEQ_WGS)), dim3(OP_THREADS), 0, st, (const longlong2*)p->column_ptr,
                            (unsigned long long)n4, pred->op, (long long)pred->literal, (uint32_t*)p->out_mask_ptr);
         done = n4 * 4;
     }
     if (done < p->n_rows)
-        hipLaunchKernelGGL(k_filter_mask1, dim3(stream_grid(ctx, p->n_rows - done, OP_THREADS)), dim3(OP_THREADS), 0, st, (const long long*)p->column_ptr,
+        hipLaunchKernelGGL(k_filter_mask1, dim3(stream_grid(ctx, p->n_rows - done, OP_THREADS, SEQ_WGS)), dim3(OP_THREADS), 0, st, (const long long*)p->column_ptr,
                            (unsigned long long)done, (unsigned long long)p->n_rows, pred->op, (long long)pred->literal, (uint8_t*)p->out_mask_ptr);
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     return GOLAP_OK;
@@ -1423,7 +1430,7 @@ int32_t golap_filter_sum_nullable(golap_ctx* ctx, const golap_filter_predicate* 
     KnobScope knobs_(ctx);
     GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick_stream(ctx, stream);
-    const uint32_t grid = stream_grid(ctx, n_rows, OP_THREADS * 8);
+    const uint32_t grid = stream_grid(ctx, n_rows, OP_THREADS * 8, SEQ_WGS);
     GOLAP_TRY(ws_begin(ctx, (uint64_t)grid * 32 + 4096, st));
     double* partials = (double*)ws_take(ctx, (uint64_t)grid * 32);
     if (!partials) return fail(ctx, GOLAP_ERR_OOM, "workspace exhausted");
@@ -1532,7 +1539,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
         lds_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)cus * per_cu, ceil_div(std::max<uint64_t>(1, p->n_rows), 4096)));
         rows_per_block = round_up(ceil_div(std::max<uint64_t>(1, p->n_rows), lds_grid), 4);   // (a multiple of 4: the 16-byte-load form)
     }
-    const uint32_t red_grid = stream_grid(ctx, p->n_rows, OP_THREADS * 8);
+    const uint32_t red_grid = stream_grid(ctx, p->n_rows, OP_THREADS * 8, SEQ_WGS);
     uint64_t ws = (uint64_t)G * 32 + 8192;
     ws += lds_path ? (uint64_t)lds_grid * 4 * G * 8 : 0;
     if (part_path)
