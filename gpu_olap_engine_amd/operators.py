@@ -14,7 +14,7 @@ import pyarrow as pa
 from . import _native as N
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_HERE, "lib", "libgolap_host.so")
+HOST_LIB_PATH = os.environ.get("GOLAP_HOST_DEV_LIB") or os.path.join(_HERE, "lib", "libgolap_host.so")   # (GOLAP_HOST_DEV_LIB: developer builds, e.g. a sanitizer build)
 
 
 class ArrowSchema(C.Structure):
