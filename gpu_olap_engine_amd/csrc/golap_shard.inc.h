@@ -667,7 +667,8 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     // The agreement round is posted -- its all-gather also carries every rank's summary --, the first partition chunk is enqueued behind
     // it, and only then the host waits for the verdict: the synchronisation hides behind that kernel.  Nothing is exchanged until
     // every rank is known to be ready.
-    const int32_t posted = shard_agree_post(ctx, cm, launch_err, launch_err == GOLAP_OK && key_frames ? cm->ev_keys : nullptr);
+    const int32_t my_word = launch_err;   // what this rank tells the others (and what it returns itself when it is an error)
+    const int32_t posted = shard_agree_post(ctx, cm, my_word, my_word == GOLAP_OK && key_frames ? cm->ev_keys : nullptr);
     if (launch_err == GOLAP_OK && posted == GOLAP_OK) {
         if (key_frames) {
             GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(st, cm->ev_agree, 0));
@@ -681,7 +682,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
     }
     ht.mark("first_chunk_enqueued");
     {
-        const int32_t agreed = shard_agree_wait(ctx, cm, prep, posted);   // (on failure `drain` empties both streams and closes the workspace)
+        const int32_t agreed = shard_agree_wait(ctx, cm, my_word, posted);   // (on failure `drain` empties both streams and closes the workspace)
         if (agreed != GOLAP_OK) return agreed;
         if (launch_err != GOLAP_OK) return launch_err;   // (a launch failure behind the agreement: as fatal as a HIP error in the middle of the exchange)
     }
