@@ -3,7 +3,10 @@
 1B x 1B int64 radix hash join (config C5), at 1/2/4/8 MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W          (single GPU: the whole 1B x 1B join on one device)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts `python -m torch.distributed.run
+                                                            --nproc-per-node N bench.py <same arguments>` as a CHILD process before it
+                                                            touches the GPU, relays rank 0's JSON line and the child's exit code)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the same under an external launcher: one rank per GPU, RCCL)
     python bench.py --config C3|C4|C4L|C1                  (the other BASELINE configs, same JSON shape, one GPU)
 
 A "step" is one complete pass of the operator over the synthetic, device-resident input (join: radix passes, [partition
@@ -48,6 +51,48 @@ def parse_args():
     ap.add_argument("--no-others", action="store_true", help="C5 default run: skip the other_configs block (C3, C4, C4L, C1)")
     ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (golap_sharded_join) even with 1 rank")
     return ap.parse_args()
+
+
+def self_launch_command(argv, n_ranks, port):
+    """The command `python bench.py --gpus N` (N > 1, no launcher) starts: one rank per GPU under torch.distributed.run on this node,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve), the same bench arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without WORLD_SIZE in the environment: nobody has launched the ranks, so this process does -- as a CHILD
+    (subprocess; this process has made no GPU call and imports no torch, and it never replaces itself: an exec from a process that
+    holds the GPU takes the box down).  The child's stderr passes through; of its stdout the JSON line of rank 0 is relayed as this
+    process's one line, anything else goes to stderr.  Returns the child's exit code."""
+    import subprocess
+    cmd = self_launch_command(argv, args.gpus, int(os.environ.get("MASTER_PORT", 0)) or free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, cwd=ROOT)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 without printing a line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
 
 
 def kernel_source_hash():
@@ -114,6 +159,24 @@ def cpu_join_baseline(sample, rank):
             "fair_note": f"radix-partitioned, std::thread over all {cores} host cores; {t2 - t1:.2f} s"}
 
 
+def exchange_rates(join_info, world):
+    """What this rank's partition exchange moved, from the last call's device timestamps (golap_sharded_join_info): bytes this rank
+    SENT to its world - 1 peers (the library counts them; its own partitions never leave the device) / the exchange stage's
+    duration, per side.  per_link = that / (world - 1): every peer is one xGMI hop away and all are served at once, so this is the
+    rate ONE link carried in ONE direction while the others were busy too -- a lower bound of the link's capability (the stage also
+    waits for the partition chunks it ships)."""
+    if world < 2 or not join_info.get("fast_path"):
+        return None
+    out = {}
+    for side, (nm, stage) in enumerate((("build", "exchange_build"), ("probe", "exchange_probe"))):
+        t0, t1 = join_info["stage_ms"][stage]
+        if t1 > t0:
+            gbps = join_info["bytes_sent"][side] / ((t1 - t0) * 1e-3) / 1e9
+            out[f"{nm}_out_GBps"] = round(gbps, 1)
+            out[f"{nm}_per_link_GBps"] = round(gbps / (world - 1), 1)
+    return out or None
+
+
 def device_block(info):
     return {"name": info["name"], "arch": info["gcn_arch"], "cus": info["compute_units"], "hbm_bus_bits": info["memory_bus_bits"],
             "mem_clock_mhz": info["memory_clock_mhz"]}
@@ -144,8 +207,9 @@ def bench_join(args, n_total, label):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` (it launches its ranks itself) or "
+                         f"torch.distributed.run --nproc-per-node N with the same N")
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -274,8 +338,12 @@ def bench_join(args, n_total, label):
         # where the time went on every rank (device timestamps of the fast path's stages, ms since that rank's first kernel)
         if world > 1:
             infos = [None] * world
-            dist.all_gather_object(infos, {"stage_ms": join_info["stage_ms"], "total_ms": join_info["total_ms"], "bytes_sent": join_info["bytes_sent"]})
+            dist.all_gather_object(infos, {"stage_ms": join_info["stage_ms"], "total_ms": join_info["total_ms"], "bytes_sent": join_info["bytes_sent"],
+                                           "fast_path": join_info["fast_path"], "exchange": exchange_rates(join_info, world)})
             join_info["per_rank"] = infos
+            ex = [i["exchange"] for i in infos if i["exchange"]]
+            if ex:   # the slowest rank's figures: what one xGMI link of this node moved per direction, measured (DESIGN 4.3's 153 vs 76.8 GB/s question)
+                join_info["exchange"] = {k: min(e[k] for e in ex) for k in ex[0]}
         line["sharded_join"] = join_info
 
     # ---- further legs: the same join with keys outside [0, 2^32) -------------------------------
@@ -541,6 +609,8 @@ def other_configs(args):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     line = run_config(args, args.config)
     # the driver runs the default line only: it carries the other BASELINE configurations too (one GPU, < 2 s of GPU time)
     if line is not None and args.config == "C5" and args.gpus == 1 and not args.sharded and not args.rehearse and not args.rows and not args.no_others:

@@ -538,6 +538,26 @@ def test_bench_sharded_group_by_two_ranks_rehearsed():
     assert d["n_gpus"] == 2 and d["verify"]["groups_equal_index_add"] and d["scaling"] == "strong"
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher on the command line and no WORLD_SIZE: bench.py starts its two ranks itself
+    (a child torch.distributed.run), the join runs through golap_sharded_join on both (rehearsed on this one GPU) and this process
+    prints rank 0's line -- with every rank's stage timestamps and what its exchange moved."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--rows", "40000000", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line, nothing else on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verify"]["matches"] == 40_000_000 and d["verify"]["probe_id_sum_ok"]
+    sj = d["sharded_join"]
+    assert len(sj["per_rank"]) == 2 and all(len(r["bytes_sent"]) == 2 and "stage_ms" in r for r in sj["per_rank"])
+    if sj["fast_path"]:
+        assert sj["exchange"]["build_per_link_GBps"] > 0 and sj["exchange"]["probe_per_link_GBps"] > 0
+
+
 def test_join_partitioned_two_sources(ctx):
     """post-exchange path: 2 sources x 128 slots on one device must equal the plain join."""
     n = 600_000
