@@ -119,6 +119,22 @@ def pmc_traffic(kernel, rows, world):
         return None
 
 
+def step_traffic(stats, steps, rows, world):
+    """HBM bytes ONE step moved according to the committed PMC passes: sum over the step's kernels of (bytes per launch x launches per
+    step); None unless every kernel that takes more than 2 % of the step's device time has an entry for these sources and this size."""
+    kern = {k: v for k, v in stats.items() if v["launches"]}
+    tot_ms = sum(v["total_ms"] for v in kern.values()) or 1.0
+    total = 0.0
+    for k, v in kern.items():
+        t = pmc_traffic(k, rows, world)
+        if t is None:
+            if v["total_ms"] / tot_ms > 0.02:
+                return None
+            continue
+        total += t * v["launches"] / steps
+    return int(total) if total else None
+
+
 def roofline_of(stats, rows, world, direct, matches_per_launch=0):
     """the dominant kernel (by accumulated device time): algorithmic bytes per launch / mean launch duration (hipEvents on the
     launch stream, recorded inside the library)"""
@@ -329,6 +345,9 @@ def bench_join(args, n_total, label):
         "probe_rows_per_s": round(n_total / (ms_per_step * 1e-3), 1),
         "join_alg_GBps": round(join_gbps, 1),
         "join_roofline_frac": round(join_gbps / (HBM_PEAK_GBPS * world), 4),
+        # SURVEY 8(d)'s contract figure for the WHOLE operator (not one kernel): B_join = 40 (N_b + N_p) + 8 M over the step time
+        "alg_bytes": alg_join, "alg_roofline_frac": round(join_gbps / (HBM_PEAK_GBPS * world), 4),
+        "traffic_bytes_per_step": step_traffic(stats, args.steps, n_total, world) if not sharded else None,
         "roofline": roofline_of(stats, n_total, world, not sharded, m_local),
         "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in stats.items()},
         "verify": verify,
@@ -434,6 +453,10 @@ def bench_group_by(args, n, groups, label):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{label} GROUP BY int32 key SUM(float64), {n} rows, {groups} groups (dense keys), hash-aggregate with LDS pre-aggregation"},
             "agg_alg_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "agg_roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            # B_agg = N (4 + 8) + 12 G over the step time -- the contract fraction of the whole GROUP BY, whatever the
+            # implementation moves (the partition-then-aggregate path at 2^20 groups moves three times B_agg)
+            "alg_bytes": alg, "alg_roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "traffic_bytes_per_step": step_traffic(stats, args.steps, n, 1),
             "roofline": roofline_of(stats, n, 1, True), "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in stats.items()},
             "verify": verify, "device": device_block(info)}
     sample = args.cpu_sample if args.cpu_sample >= 0 else 200_000_000
@@ -555,7 +578,8 @@ def bench_filter_sum(args, n):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"C1 SELECT sum(v) FROM t WHERE k<500, {n}-row batch (k, v int64), fused predicate + sum in one pass"},
-            "alg_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "roofline": roofline_of(stats, n, 1, True),
+            "alg_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "alg_bytes": alg, "alg_roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+            "traffic_bytes_per_step": step_traffic(stats, args.steps, n, 1), "roofline": roofline_of(stats, n, 1, True),
             "kernels_ms_per_step": {kk: round(vv["total_ms"] / args.steps, 5) for kk, vv in stats.items()}, "verify": verify, "device": device_block(info)}
     sample = args.cpu_sample if args.cpu_sample >= 0 else n
     if sample:
@@ -586,24 +610,33 @@ def run_config(args, config):
 
 
 def other_configs(args):
-    """The other BASELINE configurations at their full sizes, a few steps each, GPU only (their CPU baselines are printed by
-    `--config X`): every entry is verified like its stand-alone run."""
+    """The other BASELINE configurations at their full sizes, a few steps each: every entry is verified like its stand-alone run and
+    carries the contract figure of SURVEY 8(d) for the whole operator (alg_bytes, alg_roofline_frac = alg_bytes / step time / 8 TB/s)
+    next to its dominant kernel's own roofline, the step's PMC traffic where profiles/pmc_traffic.json has its kernels, and a short
+    CPU baseline (a bounded sample, about a second each; `--config X` alone times the larger default samples)."""
     import copy
     import gc
 
     import torch
     out = {}
+    cpu_rows = {"C3": 4_000_000, "C4": 50_000_000, "C4L": 25_000_000, "C1": 1_000_000}
     for cfg in ("C3", "C4", "C4L", "C1"):
         a = copy.copy(args)
-        a.config, a.rows, a.cpu_sample, a.no_wide, a.sharded = cfg, 0, 0, True, False
+        a.config, a.rows, a.no_wide, a.sharded = cfg, 0, True, False
+        a.cpu_sample = 0 if args.cpu_sample == 0 else cpu_rows[cfg]
         a.steps, a.warmup = (50, 5) if cfg == "C1" else (5, 2)
         gc.collect()
         torch.cuda.empty_cache()
         ln = run_config(a, cfg)
         r = ln.get("roofline") or {}
         out[cfg] = {"workload": ln["config"]["workload"], "ms_per_step": ln["ms_per_step"], "value": ln["value"], "unit": ln["unit"], "steps": a.steps,
-                    "roofline": {"kernel": r.get("kernel"), "achieved": r.get("achieved"), "frac": r.get("frac"), "unit": r.get("unit")},
+                    "alg_bytes": ln["alg_bytes"], "alg_roofline_frac": ln["alg_roofline_frac"], "traffic_bytes_per_step": ln["traffic_bytes_per_step"],
+                    "roofline": {"kernel": r.get("kernel"), "achieved": r.get("achieved"), "frac": r.get("frac"), "unit": r.get("unit"),
+                                 "traffic": r.get("traffic"), "alg_bytes_per_launch": r.get("alg_bytes_per_launch")},
                     "kernels_ms_per_step": ln["kernels_ms_per_step"], "verify": ln["verify"]}
+        cb = ln.get("cpu_baseline")
+        if cb:
+            out[cfg]["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
     return out
 
 

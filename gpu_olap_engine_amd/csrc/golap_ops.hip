@@ -1488,7 +1488,11 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
     // group counts up to there are 3.5 x faster here than through the partition path.)
     bool any_mm_ = false;
     for (uint32_t i = 0; i < n_specs; ++i) any_mm_ = any_mm_ || specs[i].func == GOLAP_AGG_MIN || specs[i].func == GOLAP_AGG_MAX;
-    constexpr uint64_t LDS_TABLE_BYTES = 152 * 1024;
+    // The budget comes from the device, not from the gfx950 figure: what one work-group may ask for (sharedMemPerBlockOptin,
+    // falling back to sharedMemPerBlock) minus 8 KiB for the kernel's static LDS, capped at the 152 KiB the kernel was tuned with; a part
+    // with a smaller LDS takes fewer groups on this path and the partition path beyond, instead of failing in hipFuncSetAttribute.
+    const uint64_t lds_dev = ctx->prop.sharedMemPerBlockOptin ? ctx->prop.sharedMemPerBlockOptin : ctx->prop.sharedMemPerBlock;
+    const uint64_t LDS_TABLE_BYTES = std::min<uint64_t>(152 * 1024, lds_dev > 16 * 1024 ? lds_dev - 8 * 1024 : 0);
     const bool lds_path = grouped && (uint64_t)G * (any_mm_ ? 28 : 12) + 16 <= LDS_TABLE_BYTES;
     // beyond one LDS table: partition by slot range, then LDS-aggregate (big inputs only; GOLAP_AGG_PART=0 -> global atomics)
     const char* part_env = knob("GOLAP_AGG_PART");
@@ -1594,7 +1598,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                                  (const void*)k_group_lds<int, false, true>,       (const void*)k_group_lds<int, false, false>,
                                  (const void*)k_group_lds<long long, true, true>,  (const void*)k_group_lds<long long, true, false>,
                                  (const void*)k_group_lds<long long, false, true>, (const void*)k_group_lds<long long, false, false>};
-            for (const void* f : fns) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            for (const void* f : fns) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TABLE_BYTES));
             ctx->attr_done[2] = true;
         }
     }

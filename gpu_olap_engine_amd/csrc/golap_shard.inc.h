@@ -90,6 +90,13 @@ struct golap_comm {
     static constexpr uint32_t AGREE_UNIT = 16, AGREE_MAX_WORLD = 128, AGREE_SCRATCH = 16 + 16 * 128, AGREE_WORDS = 16 + 16 * 128 + 256;
     uint32_t* d_agree = nullptr;
     uint32_t* h_agree = nullptr;
+    // Bit 31 of the agreement word is not an error: it says "this rank runs the call in its GENERAL form" (golap_sharded_join: key columns
+    // packed first because it was handed validity arrays).  Whether a shard carries NULLs is a property of the DATA, so ranks may differ;
+    // the first agreement round of a call therefore also settles the form: agree_mode = what this rank posts, agree_seen_* = what the
+    // last round showed over ALL ranks (shard_agree_wait).
+    static constexpr uint32_t AGREE_GENERAL = 0x80000000u;
+    uint32_t agree_mode = 0;
+    bool agree_seen_general = false, agree_seen_plain = false;
     golap_sharded_join_info info{};
 };
 
@@ -439,9 +446,10 @@ static int32_t ensure_host_words(golap_comm* cm, uint64_t bytes) {
 //   shard_agree_post   h_agree[0] -> d_agree[0], all-gather of the 16-word units, ev_agree, read-back; `payload_ready` (may be null): the
 //                      communicator's stream first waits for it (the event behind the kernel that wrote d_agree[1 .. 16))
 //   shard_agree_wait   host synchronisation + verdict
+constexpr int32_t SHARD_SWITCH_TO_GENERAL = 1000;   // internal status, never returned across the ABI
 static int32_t shard_agree_post(golap_ctx* ctx, golap_comm* cm, int32_t my_err, hipEvent_t payload_ready) {
     const uint32_t P = (uint32_t)cm->world;
-    cm->h_agree[0] = (uint32_t)my_err;
+    cm->h_agree[0] = (uint32_t)my_err | cm->agree_mode;
     hipError_t e = hipSuccess;
     if (payload_ready) e = hipStreamWaitEvent(cm->stream, payload_ready, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(cm->d_agree, cm->h_agree, 4, hipMemcpyHostToDevice, cm->stream);
@@ -460,10 +468,16 @@ static int32_t shard_agree_wait(golap_ctx* ctx, golap_comm* cm, int32_t my_err, 
     if (my_err != GOLAP_OK) { ctx->err = my_msg; set_thread_error(my_msg.c_str()); return my_err; }
     if (post_status != GOLAP_OK) return post_status;
     if (e != hipSuccess) return fail(ctx, GOLAP_ERR_HIP, "agreement round failed: %s", hipGetErrorString(e));
-    for (uint32_t r = 0; r < P; ++r)
-        if (cm->h_agree[16 + golap_comm::AGREE_UNIT * r] != 0u)
+    cm->agree_seen_general = cm->agree_seen_plain = false;
+    for (uint32_t r = 0; r < P; ++r) {
+        const uint32_t w = cm->h_agree[16 + golap_comm::AGREE_UNIT * r];
+        if ((w & ~golap_comm::AGREE_GENERAL) != 0u)
             return fail(ctx, GOLAP_ERR_PEER, "golap_sharded_join: rank %u failed before the exchange (its error code %u); no rank exchanged anything", r,
-                        cm->h_agree[16 + golap_comm::AGREE_UNIT * r]);
+                        w & ~golap_comm::AGREE_GENERAL);
+        if (w & golap_comm::AGREE_GENERAL) cm->agree_seen_general = true; else cm->agree_seen_plain = true;
+    }
+    // a rank in the plain form among ranks in the general one: not an error, but it cannot go on as it is (golap_sharded_join starts over)
+    if (cm->agree_seen_general && !cm->agree_mode) return SHARD_SWITCH_TO_GENERAL;
     return GOLAP_OK;
 }
 static int32_t shard_agree(golap_ctx* ctx, golap_comm* cm, int32_t my_err) {
@@ -1181,8 +1195,10 @@ __global__ __launch_bounds__(256) void k_pack_keys(PackCols pc, unsigned long lo
 }
 
 // -> *packed_b / *packed_p: device int64 columns (slabs in `hold`) that replace the key columns; collective (one all-gather + host read)
+// `switched`: this rank came here from the plain form after its first agreement round showed general peers (that round is the
+// one the general ranks ran below); both kinds then meet in a second round, which carries the late-comers' prepare() outcome.
 static int32_t shard_pack_keys(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, hipStream_t st, SlabHold& hold, uint64_t* packed_b,
-                               uint64_t* packed_p) {
+                               uint64_t* packed_p, bool switched) {
     const uint32_t P = (uint32_t)cm->world, K = std::max<uint32_t>(1, p->n_key_cols);
     const uint64_t n[2] = {p->n_build_local, p->n_probe_local};
     uint64_t cols[2][4], valids[2][4];
@@ -1206,7 +1222,12 @@ static int32_t shard_pack_keys(golap_ctx* ctx, golap_comm* cm, const golap_shard
         GOLAP_TRY(ensure_host_words(cm, (uint64_t)P * 64 + 64));
         return GOLAP_OK;
     };
-    GOLAP_TRY(shard_agree(ctx, cm, prepare()));
+    if (switched) {
+        GOLAP_TRY(shard_agree(ctx, cm, prepare()));
+    } else {
+        GOLAP_TRY(shard_agree(ctx, cm, prepare()));
+        if (cm->agree_seen_plain) GOLAP_TRY(shard_agree(ctx, cm, GOLAP_OK));   // (every rank saw the same words: all take this round or none)
+    }
     // value range of every key column over BOTH sides of this rank, then over all ranks
     long long init[8];
     for (uint32_t c = 0; c < 4; ++c) { init[2 * c] = INT64_MAX; init[2 * c + 1] = INT64_MIN; }
@@ -1260,31 +1281,16 @@ static int32_t shard_pack_keys(golap_ctx* ctx, golap_comm* cm, const golap_shard
 
 }  // namespace golap
 
-extern "C" {
+namespace golap {
 
-int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p_in, void* stream) {
-    if (!ctx || !cm || !p_in) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
-    if (cm->ctx != ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "communicator belongs to another context");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    KnobScope knobs_(ctx);
-    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = pick_stream(ctx, stream);
-    memset(&cm->info, 0, sizeof cm->info);
-    // composite keys / NULLs: the key columns are replaced by ONE exact int64 column per side first (every rank takes this branch
-    // or none: n_key_cols and the presence of validity arrays are part of the query, not of the data)
-    golap_sharded_join_params p_local = *p_in;
-    const golap_sharded_join_params* p = &p_local;
-    SlabHold packed_hold(ctx);
-    struct PackedSync {   // the packed columns are read by kernels of this call: they go back to the pool only when the stream is done
-        hipStream_t st; bool on = false;
-        ~PackedSync() { if (on) (void)hipStreamSynchronize(st); }
-    } packed_sync{st};
-    bool general = p_in->n_key_cols > 1;
-    for (int c = 0; c < 4; ++c) general = general || p_in->build_validity[c] || p_in->probe_validity[c];
+static int32_t sharded_join_run(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p_in, golap_sharded_join_params* p_local_, hipStream_t st,
+                                bool general, bool switched, SlabHold& packed_hold, bool& packed_on) {
+    golap_sharded_join_params& p_local = *p_local_;
+    const golap_sharded_join_params* p = p_local_;
     if (general) {
         uint64_t pb = 0, pp = 0;
-        packed_sync.on = true;
-        GOLAP_TRY(shard_pack_keys(ctx, cm, p_in, st, packed_hold, &pb, &pp));
+        packed_on = true;
+        GOLAP_TRY(shard_pack_keys(ctx, cm, p_in, st, packed_hold, &pb, &pp, switched));
         p_local.build_key_ptr = pb;
         p_local.probe_key_ptr = pp;
         p_local.n_key_cols = 1;
@@ -1326,6 +1332,38 @@ int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* cm, const golap_sharded_j
         GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
     }
     return sharded_join_exact(ctx, cm, p, sp, st, arg_err);
+}
+
+}  // namespace golap
+
+extern "C" {
+
+int32_t golap_sharded_join(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p_in, void* stream) {
+    if (!ctx || !cm || !p_in) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (cm->ctx != ctx) return fail(ctx, GOLAP_ERR_INVALID_ARG, "communicator belongs to another context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    KnobScope knobs_(ctx);
+    GOLAP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick_stream(ctx, stream);
+    memset(&cm->info, 0, sizeof cm->info);
+    // composite keys / NULLs: the key columns are replaced by ONE exact int64 column per side first (sharded_join_run's general form)
+    golap_sharded_join_params p_local = *p_in;
+    SlabHold packed_hold(ctx);
+    struct PackedSync {   // the packed columns are read by kernels of this call: they go back to the pool only when the stream is done
+        hipStream_t st; bool on = false;
+        ~PackedSync() { if (on) (void)hipStreamSynchronize(st); }
+    } packed_sync{st};
+    bool general = p_in->n_key_cols > 1;
+    for (int c = 0; c < 4; ++c) general = general || p_in->build_validity[c] || p_in->probe_validity[c];
+    // n_key_cols is part of the query, but whether a shard comes with validity arrays depends on its DATA (a shard without NULLs is
+    // handed none; the Arrow import drops them when null_count is 0): the form is settled in the call's first agreement round --
+    // a plain rank that finds a general peer there (SHARD_SWITCH_TO_GENERAL) abandons what it had enqueued and starts over below.
+    cm->agree_mode = general ? golap_comm::AGREE_GENERAL : 0u;
+    struct ModeReset { golap_comm* cm; ~ModeReset() { cm->agree_mode = 0; } } mode_reset{cm};
+    const int32_t run = sharded_join_run(ctx, cm, p_in, &p_local, st, general, false, packed_hold, packed_sync.on);
+    if (run != SHARD_SWITCH_TO_GENERAL) return run;
+    cm->agree_mode = golap_comm::AGREE_GENERAL;
+    return sharded_join_run(ctx, cm, p_in, &p_local, st, true, true, packed_hold, packed_sync.on);
 }
 
 }  // extern "C"

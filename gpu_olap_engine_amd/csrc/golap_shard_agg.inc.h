@@ -130,10 +130,13 @@ extern "C" int32_t golap_sharded_aggregate(golap_ctx* ctx, golap_comm* cm, const
     q.out_ptr = t_local;
     q.out_count_ptr = 0;
     if (hashed) { q.out_keys_ptr = k_local; q.out_n_groups_ptr = d_n; }
-    GOLAP_TRY(golap_aggregate(ctx, derived.data(), d.n_planes, &q, st));
+    // (its argument checks and scratch allocations can fail on ONE rank -- a larger shard running out of memory, a null pointer of
+    // this rank only: the outcome is agreed on before the next collective, like prepare()'s)
+    int32_t local_err = golap_aggregate(ctx, derived.data(), d.n_planes, &q, st);
     const uint32_t fold_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->prop.multiProcessorCount * 8, ceil_div(G, 256)));
     if (!hashed) {
         // ---- all-gather the tables (in messages of at most max_msg bytes), fold in rank order ----
+        GOLAP_TRY(shard_agree(ctx, cm, local_err));   // (on the communicator's stream: the host waits beside the local aggregate's kernels, not behind them)
         const uint64_t E = (uint64_t)d.n_planes * G, chunk = std::max<uint64_t>(1, std::min<uint64_t>(E, shard_max_msg(cm, 0) / 8));
         GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_misc, st));
         GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_misc, 0));
@@ -152,18 +155,22 @@ extern "C" int32_t golap_sharded_aggregate(golap_ctx* ctx, golap_comm* cm, const
     }
     // ---- hashed keys: partition the partial groups by owner, exchange, merge ----
     uint32_t nl = 0;
-    GOLAP_HIP_TRY(ctx, hipMemcpyAsync(cm->h_status, (const void*)d_n, 4, hipMemcpyDeviceToHost, st));
-    GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
-    nl = cm->h_status[0];
-    int32_t local_err = GOLAP_OK;
-    if (nl > G) local_err = fail(ctx, GOLAP_ERR_CAPACITY, "golap_sharded_aggregate: %u distinct local keys exceed the bound n_groups = %llu", nl, (unsigned long long)G);
+    if (local_err == GOLAP_OK) {
+        GOLAP_HIP_TRY(ctx, hipMemcpyAsync(cm->h_status, (const void*)d_n, 4, hipMemcpyDeviceToHost, st));
+        GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
+        nl = cm->h_status[0];
+    }
+    if (local_err == GOLAP_OK && nl > G) local_err = fail(ctx, GOLAP_ERR_CAPACITY, "golap_sharded_aggregate: %u distinct local keys exceed the bound n_groups = %llu", nl, (unsigned long long)G);
     const uint64_t nl1 = std::max<uint32_t>(nl, 1);
-    const uint64_t pk = hold.take(nl1 * 8), pr = hold.take(nl1 * 4), offs = hold.take(257 * 4), cnt_all = hold.take((uint64_t)P * P * 4 + 256);
+    const uint64_t pk = hold.take(nl1 * 8), pr = hold.take(nl1 * 4), offs = hold.take(257 * 4), cnt_all = hold.take((uint64_t)P * (P + 1) * 4 + 512);
     uint64_t planes_sorted = hold.take((uint64_t)d.n_planes * nl1 * 8);
     if (local_err == GOLAP_OK && (!pk || !pr || !offs || !cnt_all || !planes_sorted)) local_err = fail(ctx, GOLAP_ERR_OOM, "sharded aggregate: partition buffers");
     GOLAP_TRY(shard_agree(ctx, cm, local_err));
     uint32_t send_cnt[64] = {0}, send_off[65] = {0};
-    if (nl) {
+    // partition + gather run only on ranks that hold partial groups and have argument checks and scratch of their own: what
+    // they return rides as word P of this rank's unit in the counts all-gather below -- every rank takes part in it whatever
+    // happened here, and every rank learns of a failure from the same read-back
+    auto partition_local = [&]() -> int32_t {
         golap_partition_params pp;
         memset(&pp, 0, sizeof pp);
         pp.key_ptr = k_local;
@@ -179,16 +186,31 @@ extern "C" int32_t golap_sharded_aggregate(golap_ctx* ctx, golap_comm* cm, const
         GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
         const uint32_t per = 256 / P;
         for (uint32_t r = 0; r < P; ++r) { send_off[r] = cm->h_status[r * per]; send_cnt[r] = cm->h_status[(r + 1) * per] - cm->h_status[r * per]; }
-    } else {
-        GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
-    }
-    // sizes: every rank's per-owner counts, all-gathered and read back
+        return GOLAP_OK;
+    };
+    int32_t part_err = GOLAP_OK;
+    if (nl) part_err = partition_local();
+    else GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
+    const std::string part_msg = part_err != GOLAP_OK ? ctx->err : std::string();
+    if (part_err != GOLAP_OK) for (uint32_t r = 0; r < P; ++r) send_cnt[r] = 0;
+    // sizes: every rank's per-owner counts (+ its status word), all-gathered and read back
+    const uint32_t U = P + 1;
     for (uint32_t r = 0; r < P; ++r) cm->h_agree[golap_comm::AGREE_SCRATCH + r] = send_cnt[r];
-    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)cnt_all, cm->h_agree + golap_comm::AGREE_SCRATCH, (size_t)P * 4, hipMemcpyHostToDevice, cm->stream));
-    GOLAP_TRY(comm_all_gather(cm, cnt_all, cnt_all + 256, (uint64_t)P * 4, cm->stream));
-    uint32_t* h_cnt = cm->h_status + 512;
-    GOLAP_HIP_TRY(ctx, hipMemcpyAsync(h_cnt, (const void*)(cnt_all + 256), (size_t)P * P * 4, hipMemcpyDeviceToHost, cm->stream));
+    cm->h_agree[golap_comm::AGREE_SCRATCH + P] = (uint32_t)part_err;
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)cnt_all, cm->h_agree + golap_comm::AGREE_SCRATCH, (size_t)U * 4, hipMemcpyHostToDevice, cm->stream));
+    GOLAP_TRY(comm_all_gather(cm, cnt_all, cnt_all + 512, (uint64_t)U * 4, cm->stream));
+    uint32_t* h_all = cm->h_status + 512;
+    GOLAP_HIP_TRY(ctx, hipMemcpyAsync(h_all, (const void*)(cnt_all + 512), (size_t)P * U * 4, hipMemcpyDeviceToHost, cm->stream));
     GOLAP_HIP_TRY(ctx, hipStreamSynchronize(cm->stream));
+    if (part_err != GOLAP_OK) { ctx->err = part_msg; set_thread_error(part_msg.c_str()); return part_err; }
+    for (uint32_t r = 0; r < P; ++r)
+        if (h_all[r * U + P] != 0u)
+            return fail(ctx, GOLAP_ERR_PEER, "golap_sharded_aggregate: rank %u failed before the exchange (its error code %u); no rank exchanged anything", r,
+                        h_all[r * U + P]);
+    std::vector<uint32_t> h_cnt_v((size_t)P * P);
+    for (uint32_t r = 0; r < P; ++r)
+        for (uint32_t c = 0; c < P; ++c) h_cnt_v[(size_t)r * P + c] = h_all[r * U + c];
+    const uint32_t* h_cnt = h_cnt_v.data();
     uint64_t nr = 0, recv_off[65] = {0};
     for (uint32_t r = 0; r < P; ++r) { recv_off[r] = nr; nr += h_cnt[r * P + me]; }
     recv_off[P] = nr;

@@ -557,16 +557,22 @@ def test_sharded_aggregate_ranks_share_one_gpu(world, groups, hashed):
             assert np.array_equal(r[2], full) and np.array_equal(r[3].astype(np.float64), full[1])
 
 
-def _composite_rows(n):
+def _composite_rows(n, clean=None, cols=2):
+    """clean = (lo, hi): rows [lo, hi) of every column are valid -- the shard of a rank that is handed NO validity arrays"""
     rng = np.random.default_rng(n + 3)
     mk = lambda: (rng.integers(-40, 40, n).astype(np.int64), rng.integers(1000, 1030, n).astype(np.int64))
     (b0, b1), (p0, p1) = mk(), mk()
     bv = [(rng.random(n) > 0.05).astype(np.uint8), None]
     pv = [(rng.random(n) > 0.05).astype(np.uint8), (rng.random(n) > 0.05).astype(np.uint8)]
+    if clean:
+        for v in (bv[0], pv[0], pv[1]):
+            v[clean[0]:clean[1]] = 1
+    if cols == 1:    # one key column with a few hundred distinct values (both sides), NULLs on both
+        return [b0 * 7 + b1], [p0 * 7 + p1], bv[:1], pv[:1]
     return [b0, b1], [p0, p1], bv, pv
 
 
-def _worker_composite(rank, world, port, n, jt, q):
+def _worker_composite(rank, world, port, n, jt, q, plain_rank=-1, cols=2, mode=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -577,12 +583,17 @@ def _worker_composite(rank, world, port, n, jt, q):
         torch.cuda.set_device(0)
         c = Context(max_gpu_memory=0)
         lo, hi = shard_range(n, rank, world)
-        bc, pc, bv, pv = _composite_rows(n)
+        bc, pc, bv, pv = _composite_rows(n, shard_range(n, plain_rank, world) if plain_rank >= 0 else None, cols)
         cu = lambda a: None if a is None else torch.from_numpy(a[lo:hi]).cuda()
+        if mode == "fast":
+            c.debug_set("GOLAP_SHARD_FAST", "1")
+            c.debug_set("GOLAP_LOCAL_BITS", "6")
         sj = NativeShardedJoin(c, transport="staged")
         out = torch.empty((60 * n + 16, 2), dtype=torch.int32, device="cuda")
+        no_nulls_here = rank == plain_rank     # this rank's shard has no NULLs and it is handed no validity arrays at all
         pairs, cnt, info = sj.join([cu(x) for x in bc], [cu(x) for x in pc], lo, lo, n, out_pairs=out, join_type=jt,
-                                   build_valid=[cu(x) for x in bv], probe_valid=[cu(x) for x in pv])
+                                   build_valid=None if no_nulls_here else [cu(x) for x in bv], probe_valid=None if no_nulls_here else [cu(x) for x in pv],
+                                   force_exact=(mode == "exact"))
         torch.cuda.synchronize()
         m = int(cnt.item())
         q.put((rank, pairs[:m].cpu().numpy().view(np.uint32).copy()))
@@ -613,6 +624,33 @@ def test_sharded_join_composite_and_null_keys(world, jt):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     bc, pc, bv, pv = _composite_rows(n)
+    exp, me = oracle.hash_join_multi(bc, pc, jt, bv, pv)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("world,jt,cols,plain_rank,mode", [(2, 0, 2, 1, None), (2, 3, 1, 0, "exact"), (4, 1, 1, 2, "fast"), (2, 0, 1, 1, "fast")])
+def test_sharded_join_ranks_disagree_about_validity_arrays(world, jt, cols, plain_rank, mode):
+    """Whether a shard comes with validity arrays depends on its data: ONE rank whose shard has no NULLs passes none (what the Arrow
+    import hands over when null_count is 0) while its peers pass theirs.  With one key column that rank would take the plain path
+    and its peers the packed-key path -- collectives that do not match.  The call's first agreement round settles the form: the
+    plain rank starts over in the general one, every rank returns, and the result is the oracle's NULL-aware join of the whole tables."""
+    import oracle
+    import torch.multiprocessing as mp
+    from gpu_olap_engine_amd.engine import shard_range
+    from np_twin import canonical
+    n = 40_000
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_composite, args=(r, world, port, n, jt, q, plain_rank, cols, mode)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    bc, pc, bv, pv = _composite_rows(n, shard_range(n, plain_rank, world), cols)
     exp, me = oracle.hash_join_multi(bc, pc, jt, bv, pv)
     got = canonical(np.concatenate([r[1] for r in res]))
     assert got.shape[0] == me and np.array_equal(got, exp)
