@@ -7,7 +7,7 @@
 
 use std::os::raw::{c_char, c_void};
 
-pub const GOLAP_ABI_VERSION: u32 = 3;
+pub const GOLAP_ABI_VERSION: u32 = 4;
 pub const GOLAP_OK: i32 = 0;
 pub const GOLAP_ERR_INVALID_ARG: i32 = 1;
 pub const GOLAP_ERR_NO_DEVICE: i32 = 2;

@@ -46,7 +46,8 @@ class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("gcn_arch", C.c_char * 64), ("compute_units", C.c_uint32),
                 ("lds_bytes_per_block", C.c_uint32), ("wavefront_size", C.c_uint32), ("clock_mhz", C.c_uint32),
                 ("memory_clock_mhz", C.c_uint32), ("memory_bus_bits", C.c_uint32), ("total_mem_bytes", C.c_uint64),
-                ("free_mem_bytes", C.c_uint64), ("l2_bytes", C.c_uint32)]
+                ("free_mem_bytes", C.c_uint64), ("l2_bytes", C.c_uint32), ("hidden_memory_forms", C.c_uint32), ("built_with", C.c_char * 32),
+                ("audited_with", C.c_char * 32)]
 
 
 class SlabStats(C.Structure):

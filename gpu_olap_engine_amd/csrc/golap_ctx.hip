@@ -485,6 +485,12 @@ int32_t golap_device_info_get(golap_ctx* ctx, golap_device_info* out) {
     GOLAP_HIP_TRY(ctx, hipMemGetInfo(&fr, &tot));
     out->total_mem_bytes = tot;
     out->free_mem_bytes = fr;
+    {
+        KnobScope knobs_(ctx);
+        out->hidden_memory_forms = kernel_forms_now().hidden ? 1u : 0u;
+    }
+    snprintf(out->built_with, sizeof out->built_with, "hip %d.%d.%d", (int)GOLAP_BUILD_HIP_MAJOR, (int)GOLAP_BUILD_HIP_MINOR, (int)GOLAP_BUILD_HIP_PATCH);
+    snprintf(out->audited_with, sizeof out->audited_with, "hip %d.%d.%d", GOLAP_HIDDEN_AUDITED_HIP_MAJOR, GOLAP_HIDDEN_AUDITED_HIP_MINOR, GOLAP_HIDDEN_AUDITED_HIP_PATCH);
     return GOLAP_OK;
 }
 

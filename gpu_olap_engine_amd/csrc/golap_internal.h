@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/golap.h"
+#include "golap_variants.h"
 
 namespace golap {
 
@@ -138,6 +139,8 @@ struct Knobs {
 extern thread_local const Knobs* g_knobs;
 extern thread_local const golap_engine_config* g_scope_cfg;
 inline const char* knob(const char* name) { return g_knobs ? g_knobs->get(name) : nullptr; }
+// hidden-memory or plain kernel forms by default: by the compiler that built the library (golap_variants.h), unless GOLAP_HIDDEN_FORMS says otherwise
+inline KernelForms kernel_forms_now() { return default_kernel_forms(knob("GOLAP_HIDDEN_FORMS")); }
 
 // Workspace: one slab, bump-allocated per call, cached in the context.
 struct Workspace {

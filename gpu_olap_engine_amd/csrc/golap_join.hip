@@ -1610,7 +1610,7 @@ static bool use_reserve_first_pass(const JoinPlan& plan, uint64_t n_rows, bool h
 static uint32_t part1_narrow_tile();
 // the 64-bit pipeline's reserving first pass: k_part1_narrow<.., WIDE> (12288-row tiles) when the column is 16-byte aligned, else
 // round 1's k_scatter_big.  GOLAP_P1W=0: the old kernel (A/B hook), 2: the new one with compiler-visible loads and stores.
-static int p1w_variant() { const char* e = knob("GOLAP_P1W"); return e ? atoi(e) : 1; }
+static int p1w_variant() { const char* e = knob("GOLAP_P1W"); return e ? atoi(e) : kernel_forms_now().p1w; }
 static uint32_t wide_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) {
     return p1w_variant() != 0 ? first_pass_chunks(n_rows, chunk_rows_out, 12288, 4) : first_pass_chunks(n_rows, chunk_rows_out);
 }
@@ -2170,8 +2170,9 @@ __global__ __launch_bounds__(1024) void k_key_dict(const long long* __restrict__
 }
 
 // A/B hooks for the round-2 narrow kernels (scripts/ab_env.py): GOLAP_P1N = 0 (k_scatter_big) | 24 | 18 | 16, GOLAP_P2R = 0 (k_scatter_wc) | 4 | 2
-static int p1n_variant() { const char* e = knob("GOLAP_P1N"); return e ? atoi(e) : 118; }
-static int p2r_variant() { const char* e = knob("GOLAP_P2R"); return e ? atoi(e) : 104; }
+// The defaults -- hidden-memory forms (118 / 104) or plain ones (18 / 4) -- follow the compiler that built the library: golap_variants.h.
+static int p1n_variant() { const char* e = knob("GOLAP_P1N"); return e ? atoi(e) : kernel_forms_now().p1n; }
+static int p2r_variant() { const char* e = knob("GOLAP_P2R"); return e ? atoi(e) : kernel_forms_now().p2r; }
 
 // rows per tile of the first-pass kernel launch_part1_narrow will choose (chunks are cut in whole tiles of it)
 static uint32_t part1_narrow_tile() {

@@ -1663,7 +1663,7 @@ static int32_t aggregate_dense(golap_ctx* ctx, const golap_aggregate_spec* specs
                     if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
                     ctx->prof.cur_gate_host = cs == hipStreamCaptureStatusNone ? ctx->prof.take_gate_slot() : nullptr;
                 }
-                const bool plain = rsv_env && !strcmp(rsv_env, "plain");
+                const bool plain = rsv_env ? !strcmp(rsv_env, "plain") : !kernel_forms_now().agg_rsv_hidden;   // (golap_variants.h)
                 const uint32_t runs = (uint32_t)std::min<uint64_t>(65536, p->n_rows / 16);
                 const uint64_t stride = p->n_rows / runs;
                 KernelTimer t(ctx, "agg_partition_scatter", st, 0, (key_bytes + 8 + 12) * p->n_rows, false);

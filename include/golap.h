@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GOLAP_ABI_VERSION 3
+#define GOLAP_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -87,6 +87,12 @@ typedef struct golap_device_info {
     uint64_t total_mem_bytes;
     uint64_t free_mem_bytes;
     uint32_t l2_bytes;
+    /* ABI 4: which form of the four hand-scheduled kernels this library launches by default.  The forms with hidden (inline-asm) memory
+     * operations and counted waits were audited -- statically on the generated code and on a GPU against the plain forms -- for ONE
+     * hipcc (audited_with); a library built by any other hipcc (built_with) launches the plain forms: hidden_memory_forms = 0. */
+    uint32_t hidden_memory_forms;
+    char     built_with[32];     /* "hip 7.2.26015" */
+    char     audited_with[32];
 } golap_device_info;
 int32_t golap_device_info_get(golap_ctx* ctx, golap_device_info* out);
 int32_t golap_ctx_synchronize(golap_ctx* ctx, void* stream);

@@ -66,7 +66,7 @@ def test_struct_layouts_match_ctypes(tmp_path, lib):
 
 def test_host_only_entry_points(lib):
     from gpu_olap_engine_amd import _native as N
-    assert lib.golap_abi_version() == 3      # (3: sharded join ships row chunks, agreement round, stage timestamps in the info struct; GOLAP_ERR_PEER)
+    assert lib.golap_abi_version() == 4      # (4: golap_device_info says which kernel forms run and what built the library; device-side ingest entry points)
     assert lib.golap_choose_strategy(500_000) == N.JOIN_BROADCAST_HASH and lib.golap_choose_strategy(5_000_000) == N.JOIN_RADIX_HASH   # join_kernel.rs:85-87
     g, b = C.c_uint32(), C.c_uint32()
     lib.golap_compute_launch_params(1024, C.byref(g), C.byref(b))

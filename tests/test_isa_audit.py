@@ -31,7 +31,10 @@ ASM_FORMS = re.compile(r"^_ZN5golap\d+(k_part1_narrowILi\d+ELi\d+ELb[01]ELb1E(?:
 # The audit reads ONE compiler's output: the hand-counted waits and the fixed-register scheme were validated (on the GPU, row by row:
 # tests/test_join_gpu.py::test_hidden_forms_match_plain_forms) with exactly this hipcc.  A different compiler must be re-validated
 # there before this constant is changed.
-VALIDATED_HIPCC = "7.2.26015"
+# the compiler the hidden forms were audited with: csrc/golap_variants.h is the one place that names it (a library built by any other
+# compiler launches the plain forms by itself, tests/test_variants_cpu.py)
+VALIDATED_HIPCC = ".".join(re.search(r"#define GOLAP_HIDDEN_AUDITED_HIP_" + k + r" (\d+)", open(os.path.join(CSRC, "golap_variants.h")).read()).group(1)
+                           for k in ("MAJOR", "MINOR", "PATCH"))
 
 
 def _compile(tmp_path_factory, extra=()):

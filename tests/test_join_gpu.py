@@ -848,6 +848,48 @@ def test_hidden_forms_match_plain_forms(ctx, bits, ring):
                                              f"first {bad[:8].tolist()} -> {got[bad[:8]].tolist()}")
 
 
+def test_a_build_by_an_unaudited_compiler_runs_the_plain_forms(ctx):
+    """GOLAP_HIDDEN_FORMS=0 flips the one switch a compiler mismatch flips (csrc/golap_variants.h: a library built by a hipcc other
+    than the audited one): golap_device_info says so, every one of the four hand-scheduled kernels takes its plain form -- tuple
+    pipeline, 64-bit-row pipeline, dictionary columns (which then take the 64-bit rows: the dictionary forms exist hidden only) and
+    the GROUP BY scatter -- and every result is still exact."""
+    info = ctx.device_info()
+    assert info["hidden_memory_forms"] == 1 and info["built_with"] == info["audited_with"] and info["built_with"].startswith("hip ")
+    n = 24_000_011
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    inv = torch.empty(n, dtype=torch.int64, device="cuda")
+    inv[bt] = torch.arange(n, dtype=torch.int64, device="cuda")
+    exp = inv[pt]
+    del inv
+    with ctx.knobs(GOLAP_HIDDEN_FORMS="0"):
+        assert ctx.device_info()["hidden_memory_forms"] == 0
+        for shape in ("narrow", "two_upper_halves", "many_upper_halves"):
+            b, p = bt.clone(), pt.clone()
+            if shape == "two_upper_halves":
+                b += (b & 1) << 40
+                p += (p & 1) << 40
+            if shape == "many_upper_halves":
+                b += ((b * 0x9E3779B1) & 0xFF) << 44
+                p += ((p * 0x9E3779B1) & 0xFF) << 44
+            ctx.stats_reset()
+            m, got = _pairs_by_probe(ctx, b, p, n)
+            st = ctx.stats()
+            bad = torch.nonzero(got != exp).flatten()
+            assert m == n and bad.numel() == 0, f"{shape}: {m} pairs, {bad.numel()} probe rows without exactly their partner"
+            tuple_ms, wide_ms = st["join_build_probe_lds"]["total_ms"], st["join_build_probe_lds_wide"]["total_ms"]
+            assert (tuple_ms > wide_ms) == (shape == "narrow"), (shape, tuple_ms, wide_ms)
+        # the GROUP BY partition scatter: 2^20 groups over 40M rows (k_agg_scatter_rsv's plain form), against torch
+        g, nr = 1 << 20, 40_000_000
+        keys = ctx.generate(N.GEN_SM64_MOD_I32, nr, modulus=g, seed=7)
+        vals = ctx.generate(N.GEN_SM64_MOD_F64, nr, modulus=1024, seed=8)
+        out = ctx.aggregate([(N.AGG_SUM, 0)], [vals], group_keys=keys, n_groups=g)
+        ref = torch.zeros(g, dtype=torch.float64, device="cuda")
+        ref.index_add_(0, keys.to(torch.int64), vals)
+        assert torch.equal(out[0], ref)
+    assert ctx.device_info()["hidden_memory_forms"] == 1
+
+
 @pytest.mark.parametrize("sigmas", [8, 12, 40])
 def test_large_provision_sigmas_size_the_buffers_too(sigmas):
     """golap_engine_config.provision_sigmas widens the slots of the no-histogram layouts; the buffers behind them must grow with it
