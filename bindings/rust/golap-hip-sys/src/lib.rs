@@ -1,4 +1,4 @@
-//! Raw FFI of `include/golap.h` (ABI version 3), one declaration per C declaration, same names and field order.
+//! Raw FFI of `include/golap.h` (ABI version 4), one declaration per C declaration, same names and field order.
 //!
 //! NOT COMPILED in the authoring environment (no Rust toolchain): layout-checked only.  `tests/test_rust_binding.py` parses this
 //! file and the header and compares EVERY `#[repr(C)]` struct field by field and every bound function's arity; the `unsafe`
@@ -237,6 +237,21 @@ pub struct golap_join_partitioned_plan {
     pub reserved0: u32,
 }
 
+/// Composite GROUP BY key as one exact int64 (golap_pack_group_keys, ABI 4).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct golap_pack_keys_params {
+    pub col_ptrs: [u64; 4],
+    pub validity_ptrs: [u64; 4],
+    pub min_value: [i64; 4],
+    pub weight: [u64; 4],
+    pub null_digit: [u64; 4],
+    pub n_cols: u32,
+    pub reserved0: u32,
+    pub n_rows: u64,
+    pub out_ptr: u64,
+}
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
 pub struct golap_join_plan {
@@ -292,6 +307,16 @@ extern "C" {
     // ---- arrow-interop widening (record_batch_convert.rs:35-110) ----
     pub fn golap_widen_to_8byte(ctx: *mut golap_ctx, in_ptr: u64, in_dtype: i32, validity_ptr: u64, n_rows: u64, out_ptr: u64, stream: *mut c_void) -> i32;
     pub fn golap_hash_utf8(ctx: *mut golap_ctx, offsets_ptr: u64, data_ptr: u64, validity_ptr: u64, n_rows: u64, out_ptr: u64, stream: *mut c_void) -> i32;
+    // ---- device-side ingest and materialisation (ABI 4; record_batch_convert.rs:35-110, :146-178 on the device) ----
+    pub fn golap_expand_validity(ctx: *mut golap_ctx, bitmap_ptr: u64, bit_offset: u64, n_rows: u64, out_ptr: u64, stream: *mut c_void) -> i32;
+    pub fn golap_pack_validity(ctx: *mut golap_ctx, validity_ptr: u64, n_rows: u64, out_bitmap_ptr: u64, out_null_count_ptr: u64, stream: *mut c_void) -> i32;
+    pub fn golap_take_1byte(ctx: *mut golap_ctx, src_ptr: u64, indices_ptr: u64, count_ptr: u64, n_indices_max: u64, out_ptr: u64, stream: *mut c_void) -> i32;
+    pub fn golap_pairs_unzip(ctx: *mut golap_ctx, pairs_ptr: u64, n_pairs: u64, out_build_idx_ptr: u64, out_probe_idx_ptr: u64, stream: *mut c_void) -> i32;
+    pub fn golap_sort_u64(ctx: *mut golap_ctx, ptr: u64, n: u64, stream: *mut c_void) -> i32;
+    pub fn golap_key_minmax(ctx: *mut golap_ctx, column_ptr: u64, validity_ptr: u64, n_rows: u64, out_ptr: u64, stream: *mut c_void) -> i32;
+    pub fn golap_pack_group_keys(ctx: *mut golap_ctx, params: *const golap_pack_keys_params, stream: *mut c_void) -> i32;
+    pub fn golap_device_copy(ctx: *mut golap_ctx, src_ptr: u64, dst_ptr: u64, bytes: u64, stream: *mut c_void) -> i32;
+    pub fn golap_device_fill_u8(ctx: *mut golap_ctx, ptr: u64, value: u32, bytes: u64, stream: *mut c_void) -> i32;
     // ---- multi-GPU (no counterpart in the reference, README.md:414) ----
     pub fn golap_comm_unique_id(out_id: *mut u8) -> i32;
     pub fn golap_comm_create_rccl(ctx: *mut golap_ctx, id: *const u8, world: i32, rank: i32, out: *mut *mut golap_comm) -> i32;

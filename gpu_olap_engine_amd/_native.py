@@ -23,7 +23,7 @@ KEYS_DENSE, KEYS_HASHED = 0, 1
 (WIDEN_I8, WIDEN_I16, WIDEN_I32, WIDEN_I64, WIDEN_U8, WIDEN_U16, WIDEN_U32, WIDEN_U64, WIDEN_F32, WIDEN_F64) = range(10)
 GEN_BUILD_KEYS, GEN_SM64_MOD_I64, GEN_SM64_MOD_I32, GEN_SM64_MOD_F64, GEN_SHIFT32_I64 = range(5)
 HOST_TO_DEVICE, DEVICE_TO_HOST = 0, 1
-MAX_KERNEL_STATS = 48
+MAX_KERNEL_STATS = 64
 PROVISION_NONE = 0xFFFFFFFF
 
 
@@ -165,6 +165,11 @@ class JoinPlan(C.Structure):
                 ("optimistic_narrow_keys", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
+class PackKeysParams(C.Structure):
+    _fields_ = [("col_ptrs", C.c_uint64 * 4), ("validity_ptrs", C.c_uint64 * 4), ("min_value", C.c_int64 * 4), ("weight", C.c_uint64 * 4),
+                ("null_digit", C.c_uint64 * 4), ("n_cols", C.c_uint32), ("reserved0", C.c_uint32), ("n_rows", C.c_uint64), ("out_ptr", C.c_uint64)]
+
+
 # every symbol include/golap.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 _VP = C.c_void_p
@@ -215,6 +220,15 @@ SIGNATURES = {
     "golap_sharded_aggregate": (C.c_int32, [_VP, _VP, _P(AggregateSpec), C.c_uint32, _P(AggregateParams), _VP]),
     "golap_widen_to_8byte": (C.c_int32, [_VP, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_hash_utf8": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_expand_validity": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_pack_validity": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_take_1byte": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_pairs_unzip": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_sort_u64": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, _VP]),
+    "golap_key_minmax": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_pack_group_keys": (C.c_int32, [_VP, _P(PackKeysParams), _VP]),
+    "golap_device_copy": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
+    "golap_device_fill_u8": (C.c_int32, [_VP, C.c_uint64, C.c_uint32, C.c_uint64, _VP]),
     "golap_generate": (C.c_int32, [_VP, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_verify_pairs": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _VP]),
     "golap_stats_get": (C.c_int32, [_VP, _P(Stats)]),

@@ -418,6 +418,70 @@ class Context:
         self._ck(self._lib.golap_hash_utf8(self._h, _ptr(offsets), _ptr(data), _ptr(valid), max(n, 0), _ptr(out), _stream()))
         return out
 
+    # ---- device-side ingest / materialisation (ABI 4) ---------------------------------
+    def expand_validity(self, bitmap, n_rows, bit_offset=0):
+        """golap_expand_validity: Arrow validity bitmap (uint8 tensor, LSB first, first row at bit `bit_offset`) -> uint8[n_rows], 1 = valid"""
+        _chk_tensor(bitmap, torch.uint8, "bitmap")
+        out = torch.empty(n_rows, dtype=torch.uint8, device=bitmap.device)
+        self._ck(self._lib.golap_expand_validity(self._h, _ptr(bitmap), bit_offset, n_rows, _ptr(out), _stream()))
+        return out
+
+    def pack_validity(self, valid):
+        """golap_pack_validity: uint8[n] (0 = NULL) -> (Arrow bitmap uint8[ceil(n / 8)], NULL count as int64[1] on the device)"""
+        _chk_tensor(valid, torch.uint8, "valid")
+        n = valid.numel()
+        out = torch.empty((n + 7) // 8, dtype=torch.uint8, device=valid.device)
+        nulls = torch.empty(1, dtype=torch.int64, device=valid.device)
+        self._ck(self._lib.golap_pack_validity(self._h, _ptr(valid), n, _ptr(out), _ptr(nulls), _stream()))
+        return out, nulls
+
+    def take_validity(self, src_valid, indices, count=None, n_max=None):
+        """golap_take_1byte: validity of gathered rows (src_valid None = the source has no NULLs; index 0xFFFFFFFF -> 0)"""
+        n_max = indices.numel() if n_max is None else n_max
+        out = torch.zeros(n_max, dtype=torch.uint8, device=indices.device)
+        self._ck(self._lib.golap_take_1byte(self._h, _ptr(src_valid), _ptr(indices), _ptr(count), n_max, _ptr(out), _stream()))
+        return out
+
+    def pairs_unzip(self, pairs, n_pairs=None):
+        """golap_pairs_unzip: int32[m, 2] (build_rid, probe_rid) -> (build ids int32[m], probe ids int32[m])"""
+        m = pairs.shape[0] if n_pairs is None else n_pairs
+        b = torch.empty(m, dtype=torch.int32, device=pairs.device)
+        p = torch.empty(m, dtype=torch.int32, device=pairs.device)
+        self._ck(self._lib.golap_pairs_unzip(self._h, _ptr(pairs), m, _ptr(b), _ptr(p), _stream()))
+        return b, p
+
+    def sort_u64(self, words, n=None):
+        """golap_sort_u64: ascending in-place sort of the first n 64-bit words of `words` (compared as UNSIGNED; int64 or an int32[m, 2] pair list)"""
+        n = (words.numel() * words.element_size()) // 8 if n is None else n
+        self._ck(self._lib.golap_sort_u64(self._h, _ptr(words), n, _stream()))
+        return words
+
+    def key_minmax(self, column, valid=None):
+        """golap_key_minmax -> int64[3] on the device: min, max, number of the valid rows"""
+        _chk_tensor(column, torch.int64, "column")
+        out = torch.empty(3, dtype=torch.int64, device=column.device)
+        self._ck(self._lib.golap_key_minmax(self._h, _ptr(column), _ptr(valid), column.numel(), _ptr(out), _stream()))
+        return out
+
+    def pack_group_keys(self, columns, valids, mins, weights, null_digits):
+        """golap_pack_group_keys: out[i] = sum_c (valid ? col_c[i] - mins[c] : null_digits[c]) * weights[c]"""
+        p = N.PackKeysParams()
+        p.n_cols, p.n_rows = len(columns), columns[0].numel()
+        out = torch.empty(p.n_rows, dtype=torch.int64, device=columns[0].device)
+        for c, col in enumerate(columns):
+            _chk_tensor(col, torch.int64, "key column")
+            p.col_ptrs[c], p.validity_ptrs[c] = _ptr(col), _ptr(valids[c]) if valids else 0
+            p.min_value[c], p.weight[c], p.null_digit[c] = int(mins[c]), int(weights[c]), int(null_digits[c])
+        p.out_ptr = _ptr(out)
+        self._ck(self._lib.golap_pack_group_keys(self._h, C.byref(p), _stream()))
+        return out
+
+    def device_copy(self, src, dst, nbytes):
+        self._ck(self._lib.golap_device_copy(self._h, _ptr(src), _ptr(dst), nbytes, _stream()))
+
+    def device_fill_u8(self, dst, value, nbytes):
+        self._ck(self._lib.golap_device_fill_u8(self._h, _ptr(dst), value, nbytes, _stream()))
+
     # ---- generators / verifier ---------------------------------------------------
     def generate(self, kind, count, modulus=1, seed=0, first=0, out=None):
         dt = {N.GEN_BUILD_KEYS: torch.int64, N.GEN_SM64_MOD_I64: torch.int64, N.GEN_SM64_MOD_I32: torch.int32,

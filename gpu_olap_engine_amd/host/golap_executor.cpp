@@ -5,47 +5,123 @@
 // Mirrors gpu-olap-core/src/executor.rs:
 //   execute            :15-24, dispatch :37-104
 //   execute_table_scan :110-155   (empty batch, as the reference)
-//   execute_filter     :161-178   -> golap_filter_compact + golap_take_8byte
+//   execute_filter     :161-178   -> golap_filter_compact + golap_take_8byte / golap_take_1byte
 //   execute_projection :184-214   (column references and literals)
 //   execute_hash_join  :220-265   -> golap_join; unlike the reference (which returns an empty
 //                                    batch at :255-264) the pairs are materialised
-//   execute_aggregate  :297-355   -> golap_aggregate (ungrouped = reference; grouped = dense keys)
+//   execute_aggregate  :297-355   -> golap_aggregate (ungrouped = reference; grouped = dense or hashed keys)
 //   execute_sort       :361-370   (pass-through, as the reference)
 //   eval_expr          :377-409   (column by name first, then by index)
+//
+// Round 4: columns are DEVICE-RESIDENT between operators.  A batch is imported without a copy (the Arrow arrays are held, not
+// memcpy'd), uploaded once -- values at their Arrow width, validity as the Arrow BITMAP, every transfer of an operator queued on the
+// TransferQueue's streams from several host threads and waited for once -- and expanded / widened / hashed where it lands
+// (record_batch_convert.rs:35-110 on the device: golap_expand_validity, golap_widen_to_8byte, golap_hash_utf8).  Filter and join outputs
+// stay in HBM (row-id lists never visit the host: validity is gathered by golap_take_1byte, pairs are ordered by golap_sort_u64 and
+// split by golap_pairs_unzip; composite GROUP BY keys are ranged by golap_key_minmax and packed by golap_pack_group_keys); only counts
+// (8 bytes), group tables and the final result come back.  No per-row host loop is left in execute_filter / _hash_join / _aggregate.
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/golap_host.h"
 
 namespace {
 
+thread_local std::string g_err;
+int32_t herr(int32_t code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define H_TRY(expr)                      \
+    do {                                 \
+        int32_t _s = (expr);             \
+        if (_s != GOLAP_OK) return _s;   \
+    } while (0)
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // ---------------------------------------------------------------------------
-// host RecordBatch
+// columns
 // ---------------------------------------------------------------------------
-enum class DType { Int64, Float64, Int32, Utf8Raw, Other };
+// logical type (what the Arrow field said); on the device every numeric column is 8 bytes wide (record_batch_convert.rs:19:
+// "All numeric types are widened to i64 / f64"), a Utf8 column is its FNV-1a 64 hash, i.e. Int64 (:93-97)
+enum class DType { Int64, Float64, Int32, Float32, IntNarrow, Utf8, Other };
+bool is_float(DType d) { return d == DType::Float64 || d == DType::Float32; }
+bool is_numeric(DType d) { return d != DType::Other; }
+
+struct ArrowFmt { DType dtype; int width; int widen; };   // widen: GOLAP_WIDEN_* code of the raw values
+ArrowFmt fmt_of(const char* f) {
+    if (!f || !f[0] || f[1]) return {DType::Other, 0, -1};
+    switch (f[0]) {
+        case 'l': return {DType::Int64, 8, GOLAP_WIDEN_I64};
+        case 'g': return {DType::Float64, 8, GOLAP_WIDEN_F64};
+        case 'i': return {DType::Int32, 4, GOLAP_WIDEN_I32};
+        case 'f': return {DType::Float32, 4, GOLAP_WIDEN_F32};
+        case 'c': return {DType::IntNarrow, 1, GOLAP_WIDEN_I8};
+        case 'C': return {DType::IntNarrow, 1, GOLAP_WIDEN_U8};
+        case 's': return {DType::IntNarrow, 2, GOLAP_WIDEN_I16};
+        case 'S': return {DType::IntNarrow, 2, GOLAP_WIDEN_U16};
+        case 'I': return {DType::IntNarrow, 4, GOLAP_WIDEN_U32};
+        case 'L': return {DType::IntNarrow, 8, GOLAP_WIDEN_U64};
+        case 'u': case 'U': return {DType::Utf8, 0, -1};
+        default: return {DType::Other, 0, -1};
+    }
+}
+
+struct DevBuf {
+    golap_ctx* ctx = nullptr;
+    uint64_t ptr = 0;
+    uint32_t cls = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (ptr) golap_slab_free(ctx, ptr, cls); }
+    int32_t alloc(golap_ctx* c, uint64_t bytes) {
+        ctx = c;
+        return golap_slab_alloc(c, std::max<uint64_t>(bytes, 8), &ptr, &cls);
+    }
+};
+using DevPtr = std::shared_ptr<DevBuf>;
+
+// the moved-in Arrow arrays of one imported batch, alive while any column still points into them
+struct ArrowHold {
+    ArrowArray arr{};
+    ArrowSchema sch{};
+    ~ArrowHold() {
+        if (arr.release) arr.release(&arr);
+        if (sch.release) sch.release(&sch);
+    }
+};
 
 struct Column {
     std::string name;
     DType dtype = DType::Other;
-    std::vector<uint8_t> data;   // packed little-endian values, nulls -> 0 (record_batch_convert.rs:102-110)
-    std::vector<uint8_t> valid;  // Arrow validity bitmap of an exported column (empty = all valid)
-    std::vector<uint8_t> in_valid;   // byte per row, 0 = NULL (ColumnBuffer.validity, column_buffer.rs:59-60); empty = no NULLs.  Travels with
-                                     // the column through the operators; GpuFilter and GpuHashJoin hand it to the kernels (NULL keys
-                                     // match nothing), GpuAggregate skips NULL values and puts NULL group keys into a group of their own
-    uint64_t null_count = 0;
     uint64_t rows = 0;
-    // Utf8 / LargeUtf8 as imported: value i = str_bytes[str_off[i] .. str_off[i + 1]).  golap_execute turns such a column into its
-    // FNV-1a 64 hashes on the device before any operator runs (record_batch_convert.rs:93-97, :112-130: the reference's GPU columns
-    // hold the hash, null -> 0): from then on it is an Int64 column.
-    std::vector<int64_t> str_off;
-    std::vector<uint8_t> str_bytes;
-    size_t width() const { return dtype == DType::Int32 ? 4 : 8; }
+    enum Where { Arrow, Device, Host } where = Host;
+    // Arrow: as imported (no copy).  values / bitmap / offsets point into `hold`'s buffers; `off` is the array offset in rows
+    std::shared_ptr<ArrowHold> hold;
+    const uint8_t* a_values = nullptr;
+    const uint8_t* a_bitmap = nullptr;    // null: no NULLs
+    const uint8_t* a_offsets = nullptr;   // Utf8: int32 / int64 offsets, a_values = the bytes
+    int64_t off = 0;
+    char fmt = 0;
+    // Device: 8 bytes per row + one validity byte per row (column_buffer.rs:59-60; null pointer = no NULLs)
+    DevPtr d_data, d_valid;
+    // Host: small results (aggregates, literals) and what export hands out; 8 bytes per row unless `fmt` says otherwise (a passed-through column)
+    std::vector<uint8_t> data;
+    std::vector<uint8_t> in_valid;        // one byte per row, empty = no NULLs
+    std::vector<uint8_t> valid;           // Arrow bitmap (export form), with null_count
+    uint64_t null_count = 0;
+    bool has_validity() const { return where == Arrow ? a_bitmap != nullptr : where == Device ? (bool)d_valid : !in_valid.empty(); }
 };
 
 struct RecordBatch {
@@ -58,81 +134,46 @@ struct RecordBatch {
     }
 };
 
-thread_local std::string g_err;
-int32_t herr(int32_t code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-
-DType dtype_of_format(const char* f) {
-    if (!f) return DType::Other;
-    if (!strcmp(f, "l")) return DType::Int64;
-    if (!strcmp(f, "g")) return DType::Float64;
-    if (!strcmp(f, "i")) return DType::Int32;
-    return DType::Other;   // ("u" / "U" strings become DType::Utf8Raw in import_batch)
-}
-const char* format_of_dtype(DType d) { return d == DType::Int64 ? "l" : d == DType::Float64 ? "g" : d == DType::Int32 ? "i" : "n"; }
-
 bool import_batch(ArrowArray* arr, ArrowSchema* sch, RecordBatch& out, std::string& err) {
     if (!arr || !sch || !sch->format || strcmp(sch->format, "+s")) { err = "expected an Arrow struct array (format +s)"; return false; }
     if (arr->n_children != sch->n_children) { err = "array/schema children mismatch"; return false; }
-    out.num_rows = (uint64_t)arr->length;
-    for (int64_t c = 0; c < sch->n_children; ++c) {
-        ArrowSchema* cs = sch->children[c];
-        ArrowArray* ca = arr->children[c];
+    // the arrays are MOVED in (Arrow C Data Interface: copy the structs, mark the sources released); nothing is copied
+    auto hold = std::make_shared<ArrowHold>();
+    hold->arr = *arr;
+    hold->sch = *sch;
+    arr->release = nullptr;
+    sch->release = nullptr;
+    const ArrowArray& A = hold->arr;
+    const ArrowSchema& S = hold->sch;
+    out.num_rows = (uint64_t)A.length;
+    for (int64_t c = 0; c < S.n_children; ++c) {
+        const ArrowSchema* cs = S.children[c];
+        const ArrowArray* ca = A.children[c];
         Column col;
         col.name = cs->name ? cs->name : "";
-        col.dtype = dtype_of_format(cs->format);
+        const ArrowFmt f = fmt_of(cs->format);
+        col.dtype = f.dtype;
+        col.fmt = cs->format && cs->format[0] ? cs->format[0] : 0;
         col.rows = out.num_rows;
-        if (cs->format && (!strcmp(cs->format, "u") || !strcmp(cs->format, "U"))) {
-            const bool large = cs->format[0] == 'U';
-            const int64_t off = ca->offset + arr->offset;
-            const uint8_t* valid = ca->n_buffers >= 1 ? (const uint8_t*)ca->buffers[0] : nullptr;
-            if (ca->n_buffers < 3 || (out.num_rows && (!ca->buffers[1] || !ca->buffers[2]))) {
-                if (out.num_rows) { err = "string column '" + col.name + "' has no offsets / data buffer"; return false; }
-            }
-            col.dtype = DType::Utf8Raw;
-            col.str_off.resize((size_t)out.num_rows + 1, 0);
-            int64_t first = 0, last = 0;
-            for (uint64_t i = 0; i <= out.num_rows && out.num_rows; ++i) {
-                const int64_t o = large ? ((const int64_t*)ca->buffers[1])[off + (int64_t)i] : (int64_t)((const int32_t*)ca->buffers[1])[off + (int64_t)i];
-                if (i == 0) first = o;
-                col.str_off[i] = o - first;
-                last = o;
-            }
-            if (out.num_rows) col.str_bytes.assign((const uint8_t*)ca->buffers[2] + first, (const uint8_t*)ca->buffers[2] + last);
-            if (valid && ca->null_count != 0) {
-                col.in_valid.assign((size_t)out.num_rows, 1);
-                for (uint64_t i = 0; i < out.num_rows; ++i) {
-                    const int64_t j = off + (int64_t)i;
-                    if (!((valid[j >> 3] >> (j & 7)) & 1)) col.in_valid[i] = 0;
-                }
-            }
-        } else if (col.dtype != DType::Other) {
-            const size_t w = col.width();
-            col.data.resize((size_t)out.num_rows * w);
-            const uint8_t* src = ca->n_buffers >= 2 ? (const uint8_t*)ca->buffers[1] : nullptr;
-            const uint8_t* valid = ca->n_buffers >= 1 ? (const uint8_t*)ca->buffers[0] : nullptr;
-            const int64_t off = ca->offset + arr->offset;
-            if (out.num_rows && !src) { err = "column '" + col.name + "' has no data buffer"; return false; }
-            if (out.num_rows) memcpy(col.data.data(), src + (size_t)off * w, (size_t)out.num_rows * w);
-            if (valid && ca->null_count != 0) {
-                col.in_valid.assign((size_t)out.num_rows, 1);
-                for (uint64_t i = 0; i < out.num_rows; ++i) {
-                    const int64_t j = off + (int64_t)i;
-                    if (!((valid[j >> 3] >> (j & 7)) & 1)) {
-                        memset(col.data.data() + i * w, 0, w);   // null -> 0
-                        col.in_valid[i] = 0;
-                    }
-                }
-            }
+        col.where = Column::Arrow;
+        col.hold = hold;
+        col.off = ca->offset + A.offset;
+        const uint8_t* bitmap = ca->n_buffers >= 1 ? (const uint8_t*)ca->buffers[0] : nullptr;
+        col.a_bitmap = (bitmap && ca->null_count != 0) ? bitmap : nullptr;
+        if (f.dtype == DType::Utf8) {
+            if (out.num_rows && (ca->n_buffers < 3 || !ca->buffers[1] || !ca->buffers[2])) { err = "string column '" + col.name + "' has no offsets / data buffer"; return false; }
+            col.a_offsets = ca->n_buffers >= 2 ? (const uint8_t*)ca->buffers[1] : nullptr;
+            col.a_values = ca->n_buffers >= 3 ? (const uint8_t*)ca->buffers[2] : nullptr;
+        } else if (f.dtype != DType::Other) {
+            col.a_values = ca->n_buffers >= 2 ? (const uint8_t*)ca->buffers[1] : nullptr;
+            if (out.num_rows && !col.a_values) { err = "column '" + col.name + "' has no data buffer"; return false; }
         }
         out.cols.push_back(std::move(col));
     }
     return true;
 }
 
-// ---- export (the exported arrays own copies of the column data) ----
+// ---- export (the exported arrays own their buffers) ----
 struct ExportPriv {
     std::vector<std::vector<uint8_t>> data, valid;
     std::vector<const void*> bufs;   // 2 per child + 1 for the struct
@@ -140,7 +181,7 @@ struct ExportPriv {
     std::vector<ArrowArray*> child_ptrs;
     std::vector<ArrowSchema> child_schemas;
     std::vector<ArrowSchema*> child_sptrs;
-    std::vector<std::string> names;
+    std::vector<std::string> names, formats;
 };
 void release_child_array(ArrowArray* a) { a->release = nullptr; }
 void release_child_schema(ArrowSchema* s) { s->release = nullptr; }
@@ -159,6 +200,15 @@ void release_schema(ArrowSchema* s) {
     s->release = nullptr;
 }
 
+// the Arrow format a Host-state column leaves as: a passed-through column keeps its own (`fmt` set), everything that has been on the
+// device is Int64 / Float64 (gpu_buffers_to_record_batch, record_batch_convert.rs:146-178, builds nothing else)
+std::string export_format(const Column& c) {
+    if (c.dtype == DType::Other) return "n";
+    if (c.fmt && c.dtype != DType::Utf8) return std::string(1, c.fmt);
+    return is_float(c.dtype) ? "g" : "l";
+}
+
+// Host-state batch -> Arrow (byte-per-row validity is packed here: result-sized host work on columns that never were on the device)
 void export_batch(RecordBatch&& b, ArrowArray* oa, ArrowSchema* os) {
     auto priv = std::make_shared<ExportPriv>();
     const size_t nc = b.cols.size();
@@ -168,9 +218,10 @@ void export_batch(RecordBatch&& b, ArrowArray* oa, ArrowSchema* os) {
     priv->child_arrays.resize(nc);
     priv->child_schemas.resize(nc);
     priv->names.resize(nc);
+    priv->formats.resize(nc);
     for (size_t c = 0; c < nc; ++c) {
         Column& col = b.cols[c];
-        if (col.valid.empty() && !col.in_valid.empty()) {   // byte-per-row validity -> Arrow bitmap
+        if (col.valid.empty() && !col.in_valid.empty()) {
             uint64_t nulls = 0;
             col.valid.assign((size_t)(b.num_rows + 7) / 8, 0);
             for (uint64_t i = 0; i < b.num_rows; ++i) {
@@ -180,23 +231,24 @@ void export_batch(RecordBatch&& b, ArrowArray* oa, ArrowSchema* os) {
             col.null_count = nulls;
             if (!nulls) col.valid.clear();
         }
-        priv->data[c] = std::move(b.cols[c].data);
-        priv->valid[c] = std::move(b.cols[c].valid);
-        priv->names[c] = b.cols[c].name;
+        priv->formats[c] = export_format(col);
+        priv->data[c] = std::move(col.data);
+        priv->valid[c] = std::move(col.valid);
+        priv->names[c] = col.name;
         priv->bufs[2 * c] = priv->valid[c].empty() ? nullptr : (const void*)priv->valid[c].data();
         priv->bufs[2 * c + 1] = priv->data[c].empty() ? (const void*)"" : (const void*)priv->data[c].data();
         ArrowArray& ca = priv->child_arrays[c];
         memset(&ca, 0, sizeof ca);
         ca.length = (int64_t)b.num_rows;
-        ca.null_count = (int64_t)b.cols[c].null_count;
+        ca.null_count = (int64_t)col.null_count;
         ca.n_buffers = 2;
         ca.buffers = &priv->bufs[2 * c];
         ca.release = release_child_array;
         ArrowSchema& cs = priv->child_schemas[c];
         memset(&cs, 0, sizeof cs);
-        cs.format = format_of_dtype(b.cols[c].dtype);
+        cs.format = priv->formats[c].c_str();
         cs.name = priv->names[c].c_str();
-        cs.flags = b.cols[c].null_count ? 2 /* ARROW_FLAG_NULLABLE */ : 0;
+        cs.flags = col.null_count ? 2 /* ARROW_FLAG_NULLABLE */ : 0;
         cs.release = release_child_schema;
         priv->child_ptrs.push_back(&ca);
         priv->child_sptrs.push_back(&cs);
@@ -242,53 +294,57 @@ struct golap_plan {
 
 struct golap_result {
     std::vector<RecordBatch> batches;
+    golap_exec_profile profile{};
 };
 
 namespace {
 
 // ---------------------------------------------------------------------------
-// device helpers (slabs + transfer queue)
+// the executor
 // ---------------------------------------------------------------------------
-struct DevBuf {
-    golap_ctx* ctx = nullptr;
-    uint64_t ptr = 0;
-    uint32_t cls = 0;
-    DevBuf() = default;
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), ptr(o.ptr), cls(o.cls) { o.ptr = 0; }
-    ~DevBuf() { if (ptr) golap_slab_free(ctx, ptr, cls); }
-    int32_t alloc(golap_ctx* c, uint64_t bytes) {
-        ctx = c;
-        return golap_slab_alloc(c, std::max<uint64_t>(bytes, 8), &ptr, &cls);
-    }
-};
-
-#define H_TRY(expr)                      \
-    do {                                 \
-        int32_t _s = (expr);             \
-        if (_s != GOLAP_OK) return _s;   \
-    } while (0)
+struct Xfer { int32_t dir; uint64_t src, dst, bytes; };
 
 struct Exec {
-    golap_ctx* ctx;
-    uint32_t next_stream = 0;
+    golap_ctx* ctx = nullptr;
+    golap_exec_profile prof{};
+    std::vector<Xfer> pending;          // transfers of the current phase, run together by flush()
+    std::vector<DevPtr> keep;           // device temporaries that kernels still in flight may read: released by end_op() behind a ksync
 
-    int32_t h2d(const void* src, uint64_t dst, uint64_t bytes) {
-        // split large columns over the transfer streams (transfer_queue.rs:72 round-robin)
-        const uint64_t piece = 64ull << 20;
-        for (uint64_t o = 0; o < bytes; o += piece)
-            H_TRY(golap_xfer_enqueue(ctx, GOLAP_HOST_TO_DEVICE, (uint64_t)(uintptr_t)src + o, dst + o, std::min(piece, bytes - o), next_stream++));
+    int32_t need_ctx() const { return ctx ? GOLAP_OK : herr(GOLAP_ERR_INVALID_ARG, "this plan needs the device: golap_execute was called without a context (there is no CPU fallback)"); }
+    int32_t dev_alloc(DevPtr& out, uint64_t bytes) {
+        out = std::make_shared<DevBuf>();
+        return out->alloc(ctx, bytes);
+    }
+    int32_t temp(DevPtr& out, uint64_t bytes) {
+        H_TRY(dev_alloc(out, bytes));
+        keep.push_back(out);
         return GOLAP_OK;
     }
-    int32_t d2h(uint64_t src, void* dst, uint64_t bytes) {
-        const uint64_t piece = 64ull << 20;
-        for (uint64_t o = 0; o < bytes; o += piece)
-            H_TRY(golap_xfer_enqueue(ctx, GOLAP_DEVICE_TO_HOST, src + o, (uint64_t)(uintptr_t)dst + o, std::min(piece, bytes - o), next_stream++));
-        return GOLAP_OK;
+    void drop(DevPtr& p) {   // a temporary no kernel in flight uses any more (the caller has just synchronised): back to the pool now
+        keep.erase(std::remove(keep.begin(), keep.end(), p), keep.end());
+        p.reset();
     }
-    int32_t xsync() { return golap_xfer_synchronize(ctx); }
-    int32_t ksync() { return golap_ctx_synchronize(ctx, nullptr); }
+    void up(const void* src, uint64_t dst, uint64_t bytes) { if (bytes) pending.push_back({GOLAP_HOST_TO_DEVICE, (uint64_t)(uintptr_t)src, dst, bytes}); }
+    void down(uint64_t src, void* dst, uint64_t bytes) { if (bytes) pending.push_back({GOLAP_DEVICE_TO_HOST, src, (uint64_t)(uintptr_t)dst, bytes}); }
+    int32_t flush();
+    int32_t ksync() {
+        const double t0 = now_ms();
+        const int32_t s = golap_ctx_synchronize(ctx, nullptr);
+        prof.kernel_wait_ms += now_ms() - t0;
+        return s;
+    }
+    // end of an operator: the device is drained ONCE, then its temporaries go back to the slab pool
+    int32_t end_op() {
+        int32_t s = GOLAP_OK;
+        if (ctx && !keep.empty()) s = ksync();
+        keep.clear();
+        return s;
+    }
+    int32_t read_u64(uint64_t dev_ptr, uint64_t* out, uint32_t n = 1) {   // a count the host needs to size what comes next
+        H_TRY(ksync());
+        down(dev_ptr, out, 8ull * n);
+        return flush();
+    }
 
     // eval_expr, executor.rs:377-409: column by NAME first, then by index
     static int resolve_column(const golap_expr& e, const RecordBatch& b) {
@@ -298,14 +354,241 @@ struct Exec {
         return -1;
     }
 
+    int32_t to_device(const std::vector<RecordBatch*>& bs);
+    int32_t to_host(std::vector<RecordBatch>& bs);
     int32_t run(golap_plan& p, std::vector<RecordBatch>& out);
     int32_t filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::vector<RecordBatch>& out);
     int32_t projection(std::vector<RecordBatch>& in, const std::vector<std::unique_ptr<golap_expr>>& exprs, std::vector<RecordBatch>& out);
     int32_t hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out);
     int32_t aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
-    int32_t aggregate_multi_key(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
-    int32_t hash_strings(golap_plan& p);
+
+    struct Cat { uint64_t ptr = 0, vptr = 0; };   // one column of an operator's whole input as ONE device array (+ validity bytes, 0 = no NULLs)
+    int32_t concat(const std::vector<RecordBatch*>& bs, const std::vector<int>& ci, uint64_t n, Cat& out);
 };
+
+// Runs the queued transfers: large ones are cut into 32 MiB pieces and dealt to up to 8 host threads, thread t on transfer stream t
+// (transfer_queue.rs:72: stream_id % num_streams) -- pageable Arrow buffers are staged through that stream's two pinned bounce buffers,
+// so the staging memcpy of one stream runs beside the DMA of the others; the caller waits ONCE, for all of them.
+int32_t Exec::flush() {
+    if (pending.empty()) return GOLAP_OK;
+    H_TRY(need_ctx());
+    const double t0 = now_ms();
+    std::vector<Xfer> pieces;
+    uint64_t up_bytes = 0, down_bytes = 0;
+    const uint64_t piece = 32ull << 20;
+    for (const Xfer& x : pending) {
+        (x.dir == GOLAP_HOST_TO_DEVICE ? up_bytes : down_bytes) += x.bytes;
+        for (uint64_t o = 0; o < x.bytes; o += piece) pieces.push_back({x.dir, x.src + o, x.dst + o, std::min(piece, x.bytes - o)});
+    }
+    pending.clear();
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t T = (up_bytes + down_bytes) < (8ull << 20) ? 1 : std::min<size_t>({8, hw, pieces.size()});
+    std::vector<int32_t> status(T, GOLAP_OK);
+    auto work = [&](size_t t) {
+        for (size_t i = t; i < pieces.size(); i += T) {
+            const int32_t s = golap_xfer_enqueue(ctx, pieces[i].dir, pieces[i].src, pieces[i].dst, pieces[i].bytes, (uint32_t)t);
+            if (s != GOLAP_OK) { status[t] = s; return; }
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    const int32_t sync = golap_xfer_synchronize(ctx);
+    const double dt = now_ms() - t0;
+    // (a phase moves one way: uploads at an operator's start, downloads of counts / results at its end)
+    if (up_bytes >= down_bytes) { prof.h2d_bytes += up_bytes; prof.h2d_ms += dt; prof.d2h_bytes += down_bytes; }
+    else { prof.d2h_bytes += down_bytes; prof.d2h_ms += dt; prof.h2d_bytes += up_bytes; }
+    for (int32_t s : status) H_TRY(s);
+    return sync;
+}
+
+// ---------------------------------------------------------------------------
+// record_batch_to_gpu_buffers (record_batch_convert.rs:22-33, column_to_buffer :35-110) on the device
+// ---------------------------------------------------------------------------
+// Every column of `bs` that is not in HBM yet goes there: phase 1 queues the raw uploads of ALL of them (values at their Arrow width
+// from the array offset on, the validity bitmap from the byte that holds the first row's bit, string offsets and bytes), one flush;
+// phase 2 expands the bitmaps to a byte per row, widens to 8 bytes with NULL -> 0 (:102-110) and hashes strings (:112-130) in place.
+int32_t Exec::to_device(const std::vector<RecordBatch*>& bs) {
+    struct Job { Column* c; DevPtr raw, bitmap, offs, offs32; uint64_t bit_off = 0; int64_t str_first = 0; int widen = -1; bool large = false; };
+    std::vector<Job> jobs;
+    for (RecordBatch* b : bs)
+        for (Column& c : b->cols) {
+            if (c.where == Column::Device) continue;
+            if (!is_numeric(c.dtype)) return herr(GOLAP_ERR_UNSUPPORTED, "column '" + c.name + "': unsupported column type for GPU conversion (record_batch_convert.rs:98)");
+            H_TRY(need_ctx());
+            Job j;
+            j.c = &c;
+            const uint64_t n = c.rows;
+            H_TRY(dev_alloc(c.d_data, n * 8));
+            if (c.where == Column::Host) {                         // a small result of an earlier operator: already 8 bytes wide, validity as bytes
+                up(c.data.data(), c.d_data->ptr, n * 8);
+                if (!c.in_valid.empty()) { H_TRY(dev_alloc(c.d_valid, n)); up(c.in_valid.data(), c.d_valid->ptr, n); }
+                jobs.push_back(std::move(j));
+                continue;
+            }
+            if (n && c.a_bitmap) {
+                const uint64_t first_byte = (uint64_t)c.off >> 3;
+                j.bit_off = (uint64_t)c.off & 7;
+                const uint64_t nbytes = (j.bit_off + n + 7) / 8;
+                H_TRY(temp(j.bitmap, nbytes));
+                H_TRY(dev_alloc(c.d_valid, n));
+                up(c.a_bitmap + first_byte, j.bitmap->ptr, nbytes);
+            }
+            if (c.dtype == DType::Utf8) {
+                j.large = c.fmt == 'U';
+                const size_t ow = j.large ? 8 : 4;
+                if (n) {
+                    const int64_t first = j.large ? ((const int64_t*)c.a_offsets)[c.off] : (int64_t)((const int32_t*)c.a_offsets)[c.off];
+                    const int64_t last = j.large ? ((const int64_t*)c.a_offsets)[c.off + (int64_t)n] : (int64_t)((const int32_t*)c.a_offsets)[c.off + (int64_t)n];
+                    j.str_first = first;
+                    H_TRY(temp(j.offs, (n + 1) * 8));
+                    if (!j.large) H_TRY(temp(j.offs32, (n + 1) * 4));   // (int32 offsets are widened on the device)
+                    H_TRY(temp(j.raw, (uint64_t)std::max<int64_t>(last - first, 8)));
+                    up(c.a_offsets + (size_t)c.off * ow, j.large ? j.offs->ptr : j.offs32->ptr, (n + 1) * ow);
+                    if (last > first) up(c.a_values + first, j.raw->ptr, (uint64_t)(last - first));
+                }
+            } else {
+                const ArrowFmt f = fmt_of(std::string(1, c.fmt).c_str());
+                j.widen = f.widen;
+                if (n) {
+                    if (f.width == 8) up(c.a_values + (size_t)c.off * 8, c.d_data->ptr, n * 8);          // straight into the column
+                    else { H_TRY(temp(j.raw, n * (uint64_t)f.width)); up(c.a_values + (size_t)c.off * (size_t)f.width, j.raw->ptr, n * (uint64_t)f.width); }
+                }
+            }
+            jobs.push_back(std::move(j));
+        }
+    if (jobs.empty()) return GOLAP_OK;
+    H_TRY(flush());
+    for (Job& j : jobs) {
+        Column& c = *j.c;
+        const uint64_t n = c.rows;
+        if (c.where == Column::Arrow && n) {
+            const uint64_t vptr = c.d_valid ? c.d_valid->ptr : 0;
+            if (j.bitmap) H_TRY(golap_expand_validity(ctx, j.bitmap->ptr, j.bit_off, n, vptr, nullptr));
+            if (c.dtype == DType::Utf8) {
+                if (!j.large) H_TRY(golap_widen_to_8byte(ctx, j.offs32->ptr, GOLAP_WIDEN_I32, 0, n + 1, j.offs->ptr, nullptr));
+                // (offsets are absolute positions in the Arrow data buffer; only [first, last) of it was uploaded)
+                H_TRY(golap_hash_utf8(ctx, j.offs->ptr, j.raw->ptr - (uint64_t)j.str_first, vptr, n, c.d_data->ptr, nullptr));
+            } else if (j.raw) {
+                H_TRY(golap_widen_to_8byte(ctx, j.raw->ptr, j.widen, vptr, n, c.d_data->ptr, nullptr));
+            } else if (vptr) {
+                H_TRY(golap_widen_to_8byte(ctx, c.d_data->ptr, j.widen, vptr, n, c.d_data->ptr, nullptr));   // 8-byte values: only NULL -> 0, in place
+            }
+        }
+        if (c.dtype == DType::Utf8) c.dtype = DType::Int64;      // from here on: the hash (DictEncodedString as i64, :93-97)
+        c.where = Column::Device;
+        c.hold.reset();
+        c.a_values = c.a_bitmap = c.a_offsets = nullptr;
+        c.fmt = 0;
+        c.data.clear(); c.data.shrink_to_fit();
+        c.in_valid.clear(); c.in_valid.shrink_to_fit();
+    }
+    return GOLAP_OK;
+}
+
+// gpu_buffers_to_record_batch (record_batch_convert.rs:136-178): the result leaves the device once -- values as they are, validity
+// packed to the Arrow bitmap (and counted) on the device first; passed-through Arrow columns are copied out of their arrays
+int32_t Exec::to_host(std::vector<RecordBatch>& bs) {
+    // a string column that no operator touched still leaves as its hash (what the GPU path holds): it has to visit the device
+    std::vector<RecordBatch*> strs;
+    for (RecordBatch& b : bs) {
+        bool any = false;
+        for (Column& c : b.cols) any = any || (c.where == Column::Arrow && c.dtype == DType::Utf8);
+        if (any) strs.push_back(&b);
+    }
+    if (!strs.empty()) H_TRY(to_device(strs));
+    struct Job { Column* c; DevPtr bitmap, nulls; uint64_t null_count = 0; };
+    std::vector<Job> jobs;
+    for (RecordBatch& b : bs)
+        for (Column& c : b.cols) {
+            const uint64_t n = c.rows;
+            if (c.where == Column::Arrow) {
+                const ArrowFmt f = fmt_of(std::string(1, c.fmt).c_str());
+                c.data.resize((size_t)n * (size_t)f.width);
+                if (n) memcpy(c.data.data(), c.a_values + (size_t)c.off * (size_t)f.width, (size_t)n * (size_t)f.width);
+                if (c.a_bitmap && n) {   // (a passed-through column never was on the device: its bitmap is re-based and its NULL slots zeroed here)
+                    c.in_valid.resize((size_t)n);
+                    for (uint64_t i = 0; i < n; ++i) {
+                        const int64_t k = c.off + (int64_t)i;
+                        const uint8_t ok = (c.a_bitmap[k >> 3] >> (k & 7)) & 1;
+                        c.in_valid[i] = ok;
+                        if (!ok) memset(c.data.data() + i * (size_t)f.width, 0, (size_t)f.width);   // null -> 0 (:102-110)
+                    }
+                }
+                c.where = Column::Host;
+                c.hold.reset();
+                c.a_values = c.a_bitmap = c.a_offsets = nullptr;
+            } else if (c.where == Column::Device) {
+                Job j;
+                j.c = &c;
+                if (c.d_valid && n) {
+                    H_TRY(temp(j.bitmap, (n + 7) / 8));
+                    H_TRY(temp(j.nulls, 8));
+                    H_TRY(golap_pack_validity(ctx, c.d_valid->ptr, n, j.bitmap->ptr, j.nulls->ptr, nullptr));
+                }
+                jobs.push_back(std::move(j));
+            }
+        }
+    if (jobs.empty()) return GOLAP_OK;
+    H_TRY(ksync());
+    for (Job& j : jobs) {
+        Column& c = *j.c;
+        c.data.resize((size_t)c.rows * 8);
+        down(c.d_data->ptr, c.data.data(), c.rows * 8);
+        if (j.bitmap) {
+            c.valid.resize((size_t)(c.rows + 7) / 8);
+            down(j.bitmap->ptr, c.valid.data(), (c.rows + 7) / 8);
+            down(j.nulls->ptr, &j.null_count, 8);
+        }
+    }
+    H_TRY(flush());
+    for (Job& j : jobs) {
+        Column& c = *j.c;
+        c.null_count = j.null_count;
+        if (!c.null_count) c.valid.clear();
+        c.where = Column::Host;
+        c.d_data.reset();
+        c.d_valid.reset();
+    }
+    return end_op();
+}
+
+// column ci[k] of batch bs[k], all batches, as one device array of n rows (values; validity bytes when any batch carries NULLs).
+// One batch -- the usual case -- is used where it lies; several are copied together on the device.
+int32_t Exec::concat(const std::vector<RecordBatch*>& bs, const std::vector<int>& ci, uint64_t n, Cat& out) {
+    out = Cat();
+    std::vector<size_t> live;
+    bool any_valid = false;
+    for (size_t k = 0; k < bs.size(); ++k)
+        if (bs[k]->num_rows) { live.push_back(k); any_valid = any_valid || (bool)bs[k]->cols[ci[k]].d_valid; }
+    if (live.empty()) return GOLAP_OK;
+    if (live.size() == 1) {
+        const Column& c = bs[live[0]]->cols[ci[live[0]]];
+        out.ptr = c.d_data->ptr;
+        out.vptr = c.d_valid ? c.d_valid->ptr : 0;
+        return GOLAP_OK;
+    }
+    DevPtr d, v;
+    H_TRY(temp(d, n * 8));
+    if (any_valid) H_TRY(temp(v, n));
+    uint64_t o = 0;
+    for (size_t k : live) {
+        const Column& c = bs[k]->cols[ci[k]];
+        H_TRY(golap_device_copy(ctx, c.d_data->ptr, d->ptr + o * 8, c.rows * 8, nullptr));
+        if (any_valid) {
+            if (c.d_valid) H_TRY(golap_device_copy(ctx, c.d_valid->ptr, v->ptr + o, c.rows, nullptr));
+            else H_TRY(golap_device_fill_u8(ctx, v->ptr + o, 1, c.rows, nullptr));
+        }
+        o += c.rows;
+    }
+    out.ptr = d->ptr;
+    out.vptr = any_valid ? v->ptr : 0;
+    return GOLAP_OK;
+}
 
 bool parse_i64(const std::string& s, int64_t& v) {
     if (s.empty()) return false;
@@ -365,73 +648,45 @@ int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::
             const int ci = resolve_column(*colx, b);
             if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + colx->name + "' not found in batch");   // :386
             int64_t lit;
-            // operands that are not both Int64 => every row passes (:449-452, :471-472)
-            if (b.cols[ci].dtype != DType::Int64 || !parse_i64(litx->value, lit)) continue;
+            // operands that are not both Int64 => every row passes (:449-452, :471-472); a Utf8 column is its Int64 hash on this path (:93-97)
+            if ((b.cols[ci].dtype != DType::Int64 && b.cols[ci].dtype != DType::Utf8) || !parse_i64(litx->value, lit)) continue;
             fps.push_back(golap_filter_predicate{(uint64_t)ci, (int32_t)op, lit});
             fcols.push_back(ci);
         }
         if (fps.empty()) { out.push_back(std::move(b)); continue; }
         const uint64_t n = b.num_rows;
         if (n == 0) continue;   // empty batches are dropped (:173)
-        DevBuf didx, dcnt;
-        std::vector<DevBuf> dkeys(fps.size()), dvals(fps.size());
+        H_TRY(need_ctx());
+        H_TRY(to_device({&b}));
+        DevPtr didx, dcnt;
+        H_TRY(temp(didx, n * 4));
+        H_TRY(temp(dcnt, 8));
         std::vector<uint64_t> kptrs(fps.size(), 0), vptrs(fps.size(), 0);
-        H_TRY(didx.alloc(ctx, n * 4));
-        H_TRY(dcnt.alloc(ctx, 8));
         for (size_t k = 0; k < fps.size(); ++k) {
             const Column& c = b.cols[fcols[k]];
-            size_t same = k;
-            for (size_t j = 0; j < k; ++j) if (fcols[j] == fcols[k]) { same = j; break; }
-            if (same != k) { kptrs[k] = kptrs[same]; vptrs[k] = vptrs[same]; continue; }   // (a range: lo <= x AND x < hi reads the column once)
-            H_TRY(dkeys[k].alloc(ctx, n * 8));
-            H_TRY(h2d(c.data.data(), dkeys[k].ptr, n * 8));
-            kptrs[k] = dkeys[k].ptr;
-            if (!c.in_valid.empty()) {   // a comparison with NULL is not true: such rows do not pass
-                H_TRY(dvals[k].alloc(ctx, n));
-                H_TRY(h2d(c.in_valid.data(), dvals[k].ptr, n));
-                vptrs[k] = dvals[k].ptr;
-            }
+            kptrs[k] = c.d_data->ptr;                           // (a range lo <= x AND x < hi names the same column twice: read once by the kernel)
+            vptrs[k] = c.d_valid ? c.d_valid->ptr : 0;          // a comparison with NULL is not true: such rows do not pass
         }
-        H_TRY(xsync());
-        if (fps.size() == 1) H_TRY(golap_filter_compact_nullable(ctx, &fps[0], kptrs[0], vptrs[0], n, didx.ptr, dcnt.ptr, nullptr));
-        else H_TRY(golap_filter_compact_and(ctx, fps.data(), kptrs.data(), vptrs.data(), (uint32_t)fps.size(), n, didx.ptr, dcnt.ptr, nullptr));
-        H_TRY(ksync());
+        if (fps.size() == 1) H_TRY(golap_filter_compact_nullable(ctx, &fps[0], kptrs[0], vptrs[0], n, didx->ptr, dcnt->ptr, nullptr));
+        else H_TRY(golap_filter_compact_and(ctx, fps.data(), kptrs.data(), vptrs.data(), (uint32_t)fps.size(), n, didx->ptr, dcnt->ptr, nullptr));
         uint64_t kept = 0;
-        H_TRY(d2h(dcnt.ptr, &kept, 8));
-        H_TRY(xsync());
-        if (kept == 0) continue;
-        std::vector<uint32_t> hidx;   // the kept row ids on the host too, when some column carries NULLs (their validity is gathered here)
-        bool any_nulls = false;
-        for (const Column& c : b.cols) any_nulls = any_nulls || !c.in_valid.empty();
-        if (any_nulls) {
-            hidx.resize(kept);
-            H_TRY(d2h(didx.ptr, hidx.data(), kept * 4));
-            H_TRY(xsync());
-        }
+        H_TRY(read_u64(dcnt->ptr, &kept));
+        if (kept == 0) { H_TRY(end_op()); continue; }
         RecordBatch ob;
         ob.num_rows = kept;
-        for (Column& c : b.cols) {
-            if (c.dtype != DType::Int64 && c.dtype != DType::Float64)
-                return herr(GOLAP_ERR_UNSUPPORTED, "GpuFilter: column '" + c.name + "' is neither Int64 nor Float64 (take_int64, executor.rs:496-507)");
-            DevBuf dcol, dout;
-            H_TRY(dcol.alloc(ctx, n * 8));
-            H_TRY(dout.alloc(ctx, kept * 8));
-            H_TRY(h2d(c.data.data(), dcol.ptr, n * 8));
-            H_TRY(xsync());
-            H_TRY(golap_take_8byte(ctx, dcol.ptr, didx.ptr, 0, kept, dout.ptr, nullptr));
-            H_TRY(ksync());
+        for (Column& c : b.cols) {      // take_int64 (:496-507) for every column -- values and, where the column has them, validity bytes: the row ids stay on the device
             Column oc;
-            oc.name = c.name; oc.dtype = c.dtype; oc.rows = kept;
-            oc.data.resize(kept * 8);
-            H_TRY(d2h(dout.ptr, oc.data.data(), kept * 8));
-            H_TRY(xsync());
-            if (!c.in_valid.empty()) {
-                oc.in_valid.resize(kept);
-                for (uint64_t i = 0; i < kept; ++i) oc.in_valid[i] = c.in_valid[hidx[i]];
+            oc.name = c.name; oc.dtype = c.dtype; oc.rows = kept; oc.where = Column::Device;
+            H_TRY(dev_alloc(oc.d_data, kept * 8));
+            H_TRY(golap_take_8byte(ctx, c.d_data->ptr, didx->ptr, 0, kept, oc.d_data->ptr, nullptr));
+            if (c.d_valid) {
+                H_TRY(dev_alloc(oc.d_valid, kept));
+                H_TRY(golap_take_1byte(ctx, c.d_valid->ptr, didx->ptr, 0, kept, oc.d_valid->ptr, nullptr));
             }
             ob.cols.push_back(std::move(oc));
         }
         out.push_back(std::move(ob));
+        H_TRY(end_op());
     }
     return GOLAP_OK;
 }
@@ -445,7 +700,7 @@ int32_t Exec::projection(std::vector<RecordBatch>& in, const std::vector<std::un
             if (e->kind == golap_expr::Column) {
                 const int ci = resolve_column(*e, b);
                 if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + e->name + "' not found in batch");
-                Column c = b.cols[ci];
+                Column c = b.cols[ci];                 // (device and Arrow buffers are shared, not copied)
                 c.name = e->name;                      // expr_name, :531
                 ob.cols.push_back(std::move(c));
             } else if (e->kind == golap_expr::Literal) {
@@ -453,7 +708,7 @@ int32_t Exec::projection(std::vector<RecordBatch>& in, const std::vector<std::un
                 if (!parse_i64(e->value, v)) return herr(GOLAP_ERR_UNSUPPORTED, "Cannot parse literal '" + e->value + "'");   // :400
                 Column c;
                 c.name = "lit(" + e->value + ")";      // :532
-                c.dtype = DType::Int64; c.rows = b.num_rows;
+                c.dtype = DType::Int64; c.rows = b.num_rows; c.where = Column::Host;
                 c.data.resize(b.num_rows * 8);
                 for (uint64_t i = 0; i < b.num_rows; ++i) memcpy(c.data.data() + i * 8, &v, 8);
                 ob.cols.push_back(std::move(c));
@@ -464,29 +719,6 @@ int32_t Exec::projection(std::vector<RecordBatch>& in, const std::vector<std::un
         out.push_back(std::move(ob));
     }
     return GOLAP_OK;
-}
-
-// concatenates column `ci(b)` of every batch (+ its validity bytes: `valid` stays empty when no batch has NULLs in it);
-// returns false if any batch's column is not Int64
-static bool concat_i64(const std::vector<RecordBatch>& bs, const golap_expr& key, std::vector<int64_t>& out, std::vector<uint8_t>& valid, std::string& err) {
-    bool any_nulls = false;
-    for (const RecordBatch& b : bs) {
-        const int ci = Exec::resolve_column(key, b);
-        if (ci < 0) { err = "Column '" + key.name + "' not found in batch"; return false; }
-        if (b.cols[ci].dtype != DType::Int64) { err = "join key '" + key.name + "' must be Int64 (executor.rs:246)"; return false; }
-        any_nulls = any_nulls || !b.cols[ci].in_valid.empty();
-    }
-    for (const RecordBatch& b : bs) {
-        const int ci = Exec::resolve_column(key, b);
-        const size_t o = out.size();
-        out.resize(o + b.num_rows);
-        if (b.num_rows) memcpy(out.data() + o, b.cols[ci].data.data(), b.num_rows * 8);
-        if (any_nulls) {
-            valid.resize(o + b.num_rows, 1);
-            if (!b.cols[ci].in_valid.empty() && b.num_rows) memcpy(valid.data() + o, b.cols[ci].in_valid.data(), b.num_rows);
-        }
-    }
-    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -500,122 +732,112 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
     const size_t nk = p.left_keys.size();
     if (p.right_keys.size() != nk) return herr(GOLAP_ERR_INVALID_ARG, "GpuHashJoin: left_keys and right_keys differ in length");
     if (nk > 4) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: at most 4 key columns");
-    std::vector<std::vector<int64_t>> bkc(nk), pkc(nk);
-    std::vector<std::vector<uint8_t>> bvc(nk), pvc(nk);
-    std::string err;
+    H_TRY(need_ctx());
+    std::vector<RecordBatch*> lb, rb, all;
+    for (RecordBatch& b : left) { lb.push_back(&b); all.push_back(&b); }
+    for (RecordBatch& b : right) { rb.push_back(&b); all.push_back(&b); }
+    // key columns, resolved per batch
+    std::vector<std::vector<int>> lci(nk, std::vector<int>(lb.size())), rci(nk, std::vector<int>(rb.size()));
     for (size_t k = 0; k < nk; ++k) {
         const golap_expr &lk = *p.left_keys[k], &rk = *p.right_keys[k];
         if (lk.kind != golap_expr::Column || rk.kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: key expressions must be column references");
-        if (!concat_i64(left, lk, bkc[k], bvc[k], err) || !concat_i64(right, rk, pkc[k], pvc[k], err)) return herr(GOLAP_ERR_INVALID_ARG, err);
+        for (int side = 0; side < 2; ++side) {
+            const std::vector<RecordBatch*>& bs = side ? rb : lb;
+            const golap_expr& key = side ? rk : lk;
+            for (size_t i = 0; i < bs.size(); ++i) {
+                const int ci = resolve_column(key, *bs[i]);
+                if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + key.name + "' not found in batch");
+                const DType d = bs[i]->cols[ci].dtype;
+                if (d != DType::Int64 && d != DType::Utf8) return herr(GOLAP_ERR_INVALID_ARG, "join key '" + key.name + "' must be Int64 (executor.rs:246)");
+                (side ? rci : lci)[k][i] = ci;
+            }
+        }
     }
-    const uint64_t nb = bkc[0].size(), np = pkc[0].size();   // global row index = running offset over batches (:249, :252)
-    RecordBatch ob;
     // output schema: left fields then right fields
-    for (const Column& c : left[0].cols) { Column oc; oc.name = c.name; oc.dtype = c.dtype; ob.cols.push_back(oc); }
+    RecordBatch ob;
+    for (const Column& c : left[0].cols) { Column oc; oc.name = c.name; oc.dtype = c.dtype == DType::Utf8 ? DType::Int64 : c.dtype; ob.cols.push_back(oc); }
     const size_t n_left_cols = ob.cols.size();
-    for (const Column& c : right[0].cols) { Column oc; oc.name = c.name; oc.dtype = c.dtype; ob.cols.push_back(oc); }
+    for (const Column& c : right[0].cols) { Column oc; oc.name = c.name; oc.dtype = c.dtype == DType::Utf8 ? DType::Int64 : c.dtype; ob.cols.push_back(oc); }
     for (const Column& c : ob.cols)
-        if (c.dtype != DType::Int64 && c.dtype != DType::Float64) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: payload column '" + c.name + "' is neither Int64 nor Float64");
+        if (!is_numeric(c.dtype)) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: payload column '" + c.name + "' has no device representation");
+    for (int side = 0; side < 2; ++side)
+        for (const RecordBatch* b : side ? rb : lb) {
+            const RecordBatch& first = side ? right[0] : left[0];
+            if (b->cols.size() != first.cols.size()) return herr(GOLAP_ERR_INVALID_ARG, "batches of one side differ in schema");
+            for (size_t c = 0; c < b->cols.size(); ++c)
+                if (is_float(b->cols[c].dtype) != is_float(first.cols[c].dtype)) return herr(GOLAP_ERR_INVALID_ARG, "batches of one side differ in schema");
+        }
+    uint64_t nb = 0, np = 0;   // global row index = running offset over batches (:249, :252)
+    for (const RecordBatch* b : lb) nb += b->num_rows;
+    for (const RecordBatch* b : rb) np += b->num_rows;
+    H_TRY(to_device(all));
     uint64_t m = 0;
-    DevBuf dpairs;
+    DevPtr dpairs;
     const bool outer_keeps_something = (nb && (p.join_type == GOLAP_JOIN_LEFT || p.join_type == GOLAP_JOIN_FULL)) ||
                                        (np && (p.join_type == GOLAP_JOIN_RIGHT || p.join_type == GOLAP_JOIN_FULL));
     if ((nb && np) || outer_keeps_something) {
-        DevBuf dcnt;
-        std::vector<DevBuf> db(nk), dp(nk), dbv(nk), dpv(nk);
-        H_TRY(dcnt.alloc(ctx, 8));
+        std::vector<Cat> bk(nk), pk(nk);
+        DevPtr dummy;
+        H_TRY(temp(dummy, 8));
         for (size_t k = 0; k < nk; ++k) {
-            H_TRY(db[k].alloc(ctx, nb * 8));
-            H_TRY(dp[k].alloc(ctx, np * 8));
-            H_TRY(h2d(bkc[k].data(), db[k].ptr, nb * 8));
-            H_TRY(h2d(pkc[k].data(), dp[k].ptr, np * 8));
-            if (!bvc[k].empty()) { H_TRY(dbv[k].alloc(ctx, nb)); H_TRY(h2d(bvc[k].data(), dbv[k].ptr, nb)); }
-            if (!pvc[k].empty()) { H_TRY(dpv[k].alloc(ctx, np)); H_TRY(h2d(pvc[k].data(), dpv[k].ptr, np)); }
+            H_TRY(concat(lb, lci[k], nb, bk[k]));
+            H_TRY(concat(rb, rci[k], np, pk[k]));
+            if (!nb) bk[k].ptr = dummy->ptr;     // (an empty side of an outer join: no row is read, the pointer just must not be null)
+            if (!np) pk[k].ptr = dummy->ptr;
         }
-        H_TRY(xsync());
+        DevPtr dcnt;
+        H_TRY(temp(dcnt, 8));
         uint64_t cap = std::max<uint64_t>(np + ((p.join_type & 1) ? nb : 0), 1);   // first guess; the count is the TRUE total (join_kernels.cuh:155-160)
         for (int attempt = 0; attempt < 2; ++attempt) {
-            H_TRY(dpairs.alloc(ctx, cap * 8));
+            H_TRY(temp(dpairs, cap * 8));
             golap_join_params jp;
             memset(&jp, 0, sizeof jp);
-            jp.build_key_ptr = db[0].ptr; jp.probe_key_ptr = dp[0].ptr; jp.n_build = nb; jp.n_probe = np;
-            jp.out_pairs_ptr = dpairs.ptr; jp.out_count_ptr = dcnt.ptr; jp.max_pairs = cap;
+            jp.build_key_ptr = bk[0].ptr; jp.probe_key_ptr = pk[0].ptr; jp.n_build = nb; jp.n_probe = np;
+            jp.out_pairs_ptr = dpairs->ptr; jp.out_count_ptr = dcnt->ptr; jp.max_pairs = cap;
             jp.join_type = (int32_t)p.join_type;
             jp.n_key_cols = (uint32_t)nk;
             for (size_t k = 0; k < nk; ++k) {
-                if (k) { jp.build_key_extra[k - 1] = db[k].ptr; jp.probe_key_extra[k - 1] = dp[k].ptr; }
-                jp.build_validity[k] = bvc[k].empty() ? 0 : dbv[k].ptr;
-                jp.probe_validity[k] = pvc[k].empty() ? 0 : dpv[k].ptr;
+                if (k) { jp.build_key_extra[k - 1] = bk[k].ptr; jp.probe_key_extra[k - 1] = pk[k].ptr; }
+                jp.build_validity[k] = bk[k].vptr;
+                jp.probe_validity[k] = pk[k].vptr;
             }
             H_TRY(golap_join(ctx, golap_choose_strategy(nb), &jp, nullptr));   // JoinKernel::choose_strategy, join_kernel.rs:71-77
-            H_TRY(ksync());
-            H_TRY(d2h(dcnt.ptr, &m, 8));
-            H_TRY(xsync());
+            H_TRY(read_u64(dcnt->ptr, &m));
             if (m <= cap) break;
-            DevBuf old = std::move(dpairs);   // too small: release, then retry with the exact size
-            cap = m;
+            cap = m;   // too small: retry with the exact size (the first buffer goes back to the pool at the end of the operator)
         }
     }
     ob.num_rows = m;
+    for (Column& c : ob.cols) { c.rows = m; c.where = m ? Column::Device : Column::Host; }
     if (m) {
-        // split the interleaved pairs into two index vectors on the host, then gather every payload column on the device
-        std::vector<uint32_t> pairs(2 * m), lidx(m), ridx(m);
-        H_TRY(d2h(dpairs.ptr, pairs.data(), m * 8));
-        H_TRY(xsync());
-        // canonical order (probe_rid, build_rid): the device order is unspecified (join_kernels.cuh:155)
-        std::vector<uint64_t> keyed(m);
-        for (uint64_t i = 0; i < m; ++i) keyed[i] = ((uint64_t)pairs[2 * i + 1] << 32) | pairs[2 * i];
-        std::sort(keyed.begin(), keyed.end());
-        for (uint64_t i = 0; i < m; ++i) { lidx[i] = (uint32_t)keyed[i]; ridx[i] = (uint32_t)(keyed[i] >> 32); }
-        DevBuf dl, dr;
-        H_TRY(dl.alloc(ctx, m * 4));
-        H_TRY(dr.alloc(ctx, m * 4));
-        H_TRY(h2d(lidx.data(), dl.ptr, m * 4));
-        H_TRY(h2d(ridx.data(), dr.ptr, m * 4));
-        H_TRY(xsync());
+        // canonical order (probe_rid, build_rid): the device order is unspecified (join_kernels.cuh:155) -- sorted, split into one index
+        // vector per side and used for the gathers without leaving the device
+        H_TRY(golap_sort_u64(ctx, dpairs->ptr, m, nullptr));
+        DevPtr dl, dr;
+        H_TRY(temp(dl, m * 4));
+        H_TRY(temp(dr, m * 4));
+        H_TRY(golap_pairs_unzip(ctx, dpairs->ptr, m, dl->ptr, dr->ptr, nullptr));
         for (size_t c = 0; c < ob.cols.size(); ++c) {
             const bool is_left = c < n_left_cols;
-            const std::vector<RecordBatch>& side = is_left ? left : right;
-            const size_t sc = is_left ? c : c - n_left_cols;
+            const std::vector<RecordBatch*>& side = is_left ? lb : rb;
+            const int sc = (int)(is_left ? c : c - n_left_cols);
             const uint64_t rows = is_left ? nb : np;
-            std::vector<uint8_t> whole(rows * 8), src_valid;
-            size_t o = 0;
-            bool src_nulls = false;
-            for (const RecordBatch& b : side) src_nulls = src_nulls || (sc < b.cols.size() && !b.cols[sc].in_valid.empty());
-            if (src_nulls) src_valid.assign(rows, 1);
-            for (const RecordBatch& b : side) {
-                if (sc >= b.cols.size() || b.cols[sc].dtype != ob.cols[c].dtype) return herr(GOLAP_ERR_INVALID_ARG, "batches of one side differ in schema");
-                if (b.num_rows) memcpy(whole.data() + o, b.cols[sc].data.data(), b.num_rows * 8);
-                if (src_nulls && !b.cols[sc].in_valid.empty() && b.num_rows) memcpy(src_valid.data() + o / 8, b.cols[sc].in_valid.data(), b.num_rows);
-                o += b.num_rows * 8;
+            Cat src;
+            H_TRY(concat(side, std::vector<int>(side.size(), sc), rows, src));
+            const uint64_t idx = is_left ? dl->ptr : dr->ptr;
+            H_TRY(dev_alloc(ob.cols[c].d_data, m * 8));
+            if (rows) H_TRY(golap_take_8byte(ctx, src.ptr, idx, 0, m, ob.cols[c].d_data->ptr, nullptr));
+            else H_TRY(golap_device_fill_u8(ctx, ob.cols[c].d_data->ptr, 0, m * 8, nullptr));
+            // rows whose source side is missing (NULL row id of an outer join) or whose source row is NULL become Arrow nulls
+            const bool missing_side = is_left ? (p.join_type & 2) != 0 : (p.join_type & 1) != 0;
+            if (src.vptr || missing_side) {
+                H_TRY(dev_alloc(ob.cols[c].d_valid, m));
+                H_TRY(golap_take_1byte(ctx, src.vptr, idx, 0, m, ob.cols[c].d_valid->ptr, nullptr));
             }
-            DevBuf dcol, dout;
-            H_TRY(dcol.alloc(ctx, rows * 8));
-            H_TRY(dout.alloc(ctx, m * 8));
-            H_TRY(h2d(whole.data(), dcol.ptr, rows * 8));
-            H_TRY(xsync());
-            H_TRY(golap_take_8byte(ctx, dcol.ptr, is_left ? dl.ptr : dr.ptr, 0, m, dout.ptr, nullptr));
-            H_TRY(ksync());
-            ob.cols[c].rows = m;
-            {   // rows whose source side is missing (NULL row id of an outer join) become Arrow nulls
-                const std::vector<uint32_t>& ix = is_left ? lidx : ridx;
-                uint64_t nulls = 0;
-                auto is_null = [&](uint64_t i) { return ix[i] == 0xFFFFFFFFu || (src_nulls && !src_valid[ix[i]]); };   // missing side, or a NULL in the source row
-                for (uint64_t i = 0; i < m; ++i) nulls += is_null(i);
-                if (nulls) {
-                    ob.cols[c].null_count = nulls;
-                    ob.cols[c].valid.assign((m + 7) / 8, 0);
-                    for (uint64_t i = 0; i < m; ++i)
-                        if (!is_null(i)) ob.cols[c].valid[i >> 3] |= (uint8_t)(1u << (i & 7));
-                }
-            }
-            ob.cols[c].data.resize(m * 8);
-            H_TRY(d2h(dout.ptr, ob.cols[c].data.data(), m * 8));
-            H_TRY(xsync());
         }
     }
     out.push_back(std::move(ob));   // one batch, like the reference's single output batch (:262-264)
-    return GOLAP_OK;
+    return end_op();
 }
 
 static const char* agg_name(int32_t f) {
@@ -625,437 +847,273 @@ static const char* agg_name(int32_t f) {
 // ---------------------------------------------------------------------------
 // execute_aggregate, executor.rs:297-355 (+ eval_agg_input :509-527)
 // ---------------------------------------------------------------------------
-// rows `idx` of a batch (host side; values, widths and validity bytes travel together)
-static RecordBatch take_rows(const RecordBatch& b, const std::vector<uint64_t>& idx) {
-    RecordBatch o;
-    o.num_rows = idx.size();
-    for (const Column& c : b.cols) {
-        Column oc;
-        oc.name = c.name; oc.dtype = c.dtype; oc.rows = idx.size();
-        const size_t w = c.width();
-        oc.data.resize(idx.size() * w);
-        for (size_t i = 0; i < idx.size(); ++i) memcpy(oc.data.data() + i * w, c.data.data() + idx[i] * w, w);
-        if (!c.in_valid.empty()) {
-            oc.in_valid.resize(idx.size());
-            for (size_t i = 0; i < idx.size(); ++i) oc.in_valid[i] = c.in_valid[idx[i]];
-        }
-        o.cols.push_back(std::move(oc));
-    }
-    return o;
-}
-
-// GROUP BY over several columns (physical_plan.rs:52-54: group_by is a Vec<PhysicalExpr>; lowering :157-172 keeps every column; the
-// reference's executor ignores it, executor.rs:307).  The columns are Int64 / Int32, so a row's composite key is a mixed-radix number:
-// digit_c = value - min_c (NULL: one past the column's largest digit -- NULLs sort last, and (NULL, 1) is a group of its own), weight_c
-// = the product of the later columns' digit counts.  While that number fits 62 bits -- dictionary-like ids, dates, small codes: the
-// usual GROUP BY columns -- it IS a single Int64 key: exact, no collisions, and the one-column path below (dense or hashed) does the
-// rest; the result's packed key column is unpacked into the key columns again.  Wider composites are refused with their sizes.
-int32_t Exec::aggregate_multi_key(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out) {
-    const size_t K = p.group_by.size();
-    const uint32_t na = (uint32_t)p.aggr_inputs.size();
-    uint64_t n = 0;
-    for (const RecordBatch& b : in) n += b.num_rows;
-    std::vector<std::vector<int64_t>> vals(K);
-    std::vector<std::vector<uint8_t>> valid(K);
-    std::vector<int64_t> mn(K, INT64_MAX), mx(K, INT64_MIN);
-    std::vector<bool> has_null(K, false);
-    for (size_t c = 0; c < K; ++c) {
-        if (p.group_by[c]->kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group-by expressions must be column references");
-        vals[c].reserve(n);
-        valid[c].reserve(n);
-        for (const RecordBatch& b : in) {
-            const int ci = resolve_column(*p.group_by[c], b);
-            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + p.group_by[c]->name + "' not found in batch");
-            const Column& col = b.cols[ci];
-            if (col.dtype != DType::Int64 && col.dtype != DType::Int32) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group key must be Int64 or Int32");
-            for (uint64_t i = 0; i < b.num_rows; ++i) {
-                const int64_t v = col.dtype == DType::Int64 ? ((const int64_t*)col.data.data())[i] : (int64_t)((const int32_t*)col.data.data())[i];
-                const uint8_t ok = col.in_valid.empty() ? 1 : col.in_valid[i];
-                vals[c].push_back(v);
-                valid[c].push_back(ok);
-                if (ok) { mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); } else has_null[c] = true;
-            }
-        }
-        if (mn[c] > mx[c]) mn[c] = mx[c] = 0;   // no valid value at all
-    }
-    // digit counts and weights (first column most significant: rows come out sorted by (k0, k1, ...), NULLS LAST per column)
-    std::vector<unsigned __int128> digits(K);
-    std::vector<uint64_t> weight(K, 1);
-    unsigned __int128 total = 1;
-    for (size_t c = K; c-- > 0;) {
-        digits[c] = (unsigned __int128)((__int128)mx[c] - (__int128)mn[c]) + 1 + (has_null[c] ? 1 : 0);
-        weight[c] = (uint64_t)total;
-        total *= digits[c];
-        if (total > ((unsigned __int128)1 << 62)) {
-            std::string sizes;
-            for (size_t k = 0; k < K; ++k) sizes += (k ? " x " : "") + std::to_string((double)((__int128)mx[k] - (__int128)mn[k]) + 1.0);
-            return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: the composite group key does not fit 62 bits (value ranges " + sizes + ")");
-        }
-    }
-    // one packed Int64 key column per batch, under a name no input column has
-    const std::string pk = "__golap_group_key";
-    uint64_t o = 0;
-    for (RecordBatch& b : in) {
-        Column kc;
-        kc.name = pk; kc.dtype = DType::Int64; kc.rows = b.num_rows;
-        kc.data.resize(b.num_rows * 8);
-        int64_t* d = (int64_t*)kc.data.data();
-        for (uint64_t i = 0; i < b.num_rows; ++i) {
-            uint64_t key = 0;
-            for (size_t c = 0; c < K; ++c) {
-                const uint64_t dg = valid[c][o + i] ? (uint64_t)(vals[c][o + i] - mn[c]) : (uint64_t)(digits[c] - 1);
-                key += dg * weight[c];
-            }
-            d[i] = (int64_t)key;
-        }
-        o += b.num_rows;
-        b.cols.push_back(std::move(kc));
-    }
-    auto gb = std::move(p.group_by);
-    p.group_by.clear();
-    p.group_by.emplace_back(new golap_expr());
-    p.group_by[0]->kind = golap_expr::Column;
-    p.group_by[0]->name = pk;
-    std::vector<RecordBatch> g;
-    const int32_t rc = aggregate(in, p, g);
-    p.group_by = std::move(gb);
-    for (RecordBatch& b : in) b.cols.pop_back();
-    H_TRY(rc);
-    if (g.empty() || g[0].cols.size() != 1 + (size_t)na) return herr(GOLAP_ERR_INVALID_ARG, "GpuAggregate: unexpected grouped result");
-    RecordBatch ob;
-    ob.num_rows = g[0].num_rows;
-    const int64_t* packed = (const int64_t*)g[0].cols[0].data.data();
-    for (size_t c = 0; c < K; ++c) {
-        Column kc;
-        kc.name = p.group_by[c]->name; kc.dtype = DType::Int64; kc.rows = ob.num_rows;
-        kc.data.resize(ob.num_rows * 8);
-        if (has_null[c]) kc.in_valid.assign(ob.num_rows, 1);
-        int64_t* d = (int64_t*)kc.data.data();
-        for (uint64_t i = 0; i < ob.num_rows; ++i) {
-            const uint64_t dg = (uint64_t)(((unsigned __int128)(uint64_t)packed[i] / weight[c]) % digits[c]);
-            if (has_null[c] && dg == (uint64_t)(digits[c] - 1)) { d[i] = 0; kc.in_valid[i] = 0; }
-            else d[i] = mn[c] + (int64_t)dg;
-        }
-        ob.cols.push_back(std::move(kc));
-    }
-    for (uint32_t i = 0; i < na; ++i) ob.cols.push_back(std::move(g[0].cols[1 + i]));
-    out.push_back(std::move(ob));
-    return GOLAP_OK;
-}
-
+// GROUP BY (physical_plan.rs:52-54: group_by is a Vec<PhysicalExpr>; lowering :157-172 keeps every column; the reference's executor
+// ignores it, executor.rs:307).  Key columns are Int64 / Int32 (and string hashes), so a row's key -- one column or several, with or
+// without NULLs -- is a mixed-radix number: digit_c = value - min_c (NULL: one past the column's largest digit -- NULLs sort last, and
+// (NULL, 1) is a group of its own), weight_c = the product of the later columns' digit counts.  While that number fits 62 bits --
+// dictionary-like ids, dates, small codes: the usual GROUP BY columns -- it IS a single Int64 key without NULLs: exact, no collisions.
+// Ranges come from golap_key_minmax (exact int64, NULL-aware), the packing is golap_pack_group_keys, both on the device; a single
+// key column without NULLs is used as it is.  The group table is unpacked into the key columns again on the host (result-sized).
 int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out) {
     const uint32_t na = (uint32_t)p.aggr_inputs.size();
-    if (p.group_by.size() > 1) return aggregate_multi_key(in, p, out);
-    // NULL group keys: SQL puts them into ONE group of their own.  Only when the key column really carries NULLs: the rows are
-    // split on the host, the rows with a key take the ordinary path below, the others an ungrouped aggregate, and the result
-    // gets one more row whose key is NULL (last, like NULLS LAST).
-    if (p.group_by.size() == 1 && p.group_by[0]->kind == golap_expr::Column) {
-        bool key_nulls = false;
-        for (const RecordBatch& b : in) {
-            const int ci = resolve_column(*p.group_by[0], b);
-            if (ci >= 0 && !b.cols[ci].in_valid.empty())
-                for (uint8_t v : b.cols[ci].in_valid) if (!v) { key_nulls = true; break; }
-            if (key_nulls) break;
-        }
-        if (key_nulls) {
-            std::vector<RecordBatch> with_key, without_key;
-            for (const RecordBatch& b : in) {
-                const int ci = resolve_column(*p.group_by[0], b);
-                if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + p.group_by[0]->name + "' not found in batch");
-                std::vector<uint64_t> yes, no;
-                const std::vector<uint8_t>& kv = b.cols[ci].in_valid;
-                for (uint64_t i = 0; i < b.num_rows; ++i) (kv.empty() || kv[i] ? yes : no).push_back(i);
-                RecordBatch y = take_rows(b, yes), n = take_rows(b, no);
-                y.cols[ci].in_valid.clear();              // no NULL keys left on this side
-                with_key.push_back(std::move(y));
-                without_key.push_back(std::move(n));
-            }
-            std::vector<RecordBatch> g, u;
-            H_TRY(aggregate(with_key, p, g));
-            auto gb = std::move(p.group_by);
-            p.group_by.clear();
-            const int32_t rc = aggregate(without_key, p, u);   // one row: the aggregates over the rows whose key is NULL
-            p.group_by = std::move(gb);
-            H_TRY(rc);
-            RecordBatch ob = g.empty() ? RecordBatch() : std::move(g[0]);
-            if (ob.cols.empty()) return herr(GOLAP_ERR_INVALID_ARG, "GpuAggregate: empty grouped result");
-            Column& kc = ob.cols[0];
-            kc.in_valid.assign(ob.num_rows, 1);
-            kc.in_valid.push_back(0);
-            kc.data.resize(kc.data.size() + 8, 0);
-            for (uint32_t i = 0; i < na; ++i) {
-                Column& ac = ob.cols[1 + i];
-                const Column& uc = u[0].cols[i];
-                ac.data.insert(ac.data.end(), uc.data.begin(), uc.data.begin() + 8);
-                if (!ac.in_valid.empty()) ac.in_valid.push_back(1);
-                ac.rows = ob.num_rows + 1;
-            }
-            ob.num_rows += 1;
-            kc.rows = ob.num_rows;
-            out.push_back(std::move(ob));
-            return GOLAP_OK;
-        }
-    }
-    // gather the distinct value columns the aggregates read
+    const size_t K = p.group_by.size();
+    if (K > 4) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: at most 4 group-by columns");
+    H_TRY(need_ctx());
+    std::vector<RecordBatch*> bs;
+    for (RecordBatch& b : in) bs.push_back(&b);
+    uint64_t n = 0;
+    for (const RecordBatch* b : bs) n += b->num_rows;
+    // the distinct value columns the aggregates read, and the key columns, resolved per batch
     std::vector<std::string> val_names;
+    std::vector<const golap_expr*> val_expr;
     std::vector<uint64_t> spec_col(na);
     for (uint32_t i = 0; i < na; ++i) {
         const golap_expr& e = *p.aggr_inputs[i];
         if (e.kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: aggregate inputs must be column references");
         auto it = std::find(val_names.begin(), val_names.end(), e.name);
-        if (it == val_names.end()) { val_names.push_back(e.name); spec_col[i] = val_names.size() - 1; }
+        if (it == val_names.end()) { val_names.push_back(e.name); val_expr.push_back(&e); spec_col[i] = val_names.size() - 1; }
         else spec_col[i] = (uint64_t)(it - val_names.begin());
     }
-    uint64_t n = 0;
-    for (const RecordBatch& b : in) n += b.num_rows;
     const uint32_t nv = (uint32_t)val_names.size();
-    std::vector<DevBuf> dvals(nv), dvalid(nv);
-    std::vector<uint64_t> vptrs(nv), vvptrs(nv, 0);   // vvptrs: validity of the value columns (0 = that column has no NULLs)
-    std::vector<int32_t> vdt(nv, GOLAP_DT_INT64);
+    std::vector<std::vector<int>> vci(nv, std::vector<int>(bs.size())), kci(K, std::vector<int>(bs.size()));
+    std::vector<int32_t> vdt(std::max<uint32_t>(nv, 1), GOLAP_DT_INT64);
+    for (uint32_t v = 0; v < nv; ++v)
+        for (size_t i = 0; i < bs.size(); ++i) {
+            const int ci = resolve_column(*val_expr[v], *bs[i]);
+            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + val_names[v] + "' not found in batch");
+            const Column& c = bs[i]->cols[ci];
+            if (!is_numeric(c.dtype) || c.dtype == DType::Utf8)
+                return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: input '" + c.name + "' must be Int64 or Float64 (executor.rs:520-526)");
+            vdt[v] = is_float(c.dtype) ? GOLAP_DT_FLOAT64 : GOLAP_DT_INT64;
+            vci[v][i] = ci;
+        }
+    for (size_t k = 0; k < K; ++k) {
+        if (p.group_by[k]->kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group-by expressions must be column references");
+        for (size_t i = 0; i < bs.size(); ++i) {
+            const int ci = resolve_column(*p.group_by[k], *bs[i]);
+            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + p.group_by[k]->name + "' not found in batch");
+            const DType d = bs[i]->cols[ci].dtype;
+            if (is_float(d) || !is_numeric(d)) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group key must be Int64 or Int32");
+            kci[k][i] = ci;
+        }
+    }
+    H_TRY(to_device(bs));
+    std::vector<Cat> vals(nv);
+    std::vector<uint64_t> vptrs(std::max<uint32_t>(nv, 1), 0), vvptrs(std::max<uint32_t>(nv, 1), 0);   // vvptrs: validity of the value columns (0 = that column has no NULLs)
     bool any_value_nulls = false;
     for (uint32_t v = 0; v < nv; ++v) {
-        H_TRY(dvals[v].alloc(ctx, n * 8));
-        vptrs[v] = dvals[v].ptr;
-        uint64_t o = 0;
-        std::vector<uint8_t> valid;   // byte per row over all batches, only when some batch carries NULLs in this column
-        {
-            bool nulls = false;
-            for (const RecordBatch& b : in) {
-                golap_expr e; e.kind = golap_expr::Column; e.name = val_names[v];
-                for (uint32_t i = 0; i < na; ++i) if (p.aggr_inputs[i]->name == val_names[v]) { e.index = p.aggr_inputs[i]->index; break; }
-                const int ci = resolve_column(e, b);
-                if (ci >= 0 && !b.cols[ci].in_valid.empty()) nulls = true;
-            }
-            if (nulls && n) {
-                valid.assign(n, 1);
-                uint64_t ro = 0;
-                for (const RecordBatch& b : in) {
-                    golap_expr e; e.kind = golap_expr::Column; e.name = val_names[v];
-                    for (uint32_t i = 0; i < na; ++i) if (p.aggr_inputs[i]->name == val_names[v]) { e.index = p.aggr_inputs[i]->index; break; }
-                    const int ci = resolve_column(e, b);
-                    if (ci >= 0 && !b.cols[ci].in_valid.empty() && b.num_rows) memcpy(valid.data() + ro, b.cols[ci].in_valid.data(), b.num_rows);
-                    ro += b.num_rows;
-                }
-                H_TRY(dvalid[v].alloc(ctx, n));
-                H_TRY(h2d(valid.data(), dvalid[v].ptr, n));
-                H_TRY(xsync());   // (the host vector goes out of scope below)
-                vvptrs[v] = dvalid[v].ptr;
-                any_value_nulls = true;
-            }
-        }
-        for (const RecordBatch& b : in) {
-            golap_expr e; e.kind = golap_expr::Column; e.name = val_names[v];
-            for (uint32_t i = 0; i < na; ++i) if (p.aggr_inputs[i]->name == val_names[v]) { e.index = p.aggr_inputs[i]->index; break; }
-            const int ci = resolve_column(e, b);
-            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + val_names[v] + "' not found in batch");
-            const Column& c = b.cols[ci];
-            if (c.dtype != DType::Int64 && c.dtype != DType::Float64)
-                return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: input '" + c.name + "' must be Int64 or Float64 (executor.rs:520-526)");
-            vdt[v] = c.dtype == DType::Float64 ? GOLAP_DT_FLOAT64 : GOLAP_DT_INT64;
-            if (b.num_rows) H_TRY(h2d(c.data.data(), dvals[v].ptr + o, b.num_rows * 8));
-            o += b.num_rows * 8;
-        }
+        H_TRY(concat(bs, vci[v], n, vals[v]));
+        vptrs[v] = vals[v].ptr;
+        vvptrs[v] = vals[v].vptr;
+        any_value_nulls = any_value_nulls || vals[v].vptr;
     }
     std::vector<golap_aggregate_spec> specs(na);
     for (uint32_t i = 0; i < na; ++i) specs[i] = golap_aggregate_spec{p.aggr_funcs[i], spec_col[i], i};
+    auto agg_col = [&](uint32_t i) {
+        Column c;
+        c.name = std::string(agg_name(p.aggr_funcs[i])) + "(" + p.aggr_inputs[i]->name + ")";
+        c.dtype = DType::Float64; c.where = Column::Host;
+        return c;
+    };
     RecordBatch ob;
-    if (p.group_by.empty()) {
+    golap_aggregate_params ap;
+    if (K == 0) {
         // the reference's single-group result: one Float64 scalar per aggregate (:330-349)
-        DevBuf dout;
-        H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * 8));
-        H_TRY(xsync());
-        golap_aggregate_params ap;
+        DevPtr dout;
+        H_TRY(temp(dout, (uint64_t)std::max<uint32_t>(na, 1) * 8));
         memset(&ap, 0, sizeof ap);
-        ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = 1; ap.out_ptr = dout.ptr;
+        ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = 1; ap.out_ptr = dout->ptr;
         ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;   // SQL aggregates skip NULL values
         ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data();
         H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
-        H_TRY(ksync());
         std::vector<double> res(std::max<uint32_t>(na, 1));
-        H_TRY(d2h(dout.ptr, res.data(), (uint64_t)na * 8));
-        H_TRY(xsync());
+        H_TRY(ksync());
+        down(dout->ptr, res.data(), (uint64_t)na * 8);
+        H_TRY(flush());
         ob.num_rows = 1;
         for (uint32_t i = 0; i < na; ++i) {
-            Column c;
-            c.name = std::string(agg_name(p.aggr_funcs[i])) + "(" + p.aggr_inputs[i]->name + ")";
-            c.dtype = DType::Float64; c.rows = 1;
+            Column c = agg_col(i);
+            c.rows = 1;
             c.data.resize(8);
             memcpy(c.data.data(), &res[i], 8);
             ob.cols.push_back(std::move(c));
         }
         out.push_back(std::move(ob));
-        return GOLAP_OK;
+        return end_op();
     }
-    // GROUP BY one Int64/Int32 key with dense non-negative values: slot = key % n_groups (join_kernels.cuh:230)
-    if (p.group_by.size() != 1 || p.group_by[0]->kind != golap_expr::Column) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: one group-by column is supported");
-    std::vector<int64_t> keys;
-    {
-        keys.reserve(n);
-        for (const RecordBatch& b : in) {
-            const int ci = resolve_column(*p.group_by[0], b);
-            if (ci < 0) return herr(GOLAP_ERR_INVALID_ARG, "Column '" + p.group_by[0]->name + "' not found in batch");
-            const Column& c = b.cols[ci];
-            if (c.dtype == DType::Int64) { const int64_t* k = (const int64_t*)c.data.data(); keys.insert(keys.end(), k, k + b.num_rows); }
-            else if (c.dtype == DType::Int32) { const int32_t* k = (const int32_t*)c.data.data(); for (uint64_t i = 0; i < b.num_rows; ++i) keys.push_back(k[i]); }
-            else return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: group key must be Int64 or Int32");
-        }
-    }
+    // ---- the key: ranges, then (unless it is one plain column) the packed column ----
+    std::vector<Column> kcs(K);
+    for (size_t k = 0; k < K; ++k) { kcs[k].name = p.group_by[k]->name; kcs[k].dtype = DType::Int64; kcs[k].where = Column::Host; }
+    std::vector<Column> acs;
+    for (uint32_t i = 0; i < na; ++i) acs.push_back(agg_col(i));
+    auto finish = [&]() {
+        for (auto& c : kcs) { c.rows = ob.num_rows; ob.cols.push_back(std::move(c)); }
+        for (auto& c : acs) { c.rows = ob.num_rows; ob.cols.push_back(std::move(c)); }
+        out.push_back(std::move(ob));
+        return end_op();
+    };
     ob.num_rows = 0;
-    Column kc; kc.name = p.group_by[0]->name; kc.dtype = DType::Int64;
-    std::vector<Column> acs(na);
-    for (uint32_t i = 0; i < na; ++i) { acs[i].name = std::string(agg_name(p.aggr_funcs[i])) + "(" + p.aggr_inputs[i]->name + ")"; acs[i].dtype = DType::Float64; }
-    if (n) {
-        DevBuf dk, dmm;
-        H_TRY(dk.alloc(ctx, n * 8));
-        H_TRY(dmm.alloc(ctx, 16));
-        H_TRY(h2d(keys.data(), dk.ptr, n * 8));
-        H_TRY(xsync());
-        // key range on the device: ungrouped MIN / MAX of the key column
-        golap_aggregate_spec mm[2] = {{GOLAP_AGG_MIN, 0, 0}, {GOLAP_AGG_MAX, 0, 1}};
-        uint64_t kp = dk.ptr; int32_t kd = GOLAP_DT_INT64;
-        golap_aggregate_params ap;
-        memset(&ap, 0, sizeof ap);
-        ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.n_rows = n; ap.n_groups = 1; ap.out_ptr = dmm.ptr; ap.value_dtypes = &kd;
-        H_TRY(golap_aggregate(ctx, mm, 2, &ap, nullptr));
-        H_TRY(ksync());
-        double mmv[2];
-        H_TRY(d2h(dmm.ptr, mmv, 16));
-        H_TRY(xsync());
-        // dense keys (non-negative, range not much wider than the row count) index the group table directly (slot = key % G,
-        // join_kernels.cuh:230); anything else -- negative, sparse, hash-like keys -- goes through the key -> slot hash table
-        // (GOLAP_KEYS_HASHED, aggregate_kernel.rs:76-77)
-        const bool dense_keys = mmv[0] >= 0 && mmv[1] <= 9e15 && (mmv[1] - mmv[0]) < (double)(64ull << 20) && (mmv[1] - mmv[0]) <= 4.0 * (double)n + 1024.0;
-        if (!dense_keys) {
-            const uint64_t bound = std::min<uint64_t>(n, 1ull << 28);   // distinct keys <= rows; the key table holds at most 2^28 groups
-            DevBuf dout, dcnt, dkeys, dn;
-            H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * bound * 8));
-            H_TRY(dcnt.alloc(ctx, bound * 8));
-            H_TRY(dkeys.alloc(ctx, bound * 8));
-            H_TRY(dn.alloc(ctx, 8));
+    if (n == 0) return finish();
+    std::vector<Cat> keys(K);
+    DevPtr dmm;
+    H_TRY(temp(dmm, K * 24));
+    for (size_t k = 0; k < K; ++k) {
+        H_TRY(concat(bs, kci[k], n, keys[k]));
+        H_TRY(golap_key_minmax(ctx, keys[k].ptr, keys[k].vptr, n, dmm->ptr + k * 24, nullptr));
+    }
+    std::vector<int64_t> mm(K * 3);
+    H_TRY(read_u64(dmm->ptr, (uint64_t*)mm.data(), (uint32_t)(K * 3)));
+    std::vector<int64_t> mn(K), mx(K);
+    std::vector<bool> has_null(K);
+    bool any_key_null = false;
+    for (size_t k = 0; k < K; ++k) {
+        has_null[k] = (uint64_t)mm[3 * k + 2] < n;
+        any_key_null = any_key_null || has_null[k];
+        mn[k] = mm[3 * k]; mx[k] = mm[3 * k + 1];
+        if (mm[3 * k + 2] == 0) mn[k] = mx[k] = 0;   // no valid value at all
+    }
+    const bool packed = K > 1 || any_key_null;
+    // digit counts and weights (first column most significant: rows come out sorted by (k0, k1, ...), NULLS LAST per column)
+    std::vector<unsigned __int128> digits(K);
+    std::vector<uint64_t> weight(K, 1);
+    unsigned __int128 total = 1;
+    if (packed)
+        for (size_t c = K; c-- > 0;) {
+            digits[c] = (unsigned __int128)((__int128)mx[c] - (__int128)mn[c]) + 1 + (has_null[c] ? 1 : 0);
+            weight[c] = (uint64_t)total;
+            total *= digits[c];
+            if (total > ((unsigned __int128)1 << 62)) {
+                std::string sizes;
+                for (size_t k = 0; k < K; ++k) sizes += (k ? " x " : "") + std::to_string((double)((__int128)mx[k] - (__int128)mn[k]) + 1.0);
+                return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: the composite group key does not fit 62 bits (value ranges " + sizes + ")");
+            }
+        }
+    uint64_t key_ptr = keys[0].ptr;
+    int64_t kmin = mn[0], kmax = mx[0];
+    if (packed) {
+        DevPtr dpk;
+        H_TRY(temp(dpk, n * 8));
+        golap_pack_keys_params pk;
+        memset(&pk, 0, sizeof pk);
+        pk.n_cols = (uint32_t)K; pk.n_rows = n; pk.out_ptr = dpk->ptr;
+        for (size_t c = 0; c < K; ++c) {
+            pk.col_ptrs[c] = keys[c].ptr; pk.validity_ptrs[c] = keys[c].vptr; pk.min_value[c] = mn[c]; pk.weight[c] = weight[c];
+            pk.null_digit[c] = (uint64_t)(digits[c] - 1);
+        }
+        H_TRY(golap_pack_group_keys(ctx, &pk, nullptr));
+        key_ptr = dpk->ptr;
+        kmin = 0;
+        kmax = (int64_t)(uint64_t)(total - 1);
+    }
+    // one group key (packed or plain) -> key columns of the result, appended in the order the caller walks the groups
+    auto emit_key = [&](int64_t key) {
+        for (size_t c = 0; c < K; ++c) {
+            int64_t v = key;
+            uint8_t ok = 1;
+            if (packed) {
+                const uint64_t dg = (uint64_t)(((unsigned __int128)(uint64_t)key / weight[c]) % digits[c]);
+                if (has_null[c] && dg == (uint64_t)(digits[c] - 1)) { v = 0; ok = 0; }
+                else v = mn[c] + (int64_t)dg;
+            }
+            kcs[c].data.insert(kcs[c].data.end(), (const uint8_t*)&v, (const uint8_t*)&v + 8);
+            if (has_null[c]) kcs[c].in_valid.push_back(ok);
+        }
+    };
+    int32_t kd = GOLAP_DT_INT64;
+    // dense keys (non-negative, range not much wider than the row count) index the group table directly (slot = key % G,
+    // join_kernels.cuh:230); anything else -- negative, sparse, hash-like keys -- goes through the key -> slot hash table
+    // (GOLAP_KEYS_HASHED, aggregate_kernel.rs:76-77)
+    const unsigned __int128 span = (unsigned __int128)((__int128)kmax - (__int128)kmin);
+    const bool dense_keys = kmin >= 0 && span < (unsigned __int128)(64ull << 20) && span <= (unsigned __int128)(4 * n + 1024);
+    if (!dense_keys) {
+        // the bound on the distinct keys starts modest and grows only when the data asks for it: every buffer below is sized from it
+        uint64_t bound = std::min<uint64_t>(n, 1ull << 22);
+        const uint64_t bound_max = std::min<uint64_t>(n, 1ull << 28);   // distinct keys <= rows; the key table holds at most 2^28 groups
+        for (;;) {
+            DevPtr dout, dcnt, dkeys, dn;
+            H_TRY(temp(dout, (uint64_t)std::max<uint32_t>(na, 1) * bound * 8));
+            H_TRY(temp(dcnt, bound * 8));
+            H_TRY(temp(dkeys, bound * 8));
+            H_TRY(temp(dn, 8));
             memset(&ap, 0, sizeof ap);
-            ap.group_key_ptr = dk.ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)bound;
+            ap.group_key_ptr = key_ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)bound;
             ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;
-            ap.out_ptr = dout.ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt.ptr;
-            ap.key_mode = GOLAP_KEYS_HASHED; ap.out_keys_ptr = dkeys.ptr; ap.out_n_groups_ptr = dn.ptr;
+            ap.out_ptr = dout->ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt->ptr;
+            ap.key_mode = GOLAP_KEYS_HASHED; ap.out_keys_ptr = dkeys->ptr; ap.out_n_groups_ptr = dn->ptr;
             if (na == 0) {
                 golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
-                ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd; ap.value_validity_ptrs = nullptr;
+                ap.value_ptrs = &key_ptr; ap.n_value_cols = 1; ap.value_dtypes = &kd; ap.value_validity_ptrs = nullptr;
                 H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
             } else {
                 H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
             }
-            H_TRY(ksync());
-            uint32_t nd = 0;
-            H_TRY(d2h(dn.ptr, &nd, 4));
-            H_TRY(xsync());
-            if (nd > bound) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^28 distinct group keys");
+            uint64_t nd64 = 0;
+            H_TRY(read_u64(dn->ptr, &nd64));
+            const uint32_t nd = (uint32_t)nd64;
+            if (nd > bound) {   // (0xFFFFFFFF: hopelessly small -- the insert pass gave up early)
+                if (bound >= bound_max) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^28 distinct group keys");
+                bound = std::min<uint64_t>(bound_max, nd == 0xFFFFFFFFu ? bound * 16 : std::max<uint64_t>(bound * 4, (uint64_t)nd + nd / 8));
+                for (DevPtr* d : {&dout, &dcnt, &dkeys, &dn}) drop(*d);   // (the device is idle: the count was just read)
+                continue;
+            }
             std::vector<int64_t> gk(nd);
-            std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * bound);
-            if (nd) H_TRY(d2h(dkeys.ptr, gk.data(), (uint64_t)nd * 8));
-            H_TRY(d2h(dout.ptr, res.data(), res.size() * 8));
-            H_TRY(xsync());
+            std::vector<std::vector<double>> res(std::max<uint32_t>(na, 1), std::vector<double>(nd));   // sized from the groups found, not from the bound
+            down(dkeys->ptr, gk.data(), (uint64_t)nd * 8);
+            for (uint32_t i = 0; i < na; ++i) down(dout->ptr + (uint64_t)i * bound * 8, res[i].data(), (uint64_t)nd * 8);
+            H_TRY(flush());
             std::vector<uint32_t> order(nd);
             for (uint32_t i = 0; i < nd; ++i) order[i] = i;
             std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return gk[a] < gk[b]; });   // rows sorted by key
             for (uint32_t slot : order) {
-                kc.data.insert(kc.data.end(), (const uint8_t*)&gk[slot], (const uint8_t*)&gk[slot] + 8);
-                for (uint32_t i = 0; i < na; ++i) {
-                    const double v = res[(size_t)i * bound + slot];
-                    acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&v, (const uint8_t*)&v + 8);
-                }
+                emit_key(gk[slot]);
+                for (uint32_t i = 0; i < na; ++i) acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&res[i][slot], (const uint8_t*)&res[i][slot] + 8);
                 ob.num_rows++;
             }
-            kc.rows = ob.num_rows;
-            ob.cols.push_back(std::move(kc));
-            for (auto& c : acs) { c.rows = ob.num_rows; ob.cols.push_back(std::move(c)); }
-            out.push_back(std::move(ob));
-            return GOLAP_OK;
-        }
-        const int64_t kmin = (int64_t)mmv[0], kmax = (int64_t)mmv[1];
-        const uint64_t G = (uint64_t)(kmax - kmin) + 1;
-        DevBuf dout, dcnt;
-        H_TRY(dout.alloc(ctx, (uint64_t)std::max<uint32_t>(na, 1) * G * 8));
-        H_TRY(dcnt.alloc(ctx, G * 8));
-        memset(&ap, 0, sizeof ap);
-        ap.group_key_ptr = dk.ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)G;
-        ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;
-        ap.out_ptr = dout.ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt.ptr;
-        if (na == 0) {   // GROUP BY without aggregates: count only, to find the present groups
-            golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
-            ap.value_ptrs = &kp; ap.n_value_cols = 1; ap.value_dtypes = &kd; ap.value_validity_ptrs = nullptr;
-            H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
-        } else {
-            H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
-            if (any_value_nulls) {
-                // out_count counted the non-NULL values of the last column; which groups EXIST is a question about rows: count the
-                // key column (no NULLs) once more into dcnt (a group whose values are all NULL is still a group)
-                DevBuf dtmp;
-                H_TRY(dtmp.alloc(ctx, G * 8));
-                golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
-                golap_aggregate_params cp = ap;
-                cp.value_ptrs = &kp; cp.n_value_cols = 1; cp.value_dtypes = &kd; cp.value_validity_ptrs = nullptr; cp.out_ptr = dtmp.ptr;
-                H_TRY(golap_aggregate(ctx, &cs, 1, &cp, nullptr));
-                H_TRY(ksync());
-            }
-        }
-        H_TRY(ksync());
-        std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * G);
-        std::vector<uint64_t> cnt(G);
-        H_TRY(d2h(dout.ptr, res.data(), res.size() * 8));
-        H_TRY(d2h(dcnt.ptr, cnt.data(), G * 8));
-        H_TRY(xsync());
-        for (int64_t k = kmin; k <= kmax; ++k) {           // rows sorted by key
-            const uint64_t slot = (uint64_t)k % G;
-            if (!cnt[slot]) continue;
-            kc.data.insert(kc.data.end(), (const uint8_t*)&k, (const uint8_t*)&k + 8);
-            for (uint32_t i = 0; i < na; ++i) {
-                const double v = res[(size_t)i * G + slot];
-                acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&v, (const uint8_t*)&v + 8);
-            }
-            ob.num_rows++;
+            return finish();
         }
     }
-    kc.rows = ob.num_rows;
-    ob.cols.push_back(std::move(kc));
-    for (auto& c : acs) { c.rows = ob.num_rows; ob.cols.push_back(std::move(c)); }
-    out.push_back(std::move(ob));
-    return GOLAP_OK;
-}
-
-// record_batch_to_gpu_buffers for Utf8 columns (record_batch_convert.rs:93-97, :112-130): every string column of every input batch
-// becomes its FNV-1a 64 hashes (as Int64, null -> 0) -- on the device: offsets and bytes go up, one thread hashes one value.  From
-// here on the column is what the reference's GPU path sees: an 8-byte key that joins, groups and filters like any Int64 (two different
-// strings with the same 64-bit hash are one key, as in the reference; the column comes back as its hash).
-int32_t Exec::hash_strings(golap_plan& p) {
-    if (p.input) H_TRY(hash_strings(*p.input));
-    if (p.right) H_TRY(hash_strings(*p.right));
-    for (RecordBatch& b : p.batches)
-        for (Column& c : b.cols) {
-            if (c.dtype != DType::Utf8Raw) continue;
-            const uint64_t n = b.num_rows;
-            c.data.assign(n * 8, 0);
-            if (n) {
-                DevBuf doff, dbytes, dvalid, dout;
-                H_TRY(doff.alloc(ctx, (n + 1) * 8));
-                H_TRY(dbytes.alloc(ctx, std::max<size_t>(c.str_bytes.size(), 8)));
-                H_TRY(dout.alloc(ctx, n * 8));
-                H_TRY(h2d(c.str_off.data(), doff.ptr, (n + 1) * 8));
-                if (!c.str_bytes.empty()) H_TRY(h2d(c.str_bytes.data(), dbytes.ptr, c.str_bytes.size()));
-                if (!c.in_valid.empty()) {
-                    H_TRY(dvalid.alloc(ctx, n));
-                    H_TRY(h2d(c.in_valid.data(), dvalid.ptr, n));
-                }
-                H_TRY(xsync());
-                H_TRY(golap_hash_utf8(ctx, doff.ptr, dbytes.ptr, c.in_valid.empty() ? 0 : dvalid.ptr, n, dout.ptr, nullptr));
-                H_TRY(ksync());
-                H_TRY(d2h(dout.ptr, c.data.data(), n * 8));
-                H_TRY(xsync());
-            }
-            c.dtype = DType::Int64;
-            c.str_off.clear(); c.str_off.shrink_to_fit();
-            c.str_bytes.clear(); c.str_bytes.shrink_to_fit();
+    const uint64_t G = (uint64_t)(kmax - kmin) + 1;
+    DevPtr dout, dcnt;
+    H_TRY(temp(dout, (uint64_t)std::max<uint32_t>(na, 1) * G * 8));
+    H_TRY(temp(dcnt, G * 8));
+    memset(&ap, 0, sizeof ap);
+    ap.group_key_ptr = key_ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)G;
+    ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;
+    ap.out_ptr = dout->ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt->ptr;
+    if (na == 0) {   // GROUP BY without aggregates: count only, to find the present groups
+        golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
+        ap.value_ptrs = &key_ptr; ap.n_value_cols = 1; ap.value_dtypes = &kd; ap.value_validity_ptrs = nullptr;
+        H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
+    } else {
+        H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
+        if (any_value_nulls) {
+            // out_count counted the non-NULL values of the last column; which groups EXIST is a question about rows: count the
+            // key column (no NULLs) once more into dcnt (a group whose values are all NULL is still a group)
+            DevPtr dtmp;
+            H_TRY(temp(dtmp, G * 8));
+            golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
+            golap_aggregate_params cp = ap;
+            cp.value_ptrs = &key_ptr; cp.n_value_cols = 1; cp.value_dtypes = &kd; cp.value_validity_ptrs = nullptr; cp.out_ptr = dtmp->ptr;
+            H_TRY(golap_aggregate(ctx, &cs, 1, &cp, nullptr));
         }
-    return GOLAP_OK;
+    }
+    std::vector<double> res((size_t)std::max<uint32_t>(na, 1) * G);
+    std::vector<uint64_t> cnt(G);
+    H_TRY(ksync());
+    down(dout->ptr, res.data(), res.size() * 8);
+    down(dcnt->ptr, cnt.data(), G * 8);
+    H_TRY(flush());
+    for (int64_t k = kmin; k <= kmax; ++k) {           // rows sorted by key
+        const uint64_t slot = (uint64_t)k % G;
+        if (!cnt[slot]) continue;
+        emit_key(k);
+        for (uint32_t i = 0; i < na; ++i) {
+            const double v = res[(size_t)i * G + slot];
+            acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&v, (const uint8_t*)&v + 8);
+        }
+        ob.num_rows++;
+    }
+    return finish();
 }
 
 // GpuExecutor::execute, executor.rs:37-104: children fully materialised before the parent runs
@@ -1126,7 +1184,7 @@ golap_plan* golap_plan_batches(ArrowArray** arrays, ArrowSchema** schemas, uint3
         RecordBatch b;
         if (ok && !import_batch(arrays[i], schemas[i], b, err)) ok = false;
         if (ok) p->batches.push_back(std::move(b));
-        if (arrays[i] && arrays[i]->release) arrays[i]->release(arrays[i]);      // moved in
+        if (arrays[i] && arrays[i]->release) arrays[i]->release(arrays[i]);      // (not imported: released here -- the arrays are consumed either way)
         if (schemas[i] && schemas[i]->release) schemas[i]->release(schemas[i]);
     }
     if (!ok) { g_err = err; return nullptr; }
@@ -1144,6 +1202,7 @@ golap_plan* golap_plan_table_scan(const char* table_name, ArrowSchema* schema) {
             col.name = schema->children[c]->name ? schema->children[c]->name : "";
             const char* f = schema->children[c]->format;
             col.dtype = (f && (!strcmp(f, "g") || !strcmp(f, "f"))) ? DType::Float64 : DType::Int64;
+            col.where = Column::Host;
             b.cols.push_back(col);
         }
     }
@@ -1190,21 +1249,33 @@ const char* golap_host_last_error(void) { return g_err.c_str(); }
 
 int32_t golap_execute(golap_ctx* ctx, golap_plan* plan, golap_result** out_result, uint32_t* out_n) {
     std::unique_ptr<golap_plan> owned(plan);
-    // ctx may be NULL for plans that never touch the device (Batches / TableScan / Sort / Projection);
-    // any device step then fails inside the C ABI with its own "null ctx" error.
+    // ctx may be NULL for plans that never touch the device (Batches / TableScan / Sort / Projection of numeric columns);
+    // any device step then fails with a "needs the device" error: there is no CPU fallback.
     if (!plan || !out_result || !out_n) return herr(GOLAP_ERR_INVALID_ARG, "null argument");
     g_err.clear();
-    Exec ex{ctx};
+    Exec ex;
+    ex.ctx = ctx;
+    const double t0 = now_ms();
     auto res = std::make_unique<golap_result>();
-    int32_t s = ex.hash_strings(*plan);
-    if (s == GOLAP_OK) s = ex.run(*plan, res->batches);
+    int32_t s = ex.run(*plan, res->batches);
+    if (s == GOLAP_OK) s = ex.to_host(res->batches);
+    ex.keep.clear();
     if (s != GOLAP_OK) {
+        if (ctx) (void)golap_ctx_synchronize(ctx, nullptr);   // nothing of this plan may still be running when its buffers go back to the pool
         if (g_err.empty()) g_err = golap_last_error(ctx);
         if (g_err.empty()) g_err = golap_last_error(nullptr);
         return s;
     }
+    ex.prof.total_ms = now_ms() - t0;
+    res->profile = ex.prof;
     *out_n = (uint32_t)res->batches.size();
     *out_result = res.release();
+    return GOLAP_OK;
+}
+
+int32_t golap_result_profile(const golap_result* r, golap_exec_profile* out) {
+    if (!r || !out) return herr(GOLAP_ERR_INVALID_ARG, "null argument");
+    *out = r->profile;
     return GOLAP_OK;
 }
 

@@ -29,6 +29,12 @@ class ArrowArray(C.Structure):
                 ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 
+class ExecProfile(C.Structure):
+    """golap_exec_profile: where the wall-clock time of one golap_execute call went"""
+    _fields_ = [("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("kernel_wait_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 _VP = C.c_void_p
 HOST_SIGNATURES = {
     "golap_expr_column": (_VP, [C.c_uint64, C.c_char_p]),
@@ -45,6 +51,7 @@ HOST_SIGNATURES = {
     "golap_plan_free": (None, [_VP]),
     "golap_execute": (C.c_int32, [_VP, _VP, C.POINTER(_VP), C.POINTER(C.c_uint32)]),
     "golap_result_export": (C.c_int32, [_VP, C.c_uint32, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
+    "golap_result_profile": (C.c_int32, [_VP, C.c_void_p]),
     "golap_result_free": (None, [_VP]),
     "golap_host_last_error": (C.c_char_p, []),
 }
@@ -226,8 +233,9 @@ def _plan(L, p):
     raise TypeError(f"not a PhysicalPlan: {p!r}")
 
 
-def execute(plan, ctx) -> List[pa.RecordBatch]:
-    """executor::execute (executor.rs:15-24): PhysicalPlan -> Vec<RecordBatch>, on the GPU of `ctx`."""
+def execute(plan, ctx, profile: Optional[dict] = None) -> List[pa.RecordBatch]:
+    """executor::execute (executor.rs:15-24): PhysicalPlan -> Vec<RecordBatch>, on the GPU of `ctx`.
+    profile: a dict that receives golap_exec_profile of the call (bytes and wall time of the upload / download phases, total)."""
     L = load_host()
     h = _plan(L, plan)
     res, n = _VP(), C.c_uint32(0)
@@ -236,6 +244,10 @@ def execute(plan, ctx) -> List[pa.RecordBatch]:
         raise OperatorError(st, L.golap_host_last_error().decode(errors="replace"))
     out = []
     try:
+        if profile is not None:
+            pr = ExecProfile()
+            L.golap_result_profile(res, C.byref(pr))
+            profile.update({f: getattr(pr, f) for f, _ in pr._fields_})
         for i in range(n.value):
             a, s = ArrowArray(), ArrowSchema()
             st = L.golap_result_export(res, i, C.byref(a), C.byref(s))

@@ -490,6 +490,45 @@ int32_t golap_hash_utf8(golap_ctx* ctx, uint64_t offsets_ptr, uint64_t data_ptr,
 enum { GOLAP_WIDEN_I8 = 0, GOLAP_WIDEN_I16, GOLAP_WIDEN_I32, GOLAP_WIDEN_I64, GOLAP_WIDEN_U8, GOLAP_WIDEN_U16,
        GOLAP_WIDEN_U32, GOLAP_WIDEN_U64, GOLAP_WIDEN_F32, GOLAP_WIDEN_F64 };
 
+/* ---- device-side ingest and materialisation (ABI 4) ------------------------
+ * What record_batch_convert.rs:35-110 (Arrow -> GPU buffers) and :146-178 (GPU buffers -> Arrow) do in per-value host loops, on the
+ * device: the raw Arrow buffers are uploaded as they are (values at their own width, validity as the BITMAP) and expanded, widened,
+ * gathered and packed where they live.  The operator layer (golap_host.h) is built on these; so is any host that keeps its columns
+ * resident in HBM between operators. */
+/* validity bitmap -> one byte per row: out[i] = bit (bit_offset + i) of the bitmap, LSB first (array.is_valid(i), :36-40) */
+int32_t golap_expand_validity(golap_ctx* ctx, uint64_t bitmap_ptr /*device*/, uint64_t bit_offset, uint64_t n_rows, uint64_t out_ptr /*u8[n_rows]*/, void* stream);
+/* one byte per row -> Arrow validity bitmap (ceil(n_rows / 8) bytes, unused bits 0) and the number of NULL rows (u64, device) */
+int32_t golap_pack_validity(golap_ctx* ctx, uint64_t validity_ptr, uint64_t n_rows, uint64_t out_bitmap_ptr, uint64_t out_null_count_ptr, void* stream);
+/* validity of gathered rows: out[i] = 0 when indices[i] is the NULL row id 0xFFFFFFFF (the missing side of an outer-join row), else
+ * src[indices[i]] != 0; src_ptr = 0: the source column has no NULLs (out[i] = 1).  count_ptr as golap_take_8byte. */
+int32_t golap_take_1byte(golap_ctx* ctx, uint64_t src_ptr, uint64_t indices_ptr, uint64_t count_ptr /*u64 device, or 0*/, uint64_t n_indices_max,
+                         uint64_t out_ptr /*u8*/, void* stream);
+/* (build_rid, probe_rid) pairs -> one u32 index vector per side (left_matches / right_matches, join_kernels.cuh:125-126) */
+int32_t golap_pairs_unzip(golap_ctx* ctx, uint64_t pairs_ptr, uint64_t n_pairs, uint64_t out_build_idx_ptr, uint64_t out_probe_idx_ptr, void* stream);
+/* ascending in-place sort of n 64-bit words (n < 2^32).  A pair list sorted as 64-bit words is in the canonical (probe_rid, build_rid)
+ * order of the parity tests, NULL row ids last: the kernels emit pairs in atomic order (join_kernels.cuh:155). */
+int32_t golap_sort_u64(golap_ctx* ctx, uint64_t ptr, uint64_t n, void* stream);
+/* out[0] = min, out[1] = max (int64, exact), out[2] = number of the valid rows of an int64 column; no valid row: INT64_MAX, INT64_MIN, 0 */
+int32_t golap_key_minmax(golap_ctx* ctx, uint64_t column_ptr, uint64_t validity_ptr /*u8[n] or 0*/, uint64_t n_rows, uint64_t out_ptr /*int64[3] device*/, void* stream);
+/* Composite GROUP BY key of up to 4 int64 columns as ONE exact int64 (physical_plan.rs:52-54 carries a Vec of key columns):
+ * out[i] = sum_c digit_c(i) * weight[c], digit_c = value - min_value[c] for a valid row, null_digit[c] for a NULL one (the caller picks
+ * weights so that the sum is unique per key tuple: a mixed-radix number). */
+typedef struct golap_pack_keys_params {
+    uint64_t col_ptrs[4];        /* device int64[n_rows] */
+    uint64_t validity_ptrs[4];   /* device u8[n_rows] or 0 */
+    int64_t  min_value[4];
+    uint64_t weight[4];
+    uint64_t null_digit[4];
+    uint32_t n_cols;
+    uint32_t reserved0;
+    uint64_t n_rows;
+    uint64_t out_ptr;            /* device int64[n_rows] */
+} golap_pack_keys_params;
+int32_t golap_pack_group_keys(golap_ctx* ctx, const golap_pack_keys_params* params, void* stream);
+/* device -> device copy and byte fill in stream order (concatenating the batches of an operator's input) */
+int32_t golap_device_copy(golap_ctx* ctx, uint64_t src_ptr, uint64_t dst_ptr, uint64_t bytes, void* stream);
+int32_t golap_device_fill_u8(golap_ctx* ctx, uint64_t ptr, uint32_t value, uint64_t bytes, void* stream);
+
 /* ---- synthetic generators --------------------
  * Counter-based, so each GPU produces its own shard.  kind selects the formula. */
 enum {
@@ -513,7 +552,7 @@ int32_t golap_verify_pairs(golap_ctx* ctx, uint64_t pairs_ptr, uint64_t n_pairs,
  * Per-kernel accumulated device time (hipEvent pairs on the launch stream),
  * collected when enable_profiling = 1.  golap_stats_get resolves pending
  * events (synchronises them). */
-#define GOLAP_MAX_KERNEL_STATS 48
+#define GOLAP_MAX_KERNEL_STATS 64
 typedef struct golap_kernel_stat {
     char     name[48];
     uint64_t launches;

@@ -80,6 +80,17 @@ void        golap_plan_free(golap_plan* p);
  * handle must be freed with golap_result_free.  Errors: status != 0 and golap_last_error(ctx). */
 typedef struct golap_result golap_result;
 int32_t golap_execute(golap_ctx* ctx, golap_plan* plan, golap_result** out_result, uint32_t* out_n_batches);
+/* Where the wall-clock time of the golap_execute call behind this result went.  Columns are device-resident between operators: an
+ * operator uploads what is not in HBM yet (every transfer of that phase queued on the TransferQueue's streams, one wait), runs its
+ * kernels, and reads back counts; the final result is downloaded once.  ("H2D excluded and reported separately".) */
+typedef struct golap_exec_profile {
+    uint64_t h2d_bytes, d2h_bytes;
+    double   h2d_ms;           /* wall time of the upload phases (enqueue from several host threads + the one wait) */
+    double   d2h_ms;           /* wall time of the download phases (counts, group tables, the final result) */
+    double   kernel_wait_ms;   /* wall time the host spent waiting for the device's compute stream */
+    double   total_ms;         /* the whole call */
+} golap_exec_profile;
+int32_t golap_result_profile(const golap_result* r, golap_exec_profile* out);
 /* Moves batch i out as an Arrow struct array (the caller releases it through the Arrow callbacks). */
 int32_t golap_result_export(golap_result* r, uint32_t i, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 void    golap_result_free(golap_result* r);

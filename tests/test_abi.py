@@ -53,7 +53,7 @@ def test_struct_layouts_match_ctypes(tmp_path, lib):
              "golap_partition_params": N.PartitionParams, "golap_partitioned_side": N.PartitionedSide,
              "golap_join_partitioned_params": N.JoinPartitionedParams, "golap_aggregate_spec": N.AggregateSpec,
              "golap_aggregate_params": N.AggregateParams, "golap_kernel_stat": N.KernelStat, "golap_stats": N.Stats, "golap_join_plan": N.JoinPlan,
-             "golap_join_partitioned_plan": N.JoinPartitionedPlan}
+             "golap_join_partitioned_plan": N.JoinPartitionedPlan, "golap_pack_keys_params": N.PackKeysParams}
     body = "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names)
     c = tmp_path / "s.c"
     c.write_text(f'#include <stdio.h>\n#include "golap.h"\nint main(void){{{body} return 0;}}\n')

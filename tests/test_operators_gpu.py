@@ -470,3 +470,66 @@ def test_string_keys_join_and_group_by(ctx):
     for x, a in zip(lk, lv):
         s = sums.setdefault(h(x), [0.0, 0.0]); s[0] += a; s[1] += 1
     assert dict(zip(g.column(0).to_pylist(), zip(g.column(1).to_pylist(), g.column(2).to_pylist()))) == {k: tuple(v) for k, v in sums.items()}
+
+
+def test_narrow_types_offsets_and_bitmaps_are_ingested_on_the_device(ctx):
+    """record_batch_convert.rs:35-110 on the device: Int8 ... UInt32 / Float32 columns are uploaded at their own width and widened there
+    (int -> Int64, Float32 -> Float64), validity travels as the Arrow BITMAP (sliced batches: a bit offset that is not a multiple of 8)
+    and is expanded there, NULL slots hold 0 (:102-110).  Filter keeps rows with k < 50; every payload column comes back widened."""
+    rng = np.random.default_rng(41)
+    n, off = 10_007, 13
+    k = rng.integers(0, 100, n).astype(np.int64)
+    cols = {"i8": (rng.integers(-128, 128, n).astype(np.int8), pa.int8()), "i16": (rng.integers(-30000, 30000, n).astype(np.int16), pa.int16()),
+            "i32": (rng.integers(-2**31, 2**31, n).astype(np.int32), pa.int32()), "u8": (rng.integers(0, 256, n).astype(np.uint8), pa.uint8()),
+            "u16": (rng.integers(0, 65536, n).astype(np.uint16), pa.uint16()), "u32": (rng.integers(0, 2**32, n).astype(np.uint32), pa.uint32()),
+            "f32": (rng.random(n).astype(np.float32), pa.float32()), "f64": (rng.random(n), pa.float64())}
+    nulls = {nm: rng.random(n) < 0.15 for nm in cols}
+    arrays = [pa.array(k)] + [pa.array([None if m else x.item() for x, m in zip(v, nulls[nm])], t) for nm, (v, t) in cols.items()]
+    full = pa.RecordBatch.from_arrays(arrays, names=["k"] + list(cols))
+    batch = full.slice(off, n - off - 3)                                       # offset 13: bitmaps start in the middle of a byte
+    out = O.execute(O.GpuFilter(O.Batches([batch]), O.BinaryExpr(O.Column(0, "k"), "<", O.Literal("50"))), ctx)[0]
+    sel = np.nonzero(k[off:n - 3] < 50)[0] + off
+    assert out.num_rows == sel.size and out.column(0).to_pylist() == k[sel].tolist()
+    for j, (nm, (v, t)) in enumerate(cols.items(), start=1):
+        want_type = pa.float64() if nm in ("f32", "f64") else pa.int64()
+        assert out.schema.field(j).type == want_type, nm
+        exp = [None if nulls[nm][i] else (float(v[i]) if nm in ("f32", "f64") else int(v[i])) for i in sel]
+        assert out.column(j).to_pylist() == exp, nm
+        raw = np.frombuffer(out.column(j).buffers()[1], dtype=np.float64 if nm in ("f32", "f64") else np.int64, count=sel.size)
+        assert not raw[nulls[nm][sel]].any(), nm                                 # null -> 0 in the value buffer
+
+
+def test_filter_join_aggregate_plan_stays_on_the_device(ctx):
+    """GpuAggregate{ GpuHashJoin{ GpuFilter{orders}, customers } } over multi-batch inputs with NULLs: every input column is uploaded
+    ONCE (the profile's H2D bytes are the Arrow buffers' bytes), nothing but counts and the result comes back, the answer is numpy's."""
+    rng = np.random.default_rng(17)
+    n_o, n_c = 400_000, 5_000
+    o_cust = rng.integers(0, n_c + 500, n_o).astype(np.int64)                   # some orders reference nobody
+    o_amt = rng.integers(1, 1000, n_o).astype(np.float64)
+    o_flag = rng.integers(0, 10, n_o).astype(np.int64)
+    amt_null = rng.random(n_o) < 0.05
+    c_id = rng.permutation(n_c).astype(np.int64)
+    c_seg = rng.integers(0, 7, n_c).astype(np.int32)
+    amt = pa.array([None if m else x for x, m in zip(o_amt.tolist(), amt_null)], pa.float64())
+    cut = 150_000
+    orders = [pa.RecordBatch.from_arrays([pa.array(o_cust[:cut]), amt[:cut], pa.array(o_flag[:cut])], names=["cust", "amt", "flag"]),
+              pa.RecordBatch.from_arrays([pa.array(o_cust[cut:]), amt[cut:], pa.array(o_flag[cut:])], names=["cust", "amt", "flag"])]
+    customers = [pa.RecordBatch.from_arrays([pa.array(c_id), pa.array(c_seg)], names=["id", "seg"])]
+    plan = O.GpuAggregate(O.GpuHashJoin(O.Batches(customers), O.GpuFilter(O.Batches(orders), O.BinaryExpr(O.Column(2, "flag"), "<", O.Literal("5"))),
+                                        [O.Column(0, "id")], [O.Column(0, "cust")]),
+                          [O.Column(1, "seg")], [O.Sum(O.Column(3, "amt")), O.Count(O.Column(3, "amt"))])
+    prof = {}
+    out = O.execute(plan, ctx, profile=prof)[0]
+    keep = (o_flag < 5) & (o_cust < n_c)
+    seg_of = np.empty(n_c, np.int64)
+    seg_of[c_id] = c_seg
+    seg = seg_of[o_cust[keep]]
+    live = ~amt_null[keep]
+    exp_sum = np.bincount(seg[live], weights=o_amt[keep][live], minlength=7)
+    exp_cnt = np.bincount(seg[live], minlength=7).astype(np.float64)
+    assert out.column(0).to_pylist() == list(range(7))
+    assert np.array_equal(out.column(1).to_numpy(), exp_sum) and np.array_equal(out.column(2).to_numpy(), exp_cnt)
+    arrow_bytes = n_o * 8 * 3 + (n_o + 7) // 8 + n_c * 8 + n_c * 4
+    assert arrow_bytes <= prof["h2d_bytes"] <= arrow_bytes + 4096, prof       # each column once, at its Arrow width, validity as a bitmap
+    assert prof["d2h_bytes"] < 64 * 1024, prof                                 # counts, key ranges, a 7-row group table -- no row-id list, no column
+    assert prof["total_ms"] > 0 and prof["h2d_ms"] > 0
