@@ -35,9 +35,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C5", choices=["C5", "C3", "C4", "C4L", "C1"],
+    ap.add_argument("--config", default="C5", choices=["C5", "C3", "C4", "C4L", "C1", "OP"],
                     help="C5 1Bx1B join (default) | C3 100Mx100M join | C4 1B-row GROUP BY int32 -> SUM(f64), 1024 groups | C4L the same "
-                         "with 1048576 groups | C1 SELECT sum(v) WHERE k<c on a 1M-row batch")
+                         "with 1048576 groups | C1 SELECT sum(v) WHERE k<c on a 1M-row batch | OP a filter -> join -> GROUP BY plan over HOST-resident "
+                         "Arrow batches through the operator layer (golap_plan_* / golap_execute): H2D / D2H reported separately")
     ap.add_argument("--rows", type=int, default=0, help="rows per side / per column of the WHOLE job (0 = the config's size)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="rows of the bounded CPU-baseline sample (-1 = the config's default, 0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
@@ -597,6 +598,94 @@ def bench_filter_sum(args, n):
     return line
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# OP: Arrow in -> Arrow out through the operator layer ("H2D excluded and reported separately" -- here it is reported)
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_operator_plan(args, n):
+    """GpuAggregate{ GpuHashJoin{ customers, GpuFilter{ orders, flag < 5 } }, [seg], [Sum(amt), Count(amt)] } over pyarrow batches in
+    (pageable) HOST memory: what the reference's GpuExecutor::execute is handed.  Every step is one golap_execute call: Arrow C Data in,
+    upload (each column once, at its Arrow width), device-resident filter / join / aggregate, the group table back as Arrow.  The line
+    says where the wall time went: upload and download phases with their bytes (PCIe), the rest is kernels + host bookkeeping."""
+    import numpy as np
+    import pyarrow as pa
+    import torch
+
+    from gpu_olap_engine_amd import operators as O
+    from gpu_olap_engine_amd.engine import Context
+    torch.cuda.set_device(0)
+    ctx = Context(profiling=False, max_gpu_memory=0)
+    info = ctx.device_info()
+    n_c = max(1000, n // 100)
+    rng = np.random.default_rng(5)
+    o_cust = rng.integers(0, n_c + n_c // 10, n, dtype=np.int64)            # 1 in 11 orders references nobody
+    o_amt = rng.integers(1, 1000, n).astype(np.float64)                     # integer-valued: sums are exact in any order (SURVEY 8(d))
+    o_flag = rng.integers(0, 10, n, dtype=np.int64)
+    c_id = rng.permutation(n_c).astype(np.int64)
+    c_seg = rng.integers(0, 1000, n_c).astype(np.int32)
+    nb = 4                                                                   # orders arrive as 4 RecordBatches
+    cuts = [n * i // nb for i in range(nb + 1)]
+    orders = [pa.RecordBatch.from_arrays([pa.array(o_cust[a:b]), pa.array(o_amt[a:b]), pa.array(o_flag[a:b])], names=["cust", "amt", "flag"])
+              for a, b in zip(cuts[:-1], cuts[1:])]
+    customers = [pa.RecordBatch.from_arrays([pa.array(c_id), pa.array(c_seg)], names=["id", "seg"])]
+
+    def plan():
+        return O.GpuAggregate(O.GpuHashJoin(O.Batches(customers), O.GpuFilter(O.Batches(orders), O.BinaryExpr(O.Column(2, "flag"), "<", O.Literal("5"))),
+                                            [O.Column(0, "id")], [O.Column(0, "cust")]),
+                              [O.Column(1, "seg")], [O.Sum(O.Column(3, "amt")), O.Count(O.Column(3, "amt"))])
+    profs = []
+    for _ in range(args.warmup):
+        out = O.execute(plan(), ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pr = {}
+        out = O.execute(plan(), ctx, profile=pr)
+        profs.append(pr)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    avg = {k: sum(p[k] for p in profs) / len(profs) for k in profs[0]}
+    verify = {}
+    if not args.no_verify:
+        keep = (o_flag < 5) & (o_cust < n_c)
+        seg_of = np.empty(n_c, np.int64)
+        seg_of[c_id] = c_seg
+        seg = seg_of[o_cust[keep]]
+        exp_sum = np.bincount(seg, weights=o_amt[keep], minlength=1000)
+        exp_cnt = np.bincount(seg, minlength=1000)
+        present = np.nonzero(exp_cnt)[0]
+        assert out[0].column(0).to_pylist() == present.tolist(), "group keys differ from numpy"
+        assert np.array_equal(out[0].column(1).to_numpy(), exp_sum[present]) and np.array_equal(out[0].column(2).to_numpy(), exp_cnt[present].astype(np.float64))
+        verify = {"groups": int(present.size), "joined_rows": int(keep.sum()), "sum_of_sums": float(exp_sum.sum())}
+    in_bytes = n * 24 + n_c * 12
+    line = {"metric": "operator-plan input rows/sec, filter -> hash join -> GROUP BY over host-resident Arrow batches", "value": round(n / (ms * 1e-3), 1), "unit": "rows/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"OP GpuAggregate{{GpuHashJoin{{customers {n_c} rows, GpuFilter{{orders {n} rows in {nb} batches, flag < 5}}}}, GROUP BY seg, SUM + COUNT}} "
+                                   f"through golap_plan_* / golap_execute, inputs in pageable host memory (pyarrow), result back as Arrow"},
+            "end_to_end_ms": round(ms, 3), "input_bytes": in_bytes,
+            "h2d_bytes": int(avg["h2d_bytes"]), "h2d_ms": round(avg["h2d_ms"], 3), "h2d_GBps": round(avg["h2d_bytes"] / max(avg["h2d_ms"], 1e-9) / 1e6, 2),
+            "d2h_bytes": int(avg["d2h_bytes"]), "d2h_ms": round(avg["d2h_ms"], 3), "d2h_GBps": round(avg["d2h_bytes"] / max(avg["d2h_ms"], 1e-9) / 1e6, 4),
+            "device_and_host_ms": round(avg["total_ms"] - avg["h2d_ms"] - avg["d2h_ms"], 3), "kernel_wait_ms": round(avg["kernel_wait_ms"], 3),
+            "alg_bytes": in_bytes, "alg_roofline_frac": round(in_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic_bytes_per_step": None,
+            "roofline": None, "kernels_ms_per_step": {}, "verify": verify, "device": device_block(info)}
+    sample = args.cpu_sample if args.cpu_sample >= 0 else min(n, 4_000_000)
+    if sample:   # the same plan on the host cores, single thread, with the oracle's pieces (4-pass filter, HashMap join, sequential GROUP BY)
+        import oracle
+        s = min(sample, n)
+        t0 = time.perf_counter()
+        mask = oracle.eval_filter_mask(o_flag[:s], "<", 5).astype(bool)
+        idx = np.nonzero(mask)[0]
+        pairs, m = oracle.hash_join(c_id, o_cust[:s][idx])
+        seg_rows = c_seg[pairs[:, 0].astype(np.int64)].astype(np.int64)
+        oracle.group_aggregate(seg_rows, o_amt[:s][idx][pairs[:, 1].astype(np.int64)])
+        t1 = time.perf_counter()
+        line["cpu_baseline"] = {"value": s / (t1 - t0), "unit": "rows/s", "cores": 1, "kind": "port",
+                                "sample": f"the first {s} orders against all {n_c} customers: the reference's CPU pieces restated (filter mask executor.rs:443-476, "
+                                          f"HashMap build + probe :238-253, sequential f64 GROUP BY :313-327), single thread; {t1 - t0:.2f} s"}
+    ctx.close()
+    return line
+
+
 def run_config(args, config):
     if config == "C5":
         return bench_join(args, args.rows or 1_000_000_000, "C5")
@@ -606,6 +695,8 @@ def run_config(args, config):
         return bench_group_by(args, args.rows or 1_000_000_000, 1024, "C4")
     if config == "C4L":
         return bench_group_by(args, args.rows or 1_000_000_000, 1_048_576, "C4L")
+    if config == "OP":
+        return bench_operator_plan(args, args.rows or 100_000_000)
     return bench_filter_sum(args, args.rows or 1_000_000)
 
 
@@ -619,12 +710,12 @@ def other_configs(args):
 
     import torch
     out = {}
-    cpu_rows = {"C3": 4_000_000, "C4": 50_000_000, "C4L": 25_000_000, "C1": 1_000_000}
-    for cfg in ("C3", "C4", "C4L", "C1"):
+    cpu_rows = {"C3": 4_000_000, "C4": 50_000_000, "C4L": 25_000_000, "C1": 1_000_000, "OP": 2_000_000}
+    for cfg in ("C3", "C4", "C4L", "C1", "OP"):
         a = copy.copy(args)
         a.config, a.rows, a.no_wide, a.sharded = cfg, 0, True, False
         a.cpu_sample = 0 if args.cpu_sample == 0 else cpu_rows[cfg]
-        a.steps, a.warmup = (50, 5) if cfg == "C1" else (5, 2)
+        a.steps, a.warmup = (50, 5) if cfg == "C1" else (3, 1) if cfg == "OP" else (5, 2)
         gc.collect()
         torch.cuda.empty_cache()
         ln = run_config(a, cfg)
@@ -634,6 +725,8 @@ def other_configs(args):
                     "roofline": {"kernel": r.get("kernel"), "achieved": r.get("achieved"), "frac": r.get("frac"), "unit": r.get("unit"),
                                  "traffic": r.get("traffic"), "alg_bytes_per_launch": r.get("alg_bytes_per_launch")},
                     "kernels_ms_per_step": ln["kernels_ms_per_step"], "verify": ln["verify"]}
+        if cfg == "OP":   # Arrow in -> Arrow out: where the wall time went (PCIe phases with their bytes; the rest is kernels + host bookkeeping)
+            out[cfg].update({k: ln[k] for k in ("end_to_end_ms", "h2d_bytes", "h2d_ms", "h2d_GBps", "d2h_bytes", "d2h_ms", "d2h_GBps", "device_and_host_ms", "kernel_wait_ms")})
         cb = ln.get("cpu_baseline")
         if cb:
             out[cfg]["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}

@@ -19,6 +19,7 @@ def test_expand_validity_matches_arrow(ctx, n, off):
     """bit (off + i) of the bitmap, LSB first == pyarrow's is_valid(i) of the sliced array (record_batch_convert.rs:36-40)"""
     rng = np.random.default_rng(n + off)
     vals = [None if x < 0.3 else 1 for x in rng.random(n + off)]
+    vals[off + n // 2] = None                                            # (at least one NULL: pyarrow builds no bitmap otherwise)
     arr = pa.array(vals, pa.int64()).slice(off, n)
     bitmap = np.frombuffer(arr.buffers()[0], dtype=np.uint8)
     got = ctx.expand_validity(cu(bitmap.copy()), n, bit_offset=arr.offset).cpu().numpy()
