@@ -120,6 +120,7 @@ struct PassCfg {
                            //    owner-major, refined by e1 further hash bits
     uint32_t e1;           // extra bits of the first pass (F = 256 << e1)
     uint32_t owners_log2;  // log2(n_owners)
+    uint32_t piece_rot_off;   // k_part2_ring: 1 = visit a group's pieces from piece 0 on in every work-group (A/B hook GOLAP_P2R_ROT=0; default: rotated by the group number)
     uint32_t pre_hashed;   // k_part1_narrow / k_part2_ring: the tuples' first word is hash_int32(key32 ^ key_hi) instead of key32 -- a
                            // bijection of the key, so equality, partitions and the join are the same, and later passes need not hash
     const uint32_t* key_hi;   // tuple kernels only, may be null (= 0): the upper 32 bits every key of this join shares.  The tuples carry

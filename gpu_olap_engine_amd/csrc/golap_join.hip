@@ -70,8 +70,14 @@ constexpr int SC_ELEMS = SC_THREADS * SC_EPT;   // 4096 elements per scan block
 // ---------------------------------------------------------------------------
 // chunk descriptors
 // ---------------------------------------------------------------------------
+// zero_ptr / zero_words (stand-by chains only, may be null): the histogram array the chain's next kernel accumulates into -- cleared here
+// (grid-stride) instead of by a launch of its own; like everything in the chain only when *run_if says the chain runs at all.
 __global__ void k_setup_uniform(uint32_t n, uint32_t chunk_rows, uint32_t n_chunks, uint32_t* __restrict__ chunk_off,
-                                uint32_t* __restrict__ chunk_len) {
+                                uint32_t* __restrict__ chunk_len, uint32_t* __restrict__ zero_ptr = nullptr, uint32_t zero_words = 0,
+                                const uint32_t* __restrict__ run_if = nullptr) {
+    if (run_if && *run_if == 0) return;
+    if (zero_ptr)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x) zero_ptr[i] = 0u;
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     unsigned long long o = (unsigned long long)c * chunk_rows;
@@ -118,8 +124,10 @@ __device__ __forceinline__ void group_piece(const GroupSrc& gs, uint32_t g, uint
 // `run_if` (here and on the other exact-path kernels): when non-null the launch is a no-op unless *run_if != 0 --
 // the device-side switch that lets the histogram path stand by behind the no-histogram fast path.
 __global__ void k_setup_from_scan(GroupSrc gs, uint32_t n_groups, uint32_t S, uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_len,
-                                  const uint32_t* __restrict__ run_if = nullptr) {
+                                  const uint32_t* __restrict__ run_if = nullptr, uint32_t* __restrict__ zero_ptr = nullptr, uint32_t zero_words = 0) {
     if (run_if && *run_if == 0) return;
+    if (zero_ptr)   // (as in k_setup_uniform)
+        for (uint32_t z = blockIdx.x * blockDim.x + threadIdx.x; z < zero_words; z += gridDim.x * blockDim.x) zero_ptr[z] = 0u;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_groups * S) return;
     uint32_t g = i / S, s = i % S;
@@ -295,6 +303,35 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_down(uint32_t* __restrict__
         uint32_t i = base + e;
         if (i < n) a[i] = run;
         run += v[e];
+    }
+}
+
+// The same scan as ONE launch: a single work-group walks the array in SC_ELEMS-element steps with a running carry.  For the scans of
+// stand-by chains (run_if given): they almost never run -- then this is one launch that returns at once instead of three (a 100M x 100M
+// join enqueues four such scans: 8 launches of ~5 us less) -- and when the chain does run (a skewed column on the exact path) the walk
+// costs ~1.5 us per 4096 elements, at most ~1 ms next to a pass over the rows.
+__global__ __launch_bounds__(SC_THREADS) void k_scan_single(uint32_t* __restrict__ a, uint32_t n, const uint32_t* __restrict__ run_if) {
+    __shared__ uint32_t s_w[4];
+    if (run_if && *run_if == 0) return;
+    uint32_t carry = 0;
+    for (uint32_t blk = 0; blk < n; blk += SC_ELEMS) {
+        const uint32_t base = blk + threadIdx.x * SC_EPT;   // thread owns SC_EPT consecutive elements
+        uint32_t v[SC_EPT], sum = 0;
+#pragma unroll
+        for (int e = 0; e < SC_EPT; ++e) {
+            const uint32_t i = base + e;
+            v[e] = i < n ? a[i] : 0u;
+            sum += v[e];
+        }
+        uint32_t total;
+        uint32_t run = block_exclusive_scan_256(sum, s_w, total) + carry;
+#pragma unroll
+        for (int e = 0; e < SC_EPT; ++e) {
+            const uint32_t i = base + e;
+            if (i < n) a[i] = run;
+            run += v[e];
+        }
+        carry += total;
     }
 }
 
@@ -1482,16 +1519,27 @@ static uint32_t first_pass_chunks(uint64_t n_rows, uint32_t* chunk_rows_out, uin
     uint32_t chunk_rows = (uint32_t)round_up(round_up(ceil_div(n, c1), PT_TILE), big >= 256 ? tile : PT_TILE);
     if (big >= 256 && tile > (uint32_t)PT_TILE && !(knob("GOLAP_CHUNK_ROUNDS") && !strcmp(knob("GOLAP_CHUNK_ROUNDS"), "0"))) {
         // Chunks are whole tiles, so the rule above leaves the last round of work-groups partly empty (1B rows, 18432-row tiles: 2010
-        // chunks of 27 tiles = 7.85 rounds of 256).  Pick the tiles per chunk so that the chunks fill whole rounds: among 4 .. 8 rounds
-        // the split with the least idle tile slots (1B rows: 1024 chunks of 53 tiles, 4 rounds, 0.03 % idle instead of 1.9 %).
+        // chunks of 27 tiles = 7.85 rounds of 256).  Pick the tiles per chunk so that the chunks fill whole rounds.  Round 3 searched
+        // 4 .. 8 rounds for the least idle tile slots (1B rows: 1024 chunks of 53 tiles, 0.03 % idle instead of 1.9 %) -- which at 100M
+        // rows (5426 tiles) picked 1809 chunks of THREE tiles: every chunk pays one tile load that nothing overlaps and one write-out
+        // that overlaps nothing, a third of its work.  Round 4: 1 .. 8 rounds, cost = rounds x (tiles per chunk + RAMP), RAMP = the
+        // un-overlapped head and tail of a chunk in tile times (GOLAP_CHUNK_ROUNDS = "lo:hi[:ramp_percent]" restricts / tunes it).
         const uint64_t tiles = ceil_div(n, tile);
+        uint64_t lo = 1, hi = 8;
+        double ramp = 1.0;
+        if (const char* e = knob("GOLAP_CHUNK_ROUNDS")) {
+            unsigned a = 0, b = 0, r = 100;
+            const int got = sscanf(e, "%u:%u:%u", &a, &b, &r);
+            if (got >= 2 && a >= 1 && b >= a && b <= 16) { lo = a; hi = b; }
+            if (got >= 3) ramp = r / 100.0;
+        }
         double best = -1.0;
-        for (uint64_t rounds = 4; rounds <= 8; ++rounds) {
+        for (uint64_t rounds = lo; rounds <= hi; ++rounds) {
             const uint64_t T = ceil_div(tiles, 256 * rounds);
             if (T < min_tiles) continue;
             const uint64_t nc = ceil_div(tiles, T);
-            const double util = (double)tiles / (double)(ceil_div(nc, 256) * 256 * T);
-            if (util >= best) { best = util; chunk_rows = (uint32_t)(T * tile); }
+            const double cost = (double)ceil_div(nc, 256) * ((double)T + ramp);
+            if (best < 0 || cost < best) { best = cost; chunk_rows = (uint32_t)(T * tile); }
         }
     }
     if (chunk_rows_out) *chunk_rows_out = chunk_rows;
@@ -1591,7 +1639,9 @@ static uint32_t wide_nsub() {
 static uint64_t reserve_cap_sub(uint64_t n_rows, uint32_t F, uint32_t nsub, uint32_t n_chunks, uint32_t chunk_rows, uint32_t sig_mul = 1) {
     if (nsub <= 1) return reserve_cap(n_rows, F, sig_mul);
     const uint64_t n_s = std::min<uint64_t>(std::max<uint64_t>(n_rows, 1), ceil_div(n_chunks, nsub) * (uint64_t)chunk_rows);
-    return reserve_cap(n_s, F, sig_mul);
+    uint64_t cap = reserve_cap(n_s, F, sig_mul);
+    if (const char* e = knob("GOLAP_CAP_PAD")) cap += (uint64_t)(atoi(e) & ~15);   // experiment hook: shifts every sub-range's base address
+    return cap;
 }
 
 // No-histogram FIRST pass: single-source global pass of a two-pass plan whose second pass is the no-histogram one,
@@ -1763,6 +1813,12 @@ static int32_t flat_scan_level(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint
 }
 int32_t flat_scan(golap_ctx* ctx, hipStream_t st, uint32_t* a, uint32_t n, uint32_t* block_sums, const uint32_t* run_if) {
     KernelTimer t(ctx, "scan_offsets", st);
+    const char* e = knob("GOLAP_SCAN_SINGLE");   // "0": three launches for stand-by scans too (A/B and test hook); "1": one launch for every scan
+    const bool single = e ? !strcmp(e, "1") || (run_if && strcmp(e, "0")) : (run_if != nullptr && n <= (1u << 23));
+    if (single) {
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SC_THREADS), 0, st, a, n, run_if);
+        return GOLAP_OK;
+    }
     return flat_scan_level(ctx, st, a, n, block_sums, run_if);
 }
 
@@ -1778,7 +1834,7 @@ static uint64_t side_small_bytes(const JoinPlan& plan, uint64_t n_rows, uint32_t
         uint64_t L = (uint64_t)pp.G * pp.cfg.F * S + 1;
         total += round_up(L * 4, 256) + round_up(ceil_div(L, SC_ELEMS) * 4 + 4, 256) + 2 * round_up((uint64_t)pp.G * S * 4, 256) + 1024;
     }
-    return total + 64 * 1024;   // reservation cursors (fan-out x 8 sub-ranges) and flags of both pipelines
+    return total + 96 * 1024;   // reservation cursors (fan-out x 8 sub-ranges: 16 KiB per side and pipeline), control words and flags of both pipelines
 }
 
 // Runs all passes for one side.  `in_keys`/`in_rids` describe pass 0's input; when
@@ -1802,6 +1858,7 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
     if (gate && !(fast_last && reserve_first)) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "gated side without the no-histogram flow");
     const char* sfx = gate ? "_wide" : "";
     const uint32_t* run_if = nullptr;
+    uint32_t* side_flag2 = nullptr;   // the no-histogram last pass's overflow word when the reserving first pass has allocated (and cleared) it
     GroupSrc groups{};   // how the current pass finds its groups in the previous pass's output
     for (size_t k = 0; k < np; ++k) {
         PassPlan& pp = plan.passes[k];
@@ -1814,13 +1871,16 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             const uint32_t nc = wide_chunks(n_rows, &chunk_rows);
             const uint32_t nsub = wide_nsub();   // per-XCD sub-ranges (ReserveArgs::nsub), as in the tuple pipeline
             const uint32_t cap = (uint32_t)reserve_cap_sub(n_rows, F, nsub, nc, chunk_rows);
-            uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F * nsub * 4);
-            uint32_t* flag1 = (uint32_t*)ws_take(ctx, 4);
+            // cursors, this pass's overflow word and the next pass's (fast_last below) in ONE block, cleared by one launch: each word in a
+            // 256-byte line of its own behind the cursors (a polled word must not share a line with cursors that take atomics)
+            const uint64_t cur_bytes = round_up((uint64_t)F * nsub * 4, 256);
+            uint32_t* cursor = (uint32_t*)ws_take(ctx, cur_bytes + 512);
+            uint32_t* flag1 = cursor ? cursor + cur_bytes / 4 : nullptr;
+            side_flag2 = cursor ? cursor + cur_bytes / 4 + 64 : nullptr;
             uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
             uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
             if (!cursor || !flag1 || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (reservation arrays)");
-            GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F * nsub * 4));
-            GOLAP_TRY(zero_async(ctx, st, (void*)flag1, 4));
+            GOLAP_TRY(zero_async(ctx, st, (void*)cursor, cur_bytes + 512));
             hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_rows, chunk_rows, nc, c_off, c_len);
             PassCfg cfg = pp.cfg;
             cfg.S = nc;
@@ -1861,9 +1921,9 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             uint32_t* slot_cap = (uint32_t*)ws_take(ctx, (uint64_t)G * 4);
             uint32_t* sub_start = (uint32_t*)ws_take(ctx, (uint64_t)G * F * 4);
             uint32_t* sub_len = (uint32_t*)ws_take(ctx, (uint64_t)G * F * 4);
-            uint32_t* flag = (uint32_t*)ws_take(ctx, 4);
+            uint32_t* flag = side_flag2 ? side_flag2 : (uint32_t*)ws_take(ctx, 4);   // (side_flag2: already cleared with the first pass's cursors)
             if (!slot_base || !slot_cap || !sub_start || !sub_len || !flag) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (slot arrays)");
-            GOLAP_TRY(zero_async(ctx, st, (void*)(flag), 4));
+            if (!side_flag2) GOLAP_TRY(zero_async(ctx, st, (void*)(flag), 4));
             uint32_t sigmas, pad;
             provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
             hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F, sigmas, pad, slot_base, slot_cap,
@@ -1903,17 +1963,22 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
         uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)n_chunks * 4);
         uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)n_chunks * 4);
         if (!hist || !bsums || !c_off || !c_len) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (small arrays)");
-        GOLAP_TRY(zero_async(ctx, st, (void*)(hist), (L + 1) * 4));
+        // a stand-by chain's histogram is cleared by its own setup kernel (one launch less per pass and side that returns at once)
+        const bool fold_zero = run_if != nullptr && !(k == 0 && segs) && !(knob("GOLAP_FOLD_ZERO") && !strcmp(knob("GOLAP_FOLD_ZERO"), "0"));
+        if (!fold_zero) GOLAP_TRY(zero_async(ctx, st, (void*)(hist), (L + 1) * 4));
         // descriptors
         {
             const uint32_t tb = 256, gb = (uint32_t)ceil_div(n_chunks, tb);
+            uint32_t* zp = fold_zero ? hist : nullptr;
+            const uint32_t zw = fold_zero ? (uint32_t)(L + 1) : 0u;
             if (k == 0 && !segs)
-                hipLaunchKernelGGL(k_setup_uniform, dim3(gb), dim3(tb), 0, st, (uint32_t)n_rows, chunk_rows, n_chunks, c_off, c_len);
+                hipLaunchKernelGGL(k_setup_uniform, dim3(fold_zero ? std::max<uint32_t>(gb, 64) : gb), dim3(tb), 0, st, (uint32_t)n_rows, chunk_rows, n_chunks, c_off, c_len,
+                                   zp, zw, fold_zero ? run_if : (const uint32_t*)nullptr);
             else if (k == 0)
                 hipLaunchKernelGGL(k_setup_from_segments, dim3(gb), dim3(tb), 0, st, (const uint32_t*)segs->dev_off,
                                    (const uint32_t*)segs->dev_len, pp.G, segs->n_src, S / segs->n_src, c_off, c_len);
             else
-                hipLaunchKernelGGL(k_setup_from_scan, dim3(gb), dim3(tb), 0, st, groups, pp.G, S, c_off, c_len, run_if);
+                hipLaunchKernelGGL(k_setup_from_scan, dim3(fold_zero ? std::max<uint32_t>(gb, 64) : gb), dim3(tb), 0, st, groups, pp.G, S, c_off, c_len, run_if, zp, zw);
         }
         {
             snprintf(name, sizeof name, run_if ? "%s_hist_p%zu_standby" : "%s_hist_p%zu", pfx, k + 1);
@@ -2220,7 +2285,9 @@ static void launch_part1_narrow(hipStream_t st, uint64_t in_keys, uint32_t rid_b
 }
 
 // last pass of the narrow pipeline: per-bucket LDS rings (k_part2_ring); F <= P2R_MAX_F
-static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint64_t out_rows, const PassCfg& cfg, const FixedArgs& fx, const SegSrc& seg) {
+static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint64_t out_rows, const PassCfg& cfg_in, const FixedArgs& fx, const SegSrc& seg) {
+    PassCfg cfg = cfg_in;
+    { const char* e = knob("GOLAP_P2R_ROT"); cfg.piece_rot_off = e && !strcmp(e, "0") ? 1u : 0u; }
     const int v2 = p2r_variant();
     const uint32_t R = part2_ring_rows(cfg.F);
 #define GOLAP_P2R(RR, ASM, ...)                                                                                                           \
@@ -2242,9 +2309,11 @@ static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint
 #undef GOLAP_P2R
 }
 
+// cursor_zeroed (may be null): F1 * narrow cursors' worth of words the caller has already cleared (one launch for both sides' cursors and
+// the call's control words instead of three)
 static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, uint64_t in_keys, uint32_t rid_base, uint64_t n_rows,
                                uint64_t tmp_rows, uint64_t final_rows_ptr, uint32_t* wide, const uint32_t* zero_word, SideResult& res,
-                               const uint32_t* key_hi = nullptr) {
+                               const uint32_t* key_hi = nullptr, uint32_t* cursor_zeroed = nullptr) {
     const PassPlan& p1 = plan.passes[0];
     const PassPlan& p2 = plan.passes[1];
     const uint32_t F1 = p1.cfg.F, G = p2.G, F2 = p2.cfg.F;
@@ -2256,7 +2325,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     const bool hashed_tuples = p1n_variant() != 0 && p2r_variant() != 0 && F2 <= (uint32_t)P2R_MAX_F;
     const uint32_t cap1 = (uint32_t)reserve_cap_sub(n_rows, F1, nsub, nc, chunk_rows, key_hi ? DICT_SIGMA_MUL : 1u);
     if ((uint64_t)cap1 * F1 * nsub >= 0xFFFFFFF0ull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "narrow pipeline: first-pass positions exceed u32");
-    uint32_t* cursor = (uint32_t*)ws_take(ctx, (uint64_t)F1 * nsub * 4);
+    uint32_t* cursor = cursor_zeroed ? cursor_zeroed : (uint32_t*)ws_take(ctx, (uint64_t)F1 * nsub * 4);
     uint32_t* c_off = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
     uint32_t* c_len = (uint32_t*)ws_take(ctx, (uint64_t)nc * 4);
     uint32_t* slot_base = (uint32_t*)ws_take(ctx, (uint64_t)(G + 1) * 4);
@@ -2265,7 +2334,7 @@ static int32_t run_side_narrow(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     uint32_t* sub_len = (uint32_t*)ws_take(ctx, (uint64_t)G * F2 * 4);
     if (!cursor || !c_off || !c_len || !slot_base || !slot_cap || !sub_start || !sub_len)
         return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted (narrow pipeline arrays)");
-    GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F1 * nsub * 4));
+    if (!cursor_zeroed) GOLAP_TRY(zero_async(ctx, st, (void*)cursor, (uint64_t)F1 * nsub * 4));
     hipLaunchKernelGGL(k_setup_uniform, dim3((uint32_t)ceil_div(nc, 256)), dim3(256), 0, st, (uint32_t)n_rows, chunk_rows, nc, c_off, c_len);
     {
         PassCfg cfg = p1.cfg;
@@ -2358,10 +2427,13 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
     if (use_narrow_keys(plan, p->n_build, p->n_probe)) {
         // optimistic 32-bit pipeline first (its big buffers alias the 64-bit pipeline's: only one of the two does any work)
         // [0] wide flag, [1] constant 0, [2 ..) PassCfg::key_hi: the dictionary of upper key halves ([2 .. 5] the scalar form's, [6] its size, [10 ..) the big one)
-        const uint64_t words_bytes = (2 + (uint64_t)KEY_DICT_WORDS) * 4;
-        uint32_t* words = (uint32_t*)ws_take(ctx, words_bytes);
+        // (the control words in a 256-byte line of their own, then both sides' reservation cursors: ONE block, cleared by one launch)
+        const uint64_t words_bytes = round_up((2 + (uint64_t)KEY_DICT_WORDS) * 4, 256);
+        const uint64_t cur_bytes = round_up((uint64_t)plan.passes[0].cfg.F * narrow_nsub() * 4, 256);
+        uint32_t* words = (uint32_t*)ws_take(ctx, words_bytes + 2 * cur_bytes);
         if (!words) return fail(ctx, GOLAP_ERR_OOM, "join workspace exhausted");
-        GOLAP_TRY(zero_async(ctx, st, (void*)words, words_bytes));
+        GOLAP_TRY(zero_async(ctx, st, (void*)words, words_bytes + 2 * cur_bytes));
+        uint32_t* const cursors[2] = {words + words_bytes / 4, words + (words_bytes + cur_bytes) / 4};
         if (ctx->prof.enabled) {   // profiling: which of the two pipelines did the work is read back (asynchronously) for the byte credits
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
@@ -2385,8 +2457,8 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
             GOLAP_TRY(zero_async(ctx, st, (void*)probe_hit, nw * 4));
         }
         SideResult nb_, np_;
-        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->build_key_ptr, p->build_rid_base, p->n_build, bb.tmp_keys[0], bb.final_keys, words, words + 1, nb_, key_hi));
-        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->probe_key_ptr, p->probe_rid_base, p->n_probe, pb.tmp_keys[0], pb.final_keys, words, words + 1, np_, key_hi));
+        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->build_key_ptr, p->build_rid_base, p->n_build, bb.tmp_keys[0], bb.final_keys, words, words + 1, nb_, key_hi, cursors[0]));
+        GOLAP_TRY(run_side_narrow(ctx, st, plan, p->probe_key_ptr, p->probe_rid_base, p->n_probe, pb.tmp_keys[0], pb.final_keys, words, words + 1, np_, key_hi, cursors[1]));
         GOLAP_TRY(launch_lds_join(ctx, st, plan, nb_, np_, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type,
                                   true, nullptr, words, probe_hit));
         gate = words;

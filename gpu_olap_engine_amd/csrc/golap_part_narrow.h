@@ -334,11 +334,17 @@ __global__ __launch_bounds__(P2R_THREADS) __attribute__((amdgpu_waves_per_eu(5))
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t n_pieces = seg.n_src ? seg.n_src : group_pieces(fx.groups);
     if (tid == 0) {   // the group's pieces and their tile counts (a handful of entries: one thread)
+        // The pieces are visited in an order ROTATED by the group number: all work-groups of a launch advance at the same pace, and with
+        // every one of them in its piece 0 (then 1, ...) the addresses they stream from differ by whole multiples of one stride -- at
+        // some strides that lands the 256 streams on few HBM channels (100M rows: the pass ran 0.745 or 0.785 ms depending on 32 rows
+        // more or less in the sub-range capacity).  Rows of a group may be taken in any order.
         uint32_t tiles = 0;
+        const uint32_t rot = cfg.piece_rot_off ? 0u : g % n_pieces;
         for (uint32_t s = 0; s < n_pieces; ++s) {
             uint32_t o, l;
-            if (seg.n_src) { o = seg.off[(size_t)g * seg.n_src + s]; l = seg.len[(size_t)g * seg.n_src + s]; }
-            else group_piece(fx.groups, g, s, o, l);
+            const uint32_t ps = s + rot < n_pieces ? s + rot : s + rot - n_pieces;
+            if (seg.n_src) { o = seg.off[(size_t)g * seg.n_src + ps]; l = seg.len[(size_t)g * seg.n_src + ps]; }
+            else group_piece(fx.groups, g, ps, o, l);
             tiles += (l + TILE - 1) / TILE;
             s_poff[s] = o; s_plen[s] = l; s_pend[s] = tiles;
         }

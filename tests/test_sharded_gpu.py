@@ -211,15 +211,23 @@ def test_sharded_join_upper_key_halves(world, shape):
             assert info["fast_path"] and not info["fast_path_abandoned"] and info["host_syncs"] == 2
 
 
-@pytest.mark.parametrize("mode,join_type", [("fast", 3), ("exact", 1), ("exact", 2)])
-def test_sharded_outer_joins(mode, join_type):
-    """Left / Right / Full on the sharded path: all rows of a key meet on one rank, so unmatched rows are found locally."""
+@pytest.mark.parametrize("mode,join_type,world", [("fast", 0, 2), ("fast", 1, 2), ("fast", 2, 2), ("fast", 3, 2), ("fast", 1, 4), ("fast", 2, 4), ("exact", 1, 2), ("exact", 2, 2),
+                                                  ("exact", 3, 4)])
+def test_sharded_outer_joins(mode, join_type, world):
+    """Inner / Left / Right / Full (logical_plan.rs:53-58) on the sharded path, fast and exact: all rows of a key meet on one rank, so
+    unmatched rows of either side are found locally -- by the LDS join's own outer forms, in both group halves of the fast path (a group
+    lies in exactly one half: an unmatched row is emitted once).  The fast path keeps its two host synchronisations for every type."""
     from np_twin import canonical
-    n, world = 1_500_000, 2
+    n = 1_500_000
     res = _run(world, n, "dups", mode, join_type=join_type)
     exp, me = _expected(n, "dups", join_type, world, -1)
     got = canonical(np.concatenate([r[1] for r in res]))
     assert got.shape[0] == me and np.array_equal(got, exp)
+    for _, _, info in res:
+        if mode == "fast":
+            assert info["fast_path"] and not info["fast_path_abandoned"] and info["host_syncs"] == 2, info
+        else:
+            assert not info["fast_path"]
 
 
 def _worker_uneven(rank, world, port, n, cuts, mode, q):
