@@ -113,6 +113,7 @@ pub struct golap_aggregate_params {
     pub out_keys_ptr: u64,
     pub out_n_groups_ptr: u64,
     pub value_validity_ptrs: *const u64,
+    pub out_slot_ids_ptr: u64,
 }
 
 #[repr(C)]
@@ -315,6 +316,8 @@ extern "C" {
     pub fn golap_sort_u64(ctx: *mut golap_ctx, ptr: u64, n: u64, stream: *mut c_void) -> i32;
     pub fn golap_key_minmax(ctx: *mut golap_ctx, column_ptr: u64, validity_ptr: u64, n_rows: u64, out_ptr: u64, stream: *mut c_void) -> i32;
     pub fn golap_pack_group_keys(ctx: *mut golap_ctx, params: *const golap_pack_keys_params, stream: *mut c_void) -> i32;
+    pub fn golap_hash_key_columns(ctx: *mut golap_ctx, params: *const golap_pack_keys_params, seed: u64, stream: *mut c_void) -> i32;
+    pub fn golap_group_keys_verify(ctx: *mut golap_ctx, params: *const golap_pack_keys_params, slot_ids_ptr: u64, n_slots: u64, out_rep_rows_ptr: u64, out_mismatch_ptr: u64, stream: *mut c_void) -> i32;
     pub fn golap_device_copy(ctx: *mut golap_ctx, src_ptr: u64, dst_ptr: u64, bytes: u64, stream: *mut c_void) -> i32;
     pub fn golap_device_fill_u8(ctx: *mut golap_ctx, ptr: u64, value: u32, bytes: u64, stream: *mut c_void) -> i32;
     // ---- multi-GPU (no counterpart in the reference, README.md:414) ----

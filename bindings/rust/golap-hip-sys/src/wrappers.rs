@@ -120,6 +120,7 @@ impl AggregateKernel {
             out_keys_ptr: 0,
             out_n_groups_ptr: 0,
             value_validity_ptrs: std::ptr::null(),
+            out_slot_ids_ptr: 0,
         };
         check(self.ctx, unsafe { golap_aggregate(self.ctx, s.as_ptr(), s.len() as u32, &p, null_mut()) })
     }

@@ -147,7 +147,8 @@ class AggregateParams(C.Structure):
     _fields_ = [("group_key_ptr", C.c_uint64), ("value_ptrs", C.POINTER(C.c_uint64)), ("n_value_cols", C.c_uint32),
                 ("n_rows", C.c_uint64), ("n_groups", C.c_uint32), ("out_ptr", C.c_uint64), ("key_dtype", C.c_int32),
                 ("value_dtypes", C.POINTER(C.c_int32)), ("out_count_ptr", C.c_uint64), ("key_mode", C.c_int32), ("reserved0", C.c_int32),
-                ("out_keys_ptr", C.c_uint64), ("out_n_groups_ptr", C.c_uint64), ("value_validity_ptrs", C.POINTER(C.c_uint64))]
+                ("out_keys_ptr", C.c_uint64), ("out_n_groups_ptr", C.c_uint64), ("value_validity_ptrs", C.POINTER(C.c_uint64)),
+                ("out_slot_ids_ptr", C.c_uint64)]
 
 
 class KernelStat(C.Structure):
@@ -227,6 +228,8 @@ SIGNATURES = {
     "golap_sort_u64": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, _VP]),
     "golap_key_minmax": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_pack_group_keys": (C.c_int32, [_VP, _P(PackKeysParams), _VP]),
+    "golap_hash_key_columns": (C.c_int32, [_VP, _P(PackKeysParams), C.c_uint64, _VP]),
+    "golap_group_keys_verify": (C.c_int32, [_VP, _P(PackKeysParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_device_copy": (C.c_int32, [_VP, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),
     "golap_device_fill_u8": (C.c_int32, [_VP, C.c_uint64, C.c_uint32, C.c_uint64, _VP]),
     "golap_generate": (C.c_int32, [_VP, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _VP]),

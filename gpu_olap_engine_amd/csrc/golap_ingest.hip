@@ -126,6 +126,56 @@ __global__ __launch_bounds__(IG_THREADS) void k_pack_group_keys(golap_pack_keys_
     }
 }
 
+__device__ __forceinline__ unsigned long long ig_mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// 64-bit surrogate of a composite GROUP BY key: a seeded chain of mixes over the columns; a NULL is its own symbol per column
+// keep_mask: all ones; the test knob GOLAP_SURROGATE_BITS narrows the surrogates until two tuples do share one
+__global__ __launch_bounds__(IG_THREADS) void k_hash_key_columns(golap_pack_keys_params p, unsigned long long seed, unsigned long long keep_mask, long long* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * IG_THREADS + threadIdx.x; i < p.n_rows; i += (unsigned long long)gridDim.x * IG_THREADS) {
+        unsigned long long h = ig_mix64(seed ^ 0x243F6A8885A308D3ull);
+        for (uint32_t c = 0; c < p.n_cols; ++c) {
+            const uint8_t* v = (const uint8_t*)p.validity_ptrs[c];
+            const bool null = v && !v[i];
+            const unsigned long long x = null ? 0x9E3779B97F4A7C15ull * (c + 1) : (unsigned long long)((const long long*)p.col_ptrs[c])[i];
+            h = ig_mix64(h ^ x) + (null ? 0xD1B54A32D192ED03ull : 0x8CB92BA72F3D8DD7ull) * (c + 1);
+        }
+        out[i] = (long long)(h & keep_mask);
+    }
+}
+__global__ __launch_bounds__(IG_THREADS) void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, unsigned long long n) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * IG_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * IG_THREADS) p[i] = v;
+}
+// representative row of a slot = the smallest row index aggregated into it
+__global__ __launch_bounds__(IG_THREADS) void k_slot_rep(const uint32_t* __restrict__ slot, unsigned long long n, unsigned long long n_slots, uint32_t* __restrict__ rep) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * IG_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * IG_THREADS) {
+        const uint32_t s = slot[i];
+        if (s < n_slots && rep[s] > (uint32_t)i) atomicMin(&rep[s], (uint32_t)i);
+    }
+}
+// rows whose key tuple differs from their slot's representative (NULL == NULL here: GROUP BY puts NULLs of a column together)
+__global__ __launch_bounds__(IG_THREADS) void k_group_keys_verify(golap_pack_keys_params p, const uint32_t* __restrict__ slot, unsigned long long n_slots,
+                                                                  const uint32_t* __restrict__ rep, unsigned long long* __restrict__ mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * IG_THREADS + threadIdx.x; i < p.n_rows; i += (unsigned long long)gridDim.x * IG_THREADS) {
+        const uint32_t s = slot[i];
+        if (s >= n_slots) { ++bad; continue; }
+        const uint32_t r = rep[s];
+        bool same = true;
+        for (uint32_t c = 0; c < p.n_cols; ++c) {
+            const uint8_t* v = (const uint8_t*)p.validity_ptrs[c];
+            const bool ni = v && !v[i], nr = v && !v[r];
+            const long long* col = (const long long*)p.col_ptrs[c];
+            same = same && ni == nr && (ni || col[i] == col[r]);
+        }
+        bad += same ? 0 : 1;
+    }
+    for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 __global__ __launch_bounds__(IG_THREADS) void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, unsigned long long n) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * IG_THREADS + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * IG_THREADS) p[i] = v;
 }
@@ -243,6 +293,43 @@ int32_t golap_pack_group_keys(golap_ctx* ctx, const golap_pack_keys_params* p, v
         if (!p->col_ptrs[c]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "key column %u is null", c);
     KernelTimer t(ctx, "pack_group_keys", st, (8ull * p->n_cols + 8) * p->n_rows);
     hipLaunchKernelGGL(k_pack_group_keys, dim3(ig_grid(ctx, p->n_rows)), dim3(IG_THREADS), 0, st, *p, (long long*)p->out_ptr);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+int32_t golap_hash_key_columns(golap_ctx* ctx, const golap_pack_keys_params* p, uint64_t seed, void* stream) {
+    IG_ENTER(ctx, stream);
+    if (!p) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null params");
+    if (p->n_cols < 1 || p->n_cols > 4) return fail(ctx, GOLAP_ERR_INVALID_ARG, "1 to 4 key columns");
+    if (p->n_rows == 0) return GOLAP_OK;
+    if (!p->out_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "out_ptr is null");
+    for (uint32_t c = 0; c < p->n_cols; ++c)
+        if (!p->col_ptrs[c]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "key column %u is null", c);
+    KernelTimer t(ctx, "hash_key_columns", st, (8ull * p->n_cols + 8) * p->n_rows);
+    unsigned long long keep = ~0ull;
+    if (const char* e = knob("GOLAP_SURROGATE_BITS")) { const int b = atoi(e); if (b >= 1 && b < 64) keep = (1ull << b) - 1; }
+    hipLaunchKernelGGL(k_hash_key_columns, dim3(ig_grid(ctx, p->n_rows)), dim3(IG_THREADS), 0, st, *p, (unsigned long long)seed, keep, (long long*)p->out_ptr);
+    GOLAP_HIP_TRY(ctx, hipGetLastError());
+    return GOLAP_OK;
+}
+
+int32_t golap_group_keys_verify(golap_ctx* ctx, const golap_pack_keys_params* p, uint64_t slot_ids_ptr, uint64_t n_slots, uint64_t out_rep_rows_ptr,
+                                uint64_t out_mismatch_ptr, void* stream) {
+    IG_ENTER(ctx, stream);
+    if (!p || !out_mismatch_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null argument");
+    if (p->n_cols < 1 || p->n_cols > 4) return fail(ctx, GOLAP_ERR_INVALID_ARG, "1 to 4 key columns");
+    if (p->n_rows >= 0xFFFFFFFFull) return fail(ctx, GOLAP_ERR_UNSUPPORTED, "row indices are u32");
+    GOLAP_TRY(zero_async(ctx, st, (void*)out_mismatch_ptr, 8));
+    if (p->n_rows == 0 || n_slots == 0) return GOLAP_OK;
+    if (!slot_ids_ptr || !out_rep_rows_ptr) return fail(ctx, GOLAP_ERR_INVALID_ARG, "null pointer");
+    for (uint32_t c = 0; c < p->n_cols; ++c)
+        if (!p->col_ptrs[c]) return fail(ctx, GOLAP_ERR_INVALID_ARG, "key column %u is null", c);
+    KernelTimer t(ctx, "group_keys_verify", st, (16ull * p->n_cols + 8) * p->n_rows);
+    hipLaunchKernelGGL(k_fill_u32, dim3(ig_grid(ctx, n_slots)), dim3(IG_THREADS), 0, st, (uint32_t*)out_rep_rows_ptr, 0xFFFFFFFFu, (unsigned long long)n_slots);
+    hipLaunchKernelGGL(k_slot_rep, dim3(ig_grid(ctx, p->n_rows)), dim3(IG_THREADS), 0, st, (const uint32_t*)slot_ids_ptr, (unsigned long long)p->n_rows,
+                       (unsigned long long)n_slots, (uint32_t*)out_rep_rows_ptr);
+    hipLaunchKernelGGL(k_group_keys_verify, dim3(ig_grid(ctx, p->n_rows)), dim3(IG_THREADS), 0, st, *p, (const uint32_t*)slot_ids_ptr, (unsigned long long)n_slots,
+                       (const uint32_t*)out_rep_rows_ptr, (unsigned long long*)out_mismatch_ptr);
     GOLAP_HIP_TRY(ctx, hipGetLastError());
     return GOLAP_OK;
 }

@@ -1938,7 +1938,8 @@ static int32_t aggregate_hashed(golap_ctx* ctx, const golap_aggregate_spec* spec
     long long* table = (long long*)aux_take(ctx, (uint64_t)cap * 8);
     uint32_t* ids = (uint32_t*)aux_take(ctx, ((uint64_t)cap + 1) * 4);
     uint32_t* bsums = (uint32_t*)aux_take(ctx, flat_scan_scratch_words((uint64_t)cap + 1) * 4);
-    uint32_t* slots = (uint32_t*)aux_take(ctx, std::max<uint64_t>(n, 1) * 4);
+    // (the slot column goes straight into the caller's buffer when it wants it: out_slot_ids_ptr)
+    uint32_t* slots = p->out_slot_ids_ptr ? (uint32_t*)p->out_slot_ids_ptr : (uint32_t*)aux_take(ctx, std::max<uint64_t>(n, 1) * 4);
     uint32_t* flags = (uint32_t*)aux_take(ctx, 16);
     if (!table || !ids || !bsums || !slots || !flags) return fail(ctx, GOLAP_ERR_OOM, "aggregate scratch exhausted (key table)");
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;

@@ -852,7 +852,46 @@ struct SlabHold {   // slabs that must outlive the workspace (the workspace is r
     }
 };
 
-static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, int32_t arg_err) {
+// ---------------------------------------------------------------------------
+// key tuples that do not fit one exact int64 (composites beyond 62 bits; a full-range column with NULLs): the exact path joins
+// on a 64-bit SURROGATE of the tuple (k_surrogate: the single-GPU join's; a row with a NULL gets a key of its own) and ships the
+// real key columns and a "no NULL in this row" byte along with the rows -- same partition order, same messages, one more array
+// each.  The receiving rank joins on positions instead of row ids, checks every pair against the shipped columns (k_gj_verify /
+// k_gj_repair_*: two tuples share a surrogate with probability 2^-64 per candidate pair -- rare, not never), and only then turns
+// positions into the global row ids.
+// ---------------------------------------------------------------------------
+struct ShardWideKeys {
+    KeyCols cols[2];        // [side] this rank's original key columns and validity arrays
+};
+__global__ __launch_bounds__(256) void k_gather8_by_rid(const long long* __restrict__ col, const uint32_t* __restrict__ rids, uint32_t rid_base, unsigned long long n,
+                                                        long long* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) out[i] = col[rids[i] - rid_base];
+}
+__global__ __launch_bounds__(256) void k_rowvalid_by_rid(KeyCols k, const uint32_t* __restrict__ rids, uint32_t rid_base, unsigned long long n, uint8_t* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const uint32_t r = rids[i] - rid_base;
+        bool ok = true;
+        for (uint32_t c = 0; c < k.n_cols; ++c) ok = ok && !(k.valid[c] && !k.valid[c][r]);
+        out[i] = ok ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ out, unsigned long long n) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) out[i] = (uint32_t)i;
+}
+// (position in the received build rows, position in the received probe rows) -> global row ids; the NULL id of an outer join stays
+__global__ __launch_bounds__(256) void k_translate_pairs(uint2* __restrict__ pairs, const unsigned long long* __restrict__ count, unsigned long long max_pairs,
+                                                         const uint32_t* __restrict__ rid_b, const uint32_t* __restrict__ rid_p) {
+    const unsigned long long n = *count < max_pairs ? *count : max_pairs;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        uint2 v = pairs[i];
+        if (v.x != JN_NULL) v.x = rid_b[v.x];
+        if (v.y != JN_NULL) v.y = rid_p[v.y];
+        pairs[i] = v;
+    }
+}
+
+static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, const ShardPlan& sp, hipStream_t st, int32_t arg_err,
+                                  const ShardWideKeys* wide = nullptr) {
     const uint32_t P = sp.world, me = (uint32_t)cm->rank, e1 = sp.e1, F1 = sp.F1, per = sp.per;
     const uint64_t max_msg = shard_max_msg(cm, p->max_msg_bytes);
     const uint64_t n_local[2] = {p->n_build_local, p->n_probe_local};
@@ -866,6 +905,9 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
     // what depends on the arguments alone is allocated first; every rank says so before anything is exchanged (shard_agree).  The
     // receive buffers depend on the data: they get their own agreement round per side, next to the read-back that sizes them.
     uint64_t pk_[2] = {0, 0}, pr_[2] = {0, 0}, offs_[2] = {0, 0}, offs_all_[2] = {0, 0};
+    // wide key tuples (ShardWideKeys): the key columns and the row-valid byte in partition order (sent), and as received
+    const uint32_t WK = wide ? wide->cols[0].n_cols : 0;
+    uint64_t wsend[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wsend_v[2] = {0, 0}, wrecv[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wrecv_v[2] = {0, 0}, wiota[2] = {0, 0}, wctl = 0;
     auto prepare = [&]() -> int32_t {
         if (arg_err != GOLAP_OK) return arg_err;
         GOLAP_TRY(ensure_host_words(cm, 2 * (uint64_t)P * off_words * 4));
@@ -875,7 +917,11 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
             offs_[side] = hold.take(off_words * 4);
             offs_all_[side] = hold.take((uint64_t)P * off_words * 4);
             if (!pk_[side] || !pr_[side] || !offs_[side] || !offs_all_[side]) return fail(ctx, GOLAP_ERR_OOM, "sharded join: partition buffers");
+            for (uint32_t c = 0; c < WK; ++c)
+                if (!(wsend[side][c] = hold.take(std::max<uint64_t>(1, n_local[side]) * 8))) return fail(ctx, GOLAP_ERR_OOM, "sharded join: key columns in partition order");
+            if (WK && !(wsend_v[side] = hold.take(std::max<uint64_t>(1, n_local[side])))) return fail(ctx, GOLAP_ERR_OOM, "sharded join: key columns in partition order");
         }
+        if (WK && !(wctl = hold.take(sizeof(GjCtl)))) return fail(ctx, GOLAP_ERR_OOM, "sharded join: verification block");
         return GOLAP_OK;
     };
     GOLAP_TRY(shard_agree(ctx, cm, prepare()));
@@ -893,6 +939,15 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
         pp.out_row_id_ptr = pr;
         pp.out_offsets_ptr = offs;
         GOLAP_TRY(radix_partition_impl(ctx, &pp, st));
+        if (WK && n_local[side]) {   // the real key columns follow their rows: gathered by the partitioned row ids
+            const uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->prop.multiProcessorCount * 8, ceil_div(n_local[side], 1024)));
+            for (uint32_t c = 0; c < WK; ++c)
+                hipLaunchKernelGGL(k_gather8_by_rid, dim3(g), dim3(256), 0, st, wide->cols[side].col[c], (const uint32_t*)pr, rid_base[side], (unsigned long long)n_local[side],
+                                   (long long*)wsend[side][c]);
+            hipLaunchKernelGGL(k_rowvalid_by_rid, dim3(g), dim3(256), 0, st, wide->cols[side], (const uint32_t*)pr, rid_base[side], (unsigned long long)n_local[side],
+                               (uint8_t*)wsend_v[side]);
+            GOLAP_HIP_TRY(ctx, hipGetLastError());
+        }
         // bucket sizes of every rank: device all-gather, then the one read-back this side needs
         GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_part[side][0], st));
         GOLAP_HIP_TRY(ctx, hipStreamWaitEvent(cm->stream, cm->ev_part[side][0], 0));
@@ -911,7 +966,10 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
         }
         recv_keys[side] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 8);
         recv_rids[side] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 4);
-        GOLAP_TRY(shard_agree(ctx, cm, recv_keys[side] && recv_rids[side] ? GOLAP_OK : fail(ctx, GOLAP_ERR_OOM, "sharded join: receive buffers")));
+        bool wide_ok = true;
+        for (uint32_t c = 0; c < WK; ++c) wide_ok = wide_ok && (wrecv[side][c] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 8)) != 0;
+        if (WK) wide_ok = wide_ok && (wrecv_v[side] = hold.take(std::max<uint64_t>(1, n_recv[side]))) != 0 && (wiota[side] = hold.take(std::max<uint64_t>(1, n_recv[side]) * 4)) != 0;
+        GOLAP_TRY(shard_agree(ctx, cm, recv_keys[side] && recv_rids[side] && wide_ok ? GOLAP_OK : fail(ctx, GOLAP_ERR_OOM, "sharded join: receive buffers")));
         seg_off[side].assign((size_t)per * P, 0);
         seg_len[side].assign((size_t)per * P, 0);
         for (uint32_t r = 0; r < P; ++r) {
@@ -929,6 +987,9 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
                 if (s1 > s0) {   // own partitions never touch the transport
                     GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)(recv_keys[side] + base[r] * 8), (const void*)(pk + s0 * 8), (s1 - s0) * 8, hipMemcpyDeviceToDevice, cm->stream));
                     GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)(recv_rids[side] + base[r] * 4), (const void*)(pr + s0 * 4), (s1 - s0) * 4, hipMemcpyDeviceToDevice, cm->stream));
+                    for (uint32_t c = 0; c < WK; ++c)
+                        GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)(wrecv[side][c] + base[r] * 8), (const void*)(wsend[side][c] + s0 * 8), (s1 - s0) * 8, hipMemcpyDeviceToDevice, cm->stream));
+                    if (WK) GOLAP_HIP_TRY(ctx, hipMemcpyAsync((void*)(wrecv_v[side] + base[r]), (const void*)(wsend_v[side] + s0), s1 - s0, hipMemcpyDeviceToDevice, cm->stream));
                 }
                 continue;
             }
@@ -936,7 +997,15 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
             split_message((int32_t)r, false, recv_keys[side] + base[r] * 8, from[r] * 8, max_msg, ops);
             split_message((int32_t)r, true, pr + s0 * 4, (s1 - s0) * 4, max_msg, ops);
             split_message((int32_t)r, false, recv_rids[side] + base[r] * 4, from[r] * 4, max_msg, ops);
-            cm->info.bytes_sent[side] += (s1 - s0) * 12;
+            for (uint32_t c = 0; c < WK; ++c) {
+                split_message((int32_t)r, true, wsend[side][c] + s0 * 8, (s1 - s0) * 8, max_msg, ops);
+                split_message((int32_t)r, false, wrecv[side][c] + base[r] * 8, from[r] * 8, max_msg, ops);
+            }
+            if (WK) {
+                split_message((int32_t)r, true, wsend_v[side] + s0, s1 - s0, max_msg, ops);
+                split_message((int32_t)r, false, wrecv_v[side] + base[r], from[r], max_msg, ops);
+            }
+            cm->info.bytes_sent[side] += (s1 - s0) * (12 + 8ull * WK + (WK ? 1 : 0));
         }
         GOLAP_TRY(comm_exchange(cm, ops, cm->stream));   // in flight while the other side is partitioned
         GOLAP_HIP_TRY(ctx, hipEventRecord(cm->ev_xchg[side], cm->stream));
@@ -957,6 +1026,11 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
         golap_partitioned_side sd;
         sd.key_ptr = recv_keys[side];
         sd.row_id_ptr = recv_rids[side];
+        if (WK) {   // wide key tuples: the join emits POSITIONS in the received rows (checked against the shipped columns below)
+            if (n_recv[side]) hipLaunchKernelGGL(k_iota_u32, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(2048, ceil_div(n_recv[side], 1024)))), dim3(256), 0, st,
+                                                 (uint32_t*)wiota[side], (unsigned long long)n_recv[side]);
+            sd.row_id_ptr = wiota[side];
+        }
         sd.n_rows = n_recv[side];
         sd.seg_off = seg_off[side].data();
         sd.seg_len = seg_len[side].data();
@@ -964,6 +1038,26 @@ static int32_t sharded_join_exact(golap_ctx* ctx, golap_comm* cm, const golap_sh
     }
     if (rc == GOLAP_OK) rc = part_finish(ctx, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, st, p->join_type);
     if (rc != GOLAP_OK) { part_abort(ctx); return rc; }   // (`drain` empties both streams)
+    if (WK) {
+        KeyCols B{}, Pc{};
+        B.n_cols = Pc.n_cols = WK;
+        for (uint32_t c = 0; c < WK; ++c) { B.col[c] = (const long long*)wrecv[0][c]; Pc.col[c] = (const long long*)wrecv[1][c]; }
+        B.valid[0] = (const uint8_t*)wrecv_v[0];     // one byte per ROW ("no key column of this row is NULL"): a row with a NULL matches nothing
+        Pc.valid[0] = (const uint8_t*)wrecv_v[1];
+        GOLAP_TRY(zero_async(ctx, st, (void*)wctl, sizeof(GjCtl)));
+        const uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->prop.multiProcessorCount * 8, ceil_div(std::max<uint64_t>(p->max_pairs, 1), 1024)));
+        if (n_recv[0] && n_recv[1]) {
+            hipLaunchKernelGGL(k_gj_verify, dim3(g), dim3(256), 0, st, (const uint2*)p->out_pairs_ptr, (const unsigned long long*)p->out_count_ptr, (unsigned long long)p->max_pairs, B, Pc,
+                               0u, 0u, (GjCtl*)wctl);
+            hipLaunchKernelGGL(k_gj_repair_scan, dim3(g), dim3(256), 0, st, (const uint2*)p->out_pairs_ptr, (const unsigned long long*)p->out_count_ptr, (unsigned long long)p->max_pairs,
+                               B, Pc, 0u, 0u, (GjCtl*)wctl);
+            hipLaunchKernelGGL(k_gj_repair_fix, dim3(1), dim3(64), 0, st, (uint2*)p->out_pairs_ptr, (unsigned long long*)p->out_count_ptr, (unsigned long long)p->max_pairs, p->join_type,
+                               (GjCtl*)wctl);
+        }
+        hipLaunchKernelGGL(k_translate_pairs, dim3(g), dim3(256), 0, st, (uint2*)p->out_pairs_ptr, (const unsigned long long*)p->out_count_ptr, (unsigned long long)p->max_pairs,
+                           (const uint32_t*)recv_rids[0], (const uint32_t*)recv_rids[1]);
+        GOLAP_HIP_TRY(ctx, hipGetLastError());
+    }
     // the slabs above go back to the pool at scope exit: every kernel that reads them must have finished
     GOLAP_HIP_TRY(ctx, hipStreamSynchronize(st));
     drain.armed = false;
@@ -1198,7 +1292,7 @@ __global__ __launch_bounds__(256) void k_pack_keys(PackCols pc, unsigned long lo
 // `switched`: this rank came here from the plain form after its first agreement round showed general peers (that round is the
 // one the general ranks ran below); both kinds then meet in a second round, which carries the late-comers' prepare() outcome.
 static int32_t shard_pack_keys(golap_ctx* ctx, golap_comm* cm, const golap_sharded_join_params* p, hipStream_t st, SlabHold& hold, uint64_t* packed_b,
-                               uint64_t* packed_p, bool switched) {
+                               uint64_t* packed_p, bool switched, ShardWideKeys* wide_out, bool* is_wide) {
     const uint32_t P = (uint32_t)cm->world, K = std::max<uint32_t>(1, p->n_key_cols);
     const uint64_t n[2] = {p->n_build_local, p->n_probe_local};
     uint64_t cols[2][4], valids[2][4];
@@ -1255,12 +1349,32 @@ static int32_t shard_pack_keys(golap_ctx* ctx, golap_comm* cm, const golap_shard
         if (mn[c] > mx[c]) mn[c] = mx[c] = 0;   // no valid value anywhere
     }
     unsigned long long weight[4] = {1, 1, 1, 1};
-    for (uint32_t c = K; c-- > 0;) {
+    bool fits = true;
+    for (uint32_t c = K; c-- > 0 && fits;) {
         weight[c] = (unsigned long long)total;
         total *= (unsigned __int128)((__int128)mx[c] - (__int128)mn[c]) + 1;
-        if (total > ((unsigned __int128)1 << 62))   // (the same numbers on every rank: every rank refuses)
-            return fail(ctx, GOLAP_ERR_UNSUPPORTED, "sharded join: the composite key does not fit 62 bits (column %u spans %.0f values)", c,
-                        (double)((__int128)mx[c] - (__int128)mn[c]) + 1.0);
+        if (total > ((unsigned __int128)1 << 62)) fits = false;   // (the same numbers on every rank: every rank takes the same branch)
+    }
+    if (const char* e = knob("GOLAP_SHARD_WIDE_KEYS")) if (!strcmp(e, "1")) fits = false;   // test hook: the surrogate route for tuples that would pack
+    *is_wide = !fits;
+    if (!fits) {
+        // the tuple does not fit one exact int64: join on a 64-bit surrogate (NULL rows get keys of their own) and let the exact path ship
+        // the real columns for the check (ShardWideKeys, sharded_join_exact)
+        for (int side = 0; side < 2; ++side) {
+            KeyCols& kc = wide_out->cols[side];
+            memset(&kc, 0, sizeof kc);
+            kc.n_cols = K;
+            for (uint32_t c = 0; c < K; ++c) { kc.col[c] = (const long long*)cols[side][c]; kc.valid[c] = (const uint8_t*)valids[side][c]; }
+            if (!n[side]) continue;
+            unsigned long long keep = ~0ull;
+            if (const char* e = knob("GOLAP_GJ_HASH_BITS")) { const int b = atoi(e); if (b >= 1 && b < 64) keep = (1ull << b) - 1; }   // test knob: provoke false pairs
+            // (NULL rows: a mix of (side seed, GLOBAL row id) -- distinct across ranks too)
+            const unsigned long long seed = (side ? 0xBB67AE8584CAA73Bull : 0x6A09E667F3BCC908ull) + (unsigned long long)(side ? p->probe_rid_base : p->build_rid_base) * 0x9E3779B97F4A7C15ull;
+            hipLaunchKernelGGL(k_surrogate, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cus * 8, ceil_div(n[side], 1024)))), dim3(256), 0, st, kc,
+                               (unsigned long long)n[side], seed, keep, (long long*)(side ? *packed_p : *packed_b));
+        }
+        GOLAP_HIP_TRY(ctx, hipGetLastError());
+        return GOLAP_OK;
     }
     for (int side = 0; side < 2; ++side) {
         pc[side].n = K;
@@ -1287,10 +1401,12 @@ static int32_t sharded_join_run(golap_ctx* ctx, golap_comm* cm, const golap_shar
                                 bool general, bool switched, SlabHold& packed_hold, bool& packed_on) {
     golap_sharded_join_params& p_local = *p_local_;
     const golap_sharded_join_params* p = p_local_;
+    ShardWideKeys wide_keys;
+    bool is_wide = false;
     if (general) {
         uint64_t pb = 0, pp = 0;
         packed_on = true;
-        GOLAP_TRY(shard_pack_keys(ctx, cm, p_in, st, packed_hold, &pb, &pp, switched));
+        GOLAP_TRY(shard_pack_keys(ctx, cm, p_in, st, packed_hold, &pb, &pp, switched, &wide_keys, &is_wide));
         p_local.build_key_ptr = pb;
         p_local.probe_key_ptr = pp;
         p_local.n_key_cols = 1;
@@ -1318,7 +1434,7 @@ static int32_t sharded_join_run(golap_ctx* ctx, golap_comm* cm, const golap_shar
     cm->info.n_groups = sp.per;
     cm->info.local_bits = sp.local_bits;
     if (arg_err == GOLAP_OK) GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
-    if (sp.eligible && !p->force_exact) {
+    if (sp.eligible && !p->force_exact && !is_wide) {   // (surrogate keys are 64-bit hashes and need the shipped columns: the exact path)
         bool failed = false;
         GOLAP_TRY(sharded_join_fast(ctx, cm, p, sp, st, &failed, arg_err));
         if (!failed) { cm->info.fast_path = 1; return GOLAP_OK; }
@@ -1331,7 +1447,7 @@ static int32_t sharded_join_run(golap_ctx* ctx, golap_comm* cm, const golap_shar
         cm->info.fast_path_abandoned = 1;
         GOLAP_TRY(zero_async(ctx, st, (void*)p->out_count_ptr, 8));
     }
-    return sharded_join_exact(ctx, cm, p, sp, st, arg_err);
+    return sharded_join_exact(ctx, cm, p, sp, st, arg_err, is_wide ? &wide_keys : nullptr);
 }
 
 }  // namespace golap

@@ -977,17 +977,122 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
     std::vector<unsigned __int128> digits(K);
     std::vector<uint64_t> weight(K, 1);
     unsigned __int128 total = 1;
+    bool wide = false;   // the key tuple does not fit one exact int64: group on a 64-bit surrogate, then verify (below)
     if (packed)
         for (size_t c = K; c-- > 0;) {
             digits[c] = (unsigned __int128)((__int128)mx[c] - (__int128)mn[c]) + 1 + (has_null[c] ? 1 : 0);
             weight[c] = (uint64_t)total;
             total *= digits[c];
-            if (total > ((unsigned __int128)1 << 62)) {
-                std::string sizes;
-                for (size_t k = 0; k < K; ++k) sizes += (k ? " x " : "") + std::to_string((double)((__int128)mx[k] - (__int128)mn[k]) + 1.0);
-                return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: the composite group key does not fit 62 bits (value ranges " + sizes + ")");
+            if (total > ((unsigned __int128)1 << 62)) { wide = true; break; }
+        }
+    if (getenv("GOLAP_DEBUG_ENV"))   // (test hook, honoured like the library's knobs only in a debugging environment: the surrogate route for keys that would pack)
+        if (const char* e = getenv("GOLAP_HOST_WIDE_KEYS")) wide = wide || (packed && e[0] == '1');
+    // the hashed GROUP BY (GOLAP_KEYS_HASHED, aggregate_kernel.rs:76-77) on `hkey`; the bound on the distinct keys starts modest and
+    // grows only when the data asks for it: every buffer is sized from it.  Leaves the group count in nd, the tables in dout / dkeys.
+    struct Hashed { DevPtr dout, dcnt, dkeys, dn; uint64_t bound = 0; uint32_t nd = 0; };
+    auto run_hashed = [&](uint64_t hkey, uint64_t slot_ids_ptr, Hashed& h) -> int32_t {
+        h.bound = std::min<uint64_t>(n, 1ull << 22);
+        const uint64_t bound_max = std::min<uint64_t>(n, 1ull << 28);   // distinct keys <= rows; the key table holds at most 2^28 groups
+        int32_t kd64 = GOLAP_DT_INT64;
+        for (;;) {
+            H_TRY(temp(h.dout, (uint64_t)std::max<uint32_t>(na, 1) * h.bound * 8));
+            H_TRY(temp(h.dcnt, h.bound * 8));
+            H_TRY(temp(h.dkeys, h.bound * 8));
+            H_TRY(temp(h.dn, 8));
+            golap_aggregate_params hp;
+            memset(&hp, 0, sizeof hp);
+            hp.group_key_ptr = hkey; hp.value_ptrs = vptrs.data(); hp.n_value_cols = nv; hp.n_rows = n; hp.n_groups = (uint32_t)h.bound;
+            hp.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;
+            hp.out_ptr = h.dout->ptr; hp.key_dtype = GOLAP_DT_INT64; hp.value_dtypes = vdt.data(); hp.out_count_ptr = h.dcnt->ptr;
+            hp.key_mode = GOLAP_KEYS_HASHED; hp.out_keys_ptr = h.dkeys->ptr; hp.out_n_groups_ptr = h.dn->ptr;
+            hp.out_slot_ids_ptr = slot_ids_ptr;
+            if (na == 0) {
+                golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
+                hp.value_ptrs = &hkey; hp.n_value_cols = 1; hp.value_dtypes = &kd64; hp.value_validity_ptrs = nullptr;
+                H_TRY(golap_aggregate(ctx, &cs, 1, &hp, nullptr));
+            } else {
+                H_TRY(golap_aggregate(ctx, specs.data(), na, &hp, nullptr));
+            }
+            uint64_t nd64 = 0;
+            H_TRY(read_u64(h.dn->ptr, &nd64));
+            h.nd = (uint32_t)nd64;
+            if (h.nd <= h.bound) return GOLAP_OK;
+            // (0xFFFFFFFF: hopelessly small -- the insert pass gave up early)
+            if (h.bound >= bound_max) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^28 distinct group keys");
+            h.bound = std::min<uint64_t>(bound_max, h.nd == 0xFFFFFFFFu ? h.bound * 16 : std::max<uint64_t>(h.bound * 4, (uint64_t)h.nd + h.nd / 8));
+            for (DevPtr* d : {&h.dout, &h.dcnt, &h.dkeys, &h.dn}) drop(*d);   // (the device is idle: the count was just read)
+        }
+    };
+    if (wide) {
+        // ---- key tuples beyond one int64 (hash-like ids in several columns; a full-range column with NULLs): GROUP BY on a 64-bit
+        //      surrogate of the tuple, every row then CHECKED against its group's representative row on the device; a surrogate shared
+        //      by two tuples (probability ~ groups^2 / 2^65) shows up as a mismatch and the grouping is repeated under another seed.
+        //      The result is exact or an error -- never a silently merged group. ----
+        golap_pack_keys_params kp;
+        memset(&kp, 0, sizeof kp);
+        kp.n_cols = (uint32_t)K; kp.n_rows = n;
+        for (size_t c = 0; c < K; ++c) { kp.col_ptrs[c] = keys[c].ptr; kp.validity_ptrs[c] = keys[c].vptr; }
+        DevPtr dsur, dslots, drep, dbad;
+        H_TRY(temp(dsur, n * 8));
+        H_TRY(temp(dslots, n * 4));
+        H_TRY(temp(dbad, 8));
+        kp.out_ptr = dsur->ptr;
+        Hashed h;
+        const uint64_t seeds[3] = {0x6A09E667F3BCC908ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull};
+        uint64_t bad = 1;
+        for (int attempt = 0; attempt < 3 && bad; ++attempt) {
+            if (attempt) { for (DevPtr* d : {&h.dout, &h.dcnt, &h.dkeys, &h.dn, &drep}) drop(*d); }
+            H_TRY(golap_hash_key_columns(ctx, &kp, seeds[attempt], nullptr));
+            H_TRY(run_hashed(dsur->ptr, dslots->ptr, h));
+            H_TRY(temp(drep, (uint64_t)std::max<uint32_t>(h.nd, 1) * 4));
+            H_TRY(golap_group_keys_verify(ctx, &kp, dslots->ptr, h.nd, drep->ptr, dbad->ptr, nullptr));
+            H_TRY(read_u64(dbad->ptr, &bad));
+        }
+        if (bad) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: three different 64-bit surrogates of the composite group key all collided (" + std::to_string(bad) + " rows)");
+        const uint32_t nd = h.nd;
+        // the groups' key tuples = the representative rows' (gathered on the device), the aggregates = the slots'
+        std::vector<std::vector<int64_t>> gk(K, std::vector<int64_t>(nd));
+        std::vector<std::vector<uint8_t>> gv(K);
+        std::vector<std::vector<double>> res(std::max<uint32_t>(na, 1), std::vector<double>(nd));
+        std::vector<DevPtr> dk(K), dv(K);
+        for (size_t c = 0; c < K && nd; ++c) {
+            H_TRY(temp(dk[c], (uint64_t)nd * 8));
+            H_TRY(golap_take_8byte(ctx, keys[c].ptr, drep->ptr, 0, nd, dk[c]->ptr, nullptr));
+            if (keys[c].vptr) {
+                H_TRY(temp(dv[c], nd));
+                H_TRY(golap_take_1byte(ctx, keys[c].vptr, drep->ptr, 0, nd, dv[c]->ptr, nullptr));
+                gv[c].resize(nd);
             }
         }
+        H_TRY(ksync());
+        for (size_t c = 0; c < K && nd; ++c) {
+            down(dk[c]->ptr, gk[c].data(), (uint64_t)nd * 8);
+            if (dv[c]) down(dv[c]->ptr, gv[c].data(), nd);
+        }
+        for (uint32_t i = 0; i < na; ++i) down(h.dout->ptr + (uint64_t)i * h.bound * 8, res[i].data(), (uint64_t)nd * 8);
+        H_TRY(flush());
+        std::vector<uint32_t> order(nd);
+        for (uint32_t i = 0; i < nd; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {     // rows sorted by (k0, k1, ...), NULLS LAST per column
+            for (size_t c = 0; c < K; ++c) {
+                const bool na_ = !gv[c].empty() && !gv[c][a], nb_ = !gv[c].empty() && !gv[c][b];
+                if (na_ != nb_) return nb_;
+                if (!na_ && gk[c][a] != gk[c][b]) return gk[c][a] < gk[c][b];
+            }
+            return false;
+        });
+        for (uint32_t slot : order) {
+            for (size_t c = 0; c < K; ++c) {
+                const bool is_null = !gv[c].empty() && !gv[c][slot];
+                const int64_t v = is_null ? 0 : gk[c][slot];
+                kcs[c].data.insert(kcs[c].data.end(), (const uint8_t*)&v, (const uint8_t*)&v + 8);
+                if (has_null[c]) kcs[c].in_valid.push_back(is_null ? 0 : 1);
+            }
+            for (uint32_t i = 0; i < na; ++i) acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&res[i][slot], (const uint8_t*)&res[i][slot] + 8);
+            ob.num_rows++;
+        }
+        return finish();
+    }
     uint64_t key_ptr = keys[0].ptr;
     int64_t kmin = mn[0], kmax = mx[0];
     if (packed) {
@@ -1026,51 +1131,23 @@ int32_t Exec::aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector
     const unsigned __int128 span = (unsigned __int128)((__int128)kmax - (__int128)kmin);
     const bool dense_keys = kmin >= 0 && span < (unsigned __int128)(64ull << 20) && span <= (unsigned __int128)(4 * n + 1024);
     if (!dense_keys) {
-        // the bound on the distinct keys starts modest and grows only when the data asks for it: every buffer below is sized from it
-        uint64_t bound = std::min<uint64_t>(n, 1ull << 22);
-        const uint64_t bound_max = std::min<uint64_t>(n, 1ull << 28);   // distinct keys <= rows; the key table holds at most 2^28 groups
-        for (;;) {
-            DevPtr dout, dcnt, dkeys, dn;
-            H_TRY(temp(dout, (uint64_t)std::max<uint32_t>(na, 1) * bound * 8));
-            H_TRY(temp(dcnt, bound * 8));
-            H_TRY(temp(dkeys, bound * 8));
-            H_TRY(temp(dn, 8));
-            memset(&ap, 0, sizeof ap);
-            ap.group_key_ptr = key_ptr; ap.value_ptrs = vptrs.data(); ap.n_value_cols = nv; ap.n_rows = n; ap.n_groups = (uint32_t)bound;
-            ap.value_validity_ptrs = any_value_nulls ? vvptrs.data() : nullptr;
-            ap.out_ptr = dout->ptr; ap.key_dtype = GOLAP_DT_INT64; ap.value_dtypes = vdt.data(); ap.out_count_ptr = dcnt->ptr;
-            ap.key_mode = GOLAP_KEYS_HASHED; ap.out_keys_ptr = dkeys->ptr; ap.out_n_groups_ptr = dn->ptr;
-            if (na == 0) {
-                golap_aggregate_spec cs{GOLAP_AGG_COUNT, 0, 0};
-                ap.value_ptrs = &key_ptr; ap.n_value_cols = 1; ap.value_dtypes = &kd; ap.value_validity_ptrs = nullptr;
-                H_TRY(golap_aggregate(ctx, &cs, 1, &ap, nullptr));
-            } else {
-                H_TRY(golap_aggregate(ctx, specs.data(), na, &ap, nullptr));
-            }
-            uint64_t nd64 = 0;
-            H_TRY(read_u64(dn->ptr, &nd64));
-            const uint32_t nd = (uint32_t)nd64;
-            if (nd > bound) {   // (0xFFFFFFFF: hopelessly small -- the insert pass gave up early)
-                if (bound >= bound_max) return herr(GOLAP_ERR_UNSUPPORTED, "GpuAggregate: more than 2^28 distinct group keys");
-                bound = std::min<uint64_t>(bound_max, nd == 0xFFFFFFFFu ? bound * 16 : std::max<uint64_t>(bound * 4, (uint64_t)nd + nd / 8));
-                for (DevPtr* d : {&dout, &dcnt, &dkeys, &dn}) drop(*d);   // (the device is idle: the count was just read)
-                continue;
-            }
-            std::vector<int64_t> gk(nd);
-            std::vector<std::vector<double>> res(std::max<uint32_t>(na, 1), std::vector<double>(nd));   // sized from the groups found, not from the bound
-            down(dkeys->ptr, gk.data(), (uint64_t)nd * 8);
-            for (uint32_t i = 0; i < na; ++i) down(dout->ptr + (uint64_t)i * bound * 8, res[i].data(), (uint64_t)nd * 8);
-            H_TRY(flush());
-            std::vector<uint32_t> order(nd);
-            for (uint32_t i = 0; i < nd; ++i) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return gk[a] < gk[b]; });   // rows sorted by key
-            for (uint32_t slot : order) {
-                emit_key(gk[slot]);
-                for (uint32_t i = 0; i < na; ++i) acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&res[i][slot], (const uint8_t*)&res[i][slot] + 8);
-                ob.num_rows++;
-            }
-            return finish();
+        Hashed h;
+        H_TRY(run_hashed(key_ptr, 0, h));
+        const uint32_t nd = h.nd;
+        std::vector<int64_t> gk(nd);
+        std::vector<std::vector<double>> res(std::max<uint32_t>(na, 1), std::vector<double>(nd));   // sized from the groups found, not from the bound
+        down(h.dkeys->ptr, gk.data(), (uint64_t)nd * 8);
+        for (uint32_t i = 0; i < na; ++i) down(h.dout->ptr + (uint64_t)i * h.bound * 8, res[i].data(), (uint64_t)nd * 8);
+        H_TRY(flush());
+        std::vector<uint32_t> order(nd);
+        for (uint32_t i = 0; i < nd; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return gk[a] < gk[b]; });   // rows sorted by key
+        for (uint32_t slot : order) {
+            emit_key(gk[slot]);
+            for (uint32_t i = 0; i < na; ++i) acs[i].data.insert(acs[i].data.end(), (const uint8_t*)&res[i][slot], (const uint8_t*)&res[i][slot] + 8);
+            ob.num_rows++;
         }
+        return finish();
     }
     const uint64_t G = (uint64_t)(kmax - kmin) + 1;
     DevPtr dout, dcnt;

@@ -457,6 +457,8 @@ typedef struct golap_aggregate_params {             /* aggregate_kernel.rs:47-58
                                     0 entry = that column has no NULLs.  SQL aggregates: SUM / MIN / MAX / AVG skip NULL values, COUNT counts
                                     the non-NULL ones; a group whose values are all NULL reports COUNT 0 and the reference's identities
                                     (executor.rs:308-311, :339-345).  out_count_ptr then counts the non-NULL rows of the LAST aggregated column. */
+    uint64_t out_slot_ids_ptr;   /* ABI 4, HASHED only, optional: device u32[n_rows], the slot (row of the outputs) every input row was aggregated
+                                    into -- what a caller needs to check rows against their group (golap_group_keys_verify) */
 } golap_aggregate_params;
 enum { GOLAP_KEYS_DENSE = 0, GOLAP_KEYS_HASHED = 1 };
 
@@ -525,6 +527,15 @@ typedef struct golap_pack_keys_params {
     uint64_t out_ptr;            /* device int64[n_rows] */
 } golap_pack_keys_params;
 int32_t golap_pack_group_keys(golap_ctx* ctx, const golap_pack_keys_params* params, void* stream);
+/* Composite keys that do NOT fit one int64 (physical_plan.rs:52-54 puts no bound on the key columns): GROUP BY runs on a 64-bit
+ * SURROGATE -- out[i] = a seeded 64-bit mix of the row's key tuple, a NULL in a column mixed in as its own symbol (NULLs group together,
+ * (NULL, 1) != (1, NULL)); params: col_ptrs / validity_ptrs / n_cols / n_rows / out_ptr (min_value, weight, null_digit unused) -- and
+ * is then CHECKED: golap_group_keys_verify names a representative row per slot (rep_rows[s] = the smallest row index aggregated into
+ * slot s) and counts the rows whose key tuple differs from their slot's representative.  0: every group holds exactly one tuple and
+ * the result is exact; otherwise two tuples shared a surrogate (probability ~ groups^2 / 2^65) and the caller repeats with another seed. */
+int32_t golap_hash_key_columns(golap_ctx* ctx, const golap_pack_keys_params* params, uint64_t seed, void* stream);
+int32_t golap_group_keys_verify(golap_ctx* ctx, const golap_pack_keys_params* params, uint64_t slot_ids_ptr /*u32[n_rows]*/, uint64_t n_slots,
+                                uint64_t out_rep_rows_ptr /*u32[n_slots]*/, uint64_t out_mismatch_ptr /*u64 device*/, void* stream);
 /* device -> device copy and byte fill in stream order (concatenating the batches of an operator's input) */
 int32_t golap_device_copy(golap_ctx* ctx, uint64_t src_ptr, uint64_t dst_ptr, uint64_t bytes, void* stream);
 int32_t golap_device_fill_u8(golap_ctx* ctx, uint64_t ptr, uint32_t value, uint64_t bytes, void* stream);

@@ -770,6 +770,25 @@ def test_surrogate_collisions_are_repaired(ctx, jt):
     _multi_check(ctx, b, p, jt, N.JOIN_BROADCAST_HASH, knobs={"GOLAP_GJ_HASH_BITS": "20"})
 
 
+@pytest.mark.parametrize("jt", [N.JT_INNER, N.JT_FULL])
+def test_composite_key_join_four_full_range_columns(ctx, jt):
+    """four Int64 key columns whose values span all of int64 (hash-like ids; a mixed-radix packing would need ~250 bits), NULLs in two of
+    them: surrogate keys + verification, against the oracle's multi-column NULL-aware join."""
+    rng = np.random.default_rng(77 + jt)
+    pool = [rng.integers(-2**63, 2**63 - 1, 40) for _ in range(4)]
+    nb, npr = 30_000, 45_000
+    tb = rng.integers(0, 40, (4, nb))
+    tp = rng.integers(0, 40, (4, npr))
+    tb[2:] = tb[:2] % 7                                   # (correlated columns: ~280 distinct tuples, so that tuples do meet)
+    tp[2:] = tp[:2] % 7
+    b = [pool[c][tb[c]] for c in range(4)]
+    p = [pool[c][tp[c]] for c in range(4)]
+    bv = [None, (rng.random(nb) > 0.05).astype(np.uint8), None, None]
+    pv = [None, None, (rng.random(npr) > 0.05).astype(np.uint8), None]
+    _multi_check(ctx, b, p, jt, N.JOIN_RADIX_HASH, bv, pv)
+    _multi_check(ctx, b, p, jt, N.JOIN_BROADCAST_HASH, bv, pv)
+
+
 def test_composite_key_join_large_radix(ctx):
     """4M x 6M rows, two key columns, through the radix path (surrogates are 64-bit: the 64-bit-row pipeline) -- device-checked."""
     n, m = 4_000_000, 6_000_000

@@ -362,15 +362,99 @@ def test_group_by_several_columns(ctx, with_nulls):
     assert [out.column(5)[i].as_py() for i in live] == [stats[i][2] for i in live] and [out.column(6)[i].as_py() for i in live] == [stats[i][3] for i in live]
 
 
-def test_group_by_composite_key_too_wide_is_refused(ctx):
-    """two hash-like 64-bit columns: the mixed-radix key would need ~126 bits -> a clear error, not a wrong answer"""
-    rng = np.random.default_rng(5)
-    a = rng.integers(-2**62, 2**62, 1000).astype(np.int64)
-    b = rng.integers(-2**62, 2**62, 1000).astype(np.int64)
-    rb = pa.RecordBatch.from_arrays([pa.array(a), pa.array(b), pa.array(np.ones(1000))], names=["a", "b", "v"])
-    with pytest.raises(O.OperatorError) as e:
-        O.execute(O.GpuAggregate(O.Batches([rb]), [O.Column(0, "a"), O.Column(1, "b")], [O.Sum(O.Column(2, "v"))]), ctx)
-    assert "62 bits" in str(e.value)
+_MASK = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+    return z ^ (z >> 31)
+
+
+def _surrogate(tup, seed):
+    """csrc/golap_ingest.hip k_hash_key_columns restated: the seeded 64-bit surrogate of a key tuple (None = NULL)"""
+    h = _mix64(seed ^ 0x243F6A8885A308D3)
+    for c, v in enumerate(tup):
+        x = (0x9E3779B97F4A7C15 * (c + 1)) & _MASK if v is None else v & _MASK
+        h = (_mix64(h ^ x) + (0xD1B54A32D192ED03 if v is None else 0x8CB92BA72F3D8DD7) * (c + 1)) & _MASK
+    return h
+
+
+_SEEDS = [0x6A09E667F3BCC908, 0xBB67AE8584CAA73B, 0x3C6EF372FE94F82B]      # the executor's, in the order it tries them
+
+
+def _wide_batches(rng, tuples, n, with_nulls):
+    """n rows drawn from `tuples` (two int64 key columns, None = NULL) + a value column with some NULLs, as two batches"""
+    pick = rng.integers(0, len(tuples), n)
+    a = [tuples[i][0] for i in pick]
+    b = [tuples[i][1] for i in pick]
+    v = rng.integers(-50, 50, n).astype(np.float64)
+    vn = rng.random(n) < (0.1 if with_nulls else 0.0)
+    cols = [pa.array(a, pa.int64()), pa.array(b, pa.int64()), pa.array([None if m else float(x) for x, m in zip(v, vn)], pa.float64())]
+    cut = n // 3
+    bs = [pa.RecordBatch.from_arrays([x[:cut] for x in cols], names=["a", "b", "v"]), pa.RecordBatch.from_arrays([x[cut:] for x in cols], names=["a", "b", "v"])]
+    kn = [np.array([x is None for x in a]), np.array([x is None for x in b])]
+    return bs, [np.array([0 if x is None else x for x in a], dtype=object), np.array([0 if x is None else x for x in b], dtype=object)], kn, v, vn
+
+
+def _check_grouped(out, keys, kn, v, vn):
+    order, stats = _group_by_expected(keys, kn, v, vn)
+    assert list(zip(out.column(0).to_pylist(), out.column(1).to_pylist())) == order
+    assert out.column(2).to_pylist() == [s[0] for s in stats] and out.column(3).to_pylist() == [float(s[1]) for s in stats]
+
+
+@pytest.mark.parametrize("with_nulls", [False, True])
+def test_group_by_composite_keys_beyond_62_bits(ctx, with_nulls):
+    """physical_plan.rs:52-54 puts no bound on the group-by columns: two hash-like 64-bit columns (the mixed-radix key would need ~126
+    bits; round 3 refused them) are grouped on a 64-bit surrogate of the tuple and every row is then checked against its group's
+    representative row on the device -- exact or an error, never a merged group.  Against a pure-Python GROUP BY over the tuples."""
+    rng = np.random.default_rng(5 + with_nulls)
+    tuples = [(int(x), int(y)) for x, y in zip(rng.integers(-2**62, 2**62, 700), rng.integers(-2**62, 2**62, 700))]
+    if with_nulls:
+        tuples += [(None, tuples[3][1]), (tuples[3][0], None), (None, None), (None, tuples[9][1])]
+    bs, keys, kn, v, vn = _wide_batches(rng, tuples, 60_000, with_nulls)
+    out = O.execute(O.GpuAggregate(O.Batches(bs), [O.Column(0, "a"), O.Column(1, "b")], [O.Sum(O.Column(2, "v")), O.Count(O.Column(2, "v"))]), ctx)[0]
+    _check_grouped(out, keys, kn, v, vn)
+
+
+def test_group_by_one_full_range_column_with_nulls(ctx):
+    """ONE key column whose values span (almost) all of int64, with NULLs: value - min + a NULL digit does not fit 62 bits either --
+    the same surrogate route (the column without NULLs would take the plain hashed GROUP BY)."""
+    rng = np.random.default_rng(8)
+    pool = [np.iinfo(np.int64).min, np.iinfo(np.int64).max, -1, 0, 1, 1 << 62, -(1 << 62), None] + [int(x) for x in rng.integers(-2**63, 2**63 - 1, 50)]
+    n = 30_000
+    pick = rng.integers(0, len(pool), n)
+    g = [pool[i] for i in pick]
+    v = rng.integers(0, 100, n).astype(np.float64)
+    rb = pa.RecordBatch.from_arrays([pa.array(g, pa.int64()), pa.array(v)], names=["g", "v"])
+    out = O.execute(O.GpuAggregate(O.Batches([rb]), [O.Column(0, "g")], [O.Sum(O.Column(1, "v")), O.Count(O.Column(1, "v"))]), ctx)[0]
+    order, stats = _group_by_expected([np.array([0 if x is None else x for x in g], dtype=object)], [np.array([x is None for x in g])], v, np.zeros(n, bool))
+    assert out.column(0).to_pylist() == [k[0] for k in order] and out.column(0).to_pylist()[-1] is None
+    assert out.column(1).to_pylist() == [s[0] for s in stats] and out.column(2).to_pylist() == [float(s[1]) for s in stats]
+
+
+def test_group_by_surrogate_collisions_are_caught_and_reseeded(ctx):
+    """With the surrogates narrowed (GOLAP_SURROGATE_BITS) two different tuples DO share one.  A set of tuples is searched (on the CPU,
+    with the kernel's hash restated above) for which the executor's first seed collides and its second does not: the verify pass must
+    see the first, the second attempt must deliver the exact groups.  With 3 bits every seed collides: an error, not a merged group."""
+    bits = 11
+    for trial in range(200):
+        rng = np.random.default_rng(1000 + trial)
+        tuples = [(int(x), int(y)) for x, y in zip(rng.integers(-2**62, 2**62, 60), rng.integers(-2**62, 2**62, 60))]
+        dup = [len({_surrogate(t, s) & ((1 << bits) - 1) for t in tuples}) < len(tuples) for s in _SEEDS]
+        if dup[0] and not dup[1]:
+            break
+    else:
+        pytest.fail("no tuple set found whose first seed collides and second does not")
+    bs, keys, kn, v, vn = _wide_batches(rng, tuples, 20_000, False)
+    plan = lambda: O.GpuAggregate(O.Batches(bs), [O.Column(0, "a"), O.Column(1, "b")], [O.Sum(O.Column(2, "v")), O.Count(O.Column(2, "v"))])
+    with ctx.knobs(GOLAP_SURROGATE_BITS=str(bits)):
+        out = O.execute(plan(), ctx)[0]
+    _check_grouped(out, keys, kn, v, vn)
+    with ctx.knobs(GOLAP_SURROGATE_BITS="3"):
+        with pytest.raises(O.OperatorError) as e:
+            O.execute(plan(), ctx)
+    assert "collided" in str(e.value)
 
 
 def test_group_by_all_null_keys_is_one_null_group(ctx):

@@ -565,10 +565,15 @@ def test_sharded_aggregate_ranks_share_one_gpu(world, groups, hashed):
             assert np.array_equal(r[2], full) and np.array_equal(r[3].astype(np.float64), full[1])
 
 
-def _composite_rows(n, clean=None, cols=2):
-    """clean = (lo, hi): rows [lo, hi) of every column are valid -- the shard of a rank that is handed NO validity arrays"""
+def _composite_rows(n, clean=None, cols=2, wide=False):
+    """clean = (lo, hi): rows [lo, hi) of every column are valid -- the shard of a rank that is handed NO validity arrays.
+    wide: the two columns' values are drawn from pools that span all of int64 (a mixed-radix packing would need ~128 bits)"""
     rng = np.random.default_rng(n + 3)
-    mk = lambda: (rng.integers(-40, 40, n).astype(np.int64), rng.integers(1000, 1030, n).astype(np.int64))
+    if wide:
+        pool0, pool1 = rng.integers(-2**63, 2**63 - 1, 3000), rng.integers(-2**63, 2**63 - 1, 30)
+        mk = lambda: (pool0[rng.integers(0, 3000, n)], pool1[rng.integers(0, 30, n)])
+    else:
+        mk = lambda: (rng.integers(-40, 40, n).astype(np.int64), rng.integers(1000, 1030, n).astype(np.int64))
     (b0, b1), (p0, p1) = mk(), mk()
     bv = [(rng.random(n) > 0.05).astype(np.uint8), None]
     pv = [(rng.random(n) > 0.05).astype(np.uint8), (rng.random(n) > 0.05).astype(np.uint8)]
@@ -576,11 +581,13 @@ def _composite_rows(n, clean=None, cols=2):
         for v in (bv[0], pv[0], pv[1]):
             v[clean[0]:clean[1]] = 1
     if cols == 1:    # one key column with a few hundred distinct values (both sides), NULLs on both
+        if wide:
+            return [b0], [p0], bv[:1], pv[:1]
         return [b0 * 7 + b1], [p0 * 7 + p1], bv[:1], pv[:1]
     return [b0, b1], [p0, p1], bv, pv
 
 
-def _worker_composite(rank, world, port, n, jt, q, plain_rank=-1, cols=2, mode=None):
+def _worker_composite(rank, world, port, n, jt, q, plain_rank=-1, cols=2, mode=None, wide=False, knobs=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -591,8 +598,10 @@ def _worker_composite(rank, world, port, n, jt, q, plain_rank=-1, cols=2, mode=N
         torch.cuda.set_device(0)
         c = Context(max_gpu_memory=0)
         lo, hi = shard_range(n, rank, world)
-        bc, pc, bv, pv = _composite_rows(n, shard_range(n, plain_rank, world) if plain_rank >= 0 else None, cols)
+        bc, pc, bv, pv = _composite_rows(n, shard_range(n, plain_rank, world) if plain_rank >= 0 else None, cols, wide)
         cu = lambda a: None if a is None else torch.from_numpy(a[lo:hi]).cuda()
+        for k, v in (knobs or {}).items():
+            c.debug_set(k, v)
         if mode == "fast":
             c.debug_set("GOLAP_SHARD_FAST", "1")
             c.debug_set("GOLAP_LOCAL_BITS", "6")
@@ -659,6 +668,38 @@ def test_sharded_join_ranks_disagree_about_validity_arrays(world, jt, cols, plai
         pr.join(timeout=60)
         assert pr.exitcode == 0
     bc, pc, bv, pv = _composite_rows(n, shard_range(n, plain_rank, world), cols)
+    exp, me = oracle.hash_join_multi(bc, pc, jt, bv, pv)
+    got = canonical(np.concatenate([r[1] for r in res]))
+    assert got.shape[0] == me and np.array_equal(got, exp)
+
+
+
+@pytest.mark.parametrize("world,jt,cols,knobs", [(2, 0, 2, None), (4, 3, 2, None), (2, 1, 1, None), (2, 2, 2, {"GOLAP_GJ_HASH_BITS": "27"}),
+                                                 (2, 3, 2, {"GOLAP_GJ_HASH_BITS": "27"}), (2, 3, 2, {"GOLAP_SHARD_WIDE_KEYS": "1"})])
+def test_sharded_join_key_tuples_beyond_62_bits(world, jt, cols, knobs):
+    """physical_plan.rs:35-36 puts no bound on the key columns.  Two columns of hash-like 64-bit values (or ONE such column with NULLs)
+    do not fit the exact mixed-radix key: the ranks join on a 64-bit surrogate of the tuple and ship the real columns with the rows;
+    the owner of a partition joins on positions, checks every pair against the shipped columns, and only then emits global row ids.
+    With the surrogates narrowed to 27 bits (GOLAP_GJ_HASH_BITS) a handful of different tuples DO share one (~12 false pairs expected over
+    the 40K x 40K rows): they must be found and removed, and an outer join must give a row that thereby lost its only partner its
+    unmatched pair.  GOLAP_SHARD_WIDE_KEYS=1 sends small-range tuples (many duplicates per tuple) down the same route.  Against the
+    oracle's multi-column join."""
+    import oracle
+    import torch.multiprocessing as mp
+    from np_twin import canonical
+    n = 40_000
+    wide = not (knobs and "GOLAP_SHARD_WIDE_KEYS" in knobs)      # (last case: small value ranges forced onto the same route)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_composite, args=(r, world, port, n, jt, q, -1, cols, None, wide, knobs)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    bc, pc, bv, pv = _composite_rows(n, None, cols, wide)
     exp, me = oracle.hash_join_multi(bc, pc, jt, bv, pv)
     got = canonical(np.concatenate([r[1] for r in res]))
     assert got.shape[0] == me and np.array_equal(got, exp)
