@@ -369,7 +369,11 @@ typedef struct golap_sharded_join_params {
      * (column 0 = build_key_ptr / probe_key_ptr) and one validity byte array per column (0 pointer = no NULLs; a row with a NULL in any
      * key column matches nothing, an outer join keeps it as an unmatched row).  The ranks agree on every column's value range
      * (one small all-gather, read by the host) and join on the exact mixed-radix number of the columns' digits -- no hashing, no
-     * collisions; a composite wider than 62 bits is refused on every rank alike (GOLAP_ERR_UNSUPPORTED). */
+     * collisions.  A tuple wider than 62 bits (hash-like ids in several columns; ONE full-range column with NULLs) cannot be packed:
+     * the ranks then join on a 64-bit surrogate of the tuple and ship the real key columns with the rows; the owner of a partition
+     * checks every pair against them before it emits global row ids (exact path; ABI 4 -- ABI 3 refused such keys).
+     * Validity arrays may be given on some ranks only (a shard without NULLs has none): the call's first agreement round settles
+     * the form for all ranks. */
     uint32_t n_key_cols;                         /* 0 or 1: one key column */
     uint32_t reserved0;
     uint64_t build_key_extra[3], probe_key_extra[3];
