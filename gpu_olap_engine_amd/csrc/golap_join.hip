@@ -2289,6 +2289,8 @@ static void launch_part2_ring(hipStream_t st, uint32_t G, uint64_t in_rows, uint
     PassCfg cfg = cfg_in;
     { const char* e = knob("GOLAP_P2R_ROT"); cfg.piece_rot_off = e && !strcmp(e, "0") ? 1u : 0u; }
     const int v2 = p2r_variant();
+    // (ring rows = 16384 / F.  Shorter rings were tried once more in round 4 at the mid sizes -- F = 128: 128 rows 0.746 ms, 64 rows 0.790,
+    //  32 rows 1.152 per 2 x 100M rows; F = 256: 64 rows 2.177, 32 rows 2.907 per 2 x 300M -- the longest ring that fits is the fastest)
     const uint32_t R = part2_ring_rows(cfg.F);
 #define GOLAP_P2R(RR, ASM, ...)                                                                                                           \
     hipLaunchKernelGGL((k_part2_ring<4, RR, ASM, ##__VA_ARGS__>), dim3(G), dim3(P2R_THREADS), part2_ring_lds_bytes(cfg.F, RR), st, (const uint2*)in_rows, \
