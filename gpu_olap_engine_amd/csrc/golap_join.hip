@@ -1055,18 +1055,31 @@ __device__ __forceinline__ unsigned long long jn_reserve(uint32_t* s_wt, unsigne
 // than one table chunk (then "unmatched" is only known after the last chunk).
 // NARROW: both sides are (key32, row id) tuple arrays (see ReserveArgs); gate/gate_skip: run_if / skip_if on the
 // device word that says whether the narrow pipeline was abandoned.
-template <int JT, bool NARROW>
+// K16 (round 4, tuple pipeline only): the table keeps the UPPER 16 bits of a tuple's first word.  The word is hash_int32(key32 ^ key_hi),
+// a bijection of the key, and every row of a sub-partition shares the hash bits the partition passes consumed -- with >= 16 of them
+// (18 at 1B rows) the upper half decides equality.  8 KiB of keys instead of 16 and 1920 chain heads instead of 2048: 39.8 KiB per
+// work-group, FOUR per CU instead of three (the kernel is bound by per-work-group latency chains).
+constexpr int JN_HEADS16 = 1920;
+template <int JT, bool NARROW, bool K16 = false>
 __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const JoinSide& B, const JoinSide& P, uint2* __restrict__ out_pairs,
                                                    unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
                                                    uint32_t* __restrict__ probe_hit) {
+    static_assert(!K16 || NARROW, "16-bit table keys are a form of the tuple pipeline");
     constexpr bool KEEP_B = (JT & 1) != 0, KEEP_P = (JT & 2) != 0;
     using KeyT = typename JoinKey<NARROW>::type;
+    using TabT = typename std::conditional<K16, uint16_t, KeyT>::type;
     // chain heads: 4096 for the 72 KiB wide table (two work-groups per CU either way); 2048 for the narrow one, whose
     // 48 KiB then fit three work-groups per CU -- the kernel is bound by per-work-group latency chains, not by LDS reads
     constexpr int LOG2S = NARROW ? JN_LOG2_SLOTS - 1 : JN_LOG2_SLOTS;
-    __shared__ KeyT t_keys[JN_CAP];
+    constexpr int NHEADS = K16 ? JN_HEADS16 : (1 << LOG2S);
+    auto tab_key = [](KeyT k) -> TabT { return K16 ? (TabT)((uint32_t)k >> 16) : (TabT)k; };
+    auto slot_of_key = [](KeyT k) -> uint32_t {
+        if (K16) return (uint32_t)(((unsigned long long)((uint32_t)k * 0x9E3779B1u) * (uint32_t)JN_HEADS16) >> 32);   // (32-bit multiply + mul-hi range reduction)
+        return slot_hash((long long)k, LOG2S);
+    };
+    __shared__ TabT t_keys[JN_CAP];
     __shared__ uint32_t t_rids[JN_CAP];
-    __shared__ uint32_t heads[1 << LOG2S];
+    __shared__ uint32_t heads[NHEADS];
     __shared__ uint16_t t_next[JN_CAP];
     __shared__ uint8_t t_hit[KEEP_B ? JN_CAP : 4];
     __shared__ uint32_t s_wt[JN_R * JN_WAVES];
@@ -1118,7 +1131,7 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
     }
     for (uint32_t bc = b0; bc < b1; bc += JN_CAP) {
         const uint32_t nb = b1 - bc < (uint32_t)JN_CAP ? b1 - bc : (uint32_t)JN_CAP;
-        for (uint32_t h = tid; h < (1u << LOG2S); h += JN_THREADS) heads[h] = JN_EMPTY;
+        for (uint32_t h = tid; h < (uint32_t)NHEADS; h += JN_THREADS) heads[h] = JN_EMPTY;
         if (KEEP_B)
             for (uint32_t h = tid; h < (uint32_t)JN_CAP; h += JN_THREADS) t_hit[h] = 0;
         lds_barrier();
@@ -1135,9 +1148,9 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
             for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {
                 const uint32_t i = r * JN_THREADS + tid;
                 if (i < nb) {
-                    t_keys[i] = bk[r];
+                    t_keys[i] = tab_key(bk[r]);
                     t_rids[i] = brd[r];
-                    const uint32_t old = atomicExch(&heads[slot_hash((long long)bk[r], LOG2S)], i);   // join_kernels.cuh:109
+                    const uint32_t old = atomicExch(&heads[slot_of_key(bk[r])], i);   // join_kernels.cuh:109
                     t_next[i] = (uint16_t)old;                                                     // :110 (0xFFFFFFFF -> 0xFFFF)
                 }
             }
@@ -1163,9 +1176,9 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
                 uint32_t c = 0, f = 0xFFFFu;
                 const bool valid = first[r] != JN_EMPTY;
                 if (valid) {
-                    uint32_t e = heads[slot_hash((long long)pk[r], LOG2S)] & 0xFFFFu;
+                    uint32_t e = heads[slot_of_key(pk[r])] & 0xFFFFu;
                     while (e != 0xFFFFu) {
-                        if (t_keys[e] == pk[r]) {   // full-key compare (:152-153)
+                        if (t_keys[e] == tab_key(pk[r])) {   // full-key compare (:152-153; K16: the bits the partition passes have not already compared)
                             if (c == 0) f = e;
                             ++c;
                             if (KEEP_B) t_hit[e] = 1;   // same value from every writer: a plain store is enough
@@ -1204,7 +1217,7 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
                     uint32_t e = first[r];
                     uint32_t left = cnt[r];
                     for (;;) {
-                        if (t_keys[e] == pk[r]) {
+                        if (t_keys[e] == tab_key(pk[r])) {
                             if (pos < max_pairs) out_pairs[pos] = make_uint2(t_rids[e], prid[r]);   // join_kernels.cuh:157-160
                             ++pos;
                             if (--left == 0) break;
@@ -1272,13 +1285,14 @@ template <int JT, bool NARROW = false, bool STRIDE = false>
 __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
                                                          unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
                                                          uint32_t* __restrict__ probe_hit, uint32_t n_sub, const uint32_t* __restrict__ run_if,
-                                                         const uint32_t* __restrict__ skip_if
+                                                         const uint32_t* __restrict__ skip_if, const uint32_t* __restrict__ only_if_dict
 #ifdef GOLAP_DIAG   // timing-only experiment (WRONG results): n_spread output counters instead of one -- what does the single counter cost?
                                                          , unsigned long long* __restrict__ spread, uint32_t n_spread
 #endif
                                                          ) {
     if (run_if && *run_if == 0) return;
     if (skip_if && *skip_if != 0) return;
+    if (only_if_dict && *only_if_dict <= 1u) return;   // (k_join_lds16 in front has done the join)
 #ifdef GOLAP_DIAG
     if (n_spread) { out_count = spread + (size_t)(blockIdx.x % n_spread) * 16; max_pairs = max_pairs > (1u << 20) ? max_pairs - (1u << 20) : 0; }
 #endif
@@ -1292,6 +1306,20 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_lds(JoinSide B, JoinSide P,
     }
 }
 static_assert(JN_CAP / JN_THREADS == JN_R, "the unmatched-build pass reuses the (slice, wave) scan layout");
+
+// The tuple join with 16-bit table keys (join_sub_partition<.., K16>): four work-groups per CU = 8 waves per SIMD = 64 registers.
+// dict_n (device word, PassCfg::key_hi[KEY_DICT_MAX]): with more than one upper key half the tuples' first word is not the plain hash
+// (dictionary / window forms) and its upper 16 bits do not decide equality -- this kernel then returns at once and k_join_lds,
+// enqueued behind it with the same word, does the join (and returns at once otherwise).
+template <int JT>
+__global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_join_lds16(JoinSide B, JoinSide P, uint2* __restrict__ out_pairs,
+                                                         unsigned long long* __restrict__ out_count, unsigned long long max_pairs,
+                                                         uint32_t* __restrict__ probe_hit, const uint32_t* __restrict__ skip_if,
+                                                         const uint32_t* __restrict__ dict_n) {
+    if (skip_if && *skip_if != 0) return;
+    if (dict_n && *dict_n > 1u) return;
+    join_sub_partition<JT, true, true>(blockIdx.x, B, P, out_pairs, out_count, max_pairs, probe_hit);
+}
 
 // ---------------------------------------------------------------------------
 // BroadcastHashJoin (join_kernel.rs:62-68): one global chained table over the whole
@@ -2101,10 +2129,13 @@ static uint64_t radix_join_ws_bytes(const JoinPlan& plan, uint64_t n_build, uint
 
 // shared tail: both sides partitioned -> LDS join.  narrow: both sides are (key32, row id) tuple arrays; run_if / skip_if:
 // device gates of the narrow-then-wide scheme (see ReserveArgs); probe_hit_shared: bitmap allocated by the caller.
+// hashed_key_hi (tuple joins only, may be null): PassCfg::key_hi of tuples whose first word is hash_int32(key32 ^ key_hi) -- with >= 16
+// hash bits consumed by the partition passes the join runs in its 16-bit-key form (k_join_lds16) unless the column turned out to
+// have several upper halves.
 static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& plan, const SideResult& b, const SideResult& p, uint64_t n_build,
                                uint64_t n_probe, uint64_t out_pairs, uint64_t out_count, uint64_t max_pairs, int32_t join_type = 0,
                                bool narrow = false, const uint32_t* run_if = nullptr, const uint32_t* skip_if = nullptr,
-                               uint32_t* probe_hit_shared = nullptr) {
+                               uint32_t* probe_hit_shared = nullptr, const uint32_t* hashed_key_hi = nullptr) {
     JoinSide B{b.keys, b.rids, b.off, b.stride, b.alt_start, b.alt_len, b.flag}, P{p.keys, p.rids, p.off, p.stride, p.alt_start, p.alt_len, p.flag};
     uint32_t* probe_hit = probe_hit_shared;
     if ((join_type & 2) && !probe_hit) {   // Right / Full: bitmap over probe positions for the (rare) multi-chunk sub-partitions
@@ -2123,6 +2154,24 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     if (const char* e = knob("GOLAP_JOIN_STRIDE_GRID")) stride_grid = (uint32_t)std::max(1, atoi(e));   // debug hook
     const dim3 grid(run_if ? std::min<uint32_t>(n_sub, stride_grid) : n_sub), block(JN_THREADS);   // stand-by launch: small striding grid
     unsigned long long* oc = (unsigned long long*)out_count;
+    // 16-bit table keys: tuples carry the plain hash (hashed_key_hi given) and the passes have consumed >= 16 of its bits
+    uint32_t consumed = 0;
+    if (!plan.passes.empty()) consumed = plan.passes.back().cfg.shift + plan.passes.back().bits;
+    // ... and the sub-partitions are large enough for the fourth work-group per CU to pay (measured, join kernel alone, 32-bit -> 16-bit
+    // table: 1B x 1B, 3815 build rows per sub-partition, 4.68 -> 4.27 ms; 800M, 3052 rows, 4.06 -> 3.87; 600M, 2289 rows, 3.56 -> 3.68;
+    // 300M, [9,8], 2289 rows, 1.79 -> 1.82; 1.5B, two table chunks per sub-partition, 14.10 -> 14.03)
+    const char* k16_env = knob("GOLAP_JOIN_K16");   // "0": the 32-bit table for every tuple join, "1": the 16-bit one whenever it is valid (A/B hooks)
+    const bool k16_pays = (k16_env && !strcmp(k16_env, "1")) || n_build / std::max<uint32_t>(1, n_sub) >= 2700;
+    const bool k16 = narrow && hashed_key_hi && !run_if && consumed >= 16 && k16_pays && !(k16_env && !strcmp(k16_env, "0"));
+    const uint32_t* dict_n = k16 ? hashed_key_hi + KEY_DICT_MAX : nullptr;
+    if (k16) {
+        switch (join_type) {
+            case 0: hipLaunchKernelGGL((k_join_lds16<0>), dim3(n_sub), block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, skip_if, dict_n); break;
+            case 1: hipLaunchKernelGGL((k_join_lds16<1>), dim3(n_sub), block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, skip_if, dict_n); break;
+            case 2: hipLaunchKernelGGL((k_join_lds16<2>), dim3(n_sub), block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, skip_if, dict_n); break;
+            default: hipLaunchKernelGGL((k_join_lds16<3>), dim3(n_sub), block, 0, st, B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, skip_if, dict_n); break;
+        }
+    }
 #ifdef GOLAP_DIAG
     uint32_t n_spread = 0;
     unsigned long long* spread = nullptr;
@@ -2134,9 +2183,9 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
             GOLAP_TRY(zero_async(ctx, st, spread, (uint64_t)n_spread * 128));
         }
     }
-#define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if, spread, n_spread
+#define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if, dict_n, spread, n_spread
 #else
-#define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if
+#define GOLAP_JN_ARGS B, P, (uint2*)out_pairs, oc, (unsigned long long)max_pairs, probe_hit, n_sub, run_if, skip_if, dict_n
 #endif
 #define GOLAP_JN(JT)                                                                                          \
     if (narrow)                                                                                               \
@@ -2462,7 +2511,7 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
         GOLAP_TRY(run_side_narrow(ctx, st, plan, p->build_key_ptr, p->build_rid_base, p->n_build, bb.tmp_keys[0], bb.final_keys, words, words + 1, nb_, key_hi, cursors[0]));
         GOLAP_TRY(run_side_narrow(ctx, st, plan, p->probe_key_ptr, p->probe_rid_base, p->n_probe, pb.tmp_keys[0], pb.final_keys, words, words + 1, np_, key_hi, cursors[1]));
         GOLAP_TRY(launch_lds_join(ctx, st, plan, nb_, np_, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type,
-                                  true, nullptr, words, probe_hit));
+                                  true, nullptr, words, probe_hit, key_hi));   // (key_hi is only set when both passes are the hashed-tuple kernels)
         gate = words;
     }
     GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build_key_ptr, 0, p->build_rid_base, p->n_build, nullptr, bb, rb, gate));

@@ -794,7 +794,7 @@ static int32_t sharded_join_fast(golap_ctx* ctx, golap_comm* cm, const golap_sha
         jp.n_sub = (uint64_t)gc * F2;
         if (h == 0) stamp(2 * GOLAP_SHARD_ST_JOIN, st);
         GOLAP_TRY(launch_lds_join(ctx, st, jp, hb, hp, cm->info.rows_received[0] / H, cm->info.rows_received[1] / H, p->out_pairs_ptr, p->out_count_ptr,
-                                  p->max_pairs, p->join_type, true, nullptr, words, probe_hit));
+                                  p->max_pairs, p->join_type, true, nullptr, words, probe_hit, cfg1.pre_hashed ? (const uint32_t*)cfg1.key_hi : nullptr));
     }
     stamp(2 * GOLAP_SHARD_ST_JOIN + 1, st);
     // ---- did the narrow attempt hold on EVERY rank?  (all ranks must take the same path: the words are gathered) ----
