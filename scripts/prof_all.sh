@@ -26,6 +26,7 @@ run ops_C4L 1000000000x1 --config C4L --steps 3 --warmup 1
 run ops_C1 1000000x1 --config C1 --steps 20 --warmup 2
 run bench_C3 100000000x1 --config C3 --steps 3 --warmup 1 --no-wide
 run bench_1b_wide 1000000000x1 --steps 3 --warmup 1 --no-wide --no-others --keys random
+run ops_OP 100000000x1 --config OP --steps 2 --warmup 1
 # the partition-exchange path at world size 1 (stage timestamps in the line): unprofiled line only
 (cd $ROOT && python3 bench.py --sharded --gpus 1 --steps 5 --cpu-sample 0 2>/dev/null | grep '^{' | tail -1 > $KEEP/sharded_1gpu_bench_line.json)
 cp $ROOT/profiles/pmc_traffic.json $KEEP/pmc_traffic.json
