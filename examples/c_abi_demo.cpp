@@ -28,7 +28,8 @@ int main() {
     if (st != GOLAP_OK) { fprintf(stderr, "ctx_create -> %d: %s\n", st, golap_last_error(nullptr)); return st == GOLAP_ERR_NO_DEVICE ? 77 : 1; }
     golap_device_info info;
     CK(golap_device_info_get(ctx, &info));
-    printf("device: %s (%s), %u CUs, wave %u\n", info.name, info.gcn_arch, info.compute_units, info.wavefront_size);
+    printf("device: %s (%s), %u CUs, wave %u; library built with %s, hidden-memory kernel forms %s (audited with %s)\n", info.name, info.gcn_arch, info.compute_units,
+           info.wavefront_size, info.built_with, info.hidden_memory_forms ? "on" : "off", info.audited_with);
 
     const uint64_t nb = 200000, np = 300000;
     std::vector<int64_t> bk(nb), pk(np), pv(np);
@@ -105,6 +106,55 @@ int main() {
     for (uint64_t j = 0; j < np; ++j) { s += (double)pv[j]; mn = std::min(mn, (double)pv[j]); mx = std::max(mx, (double)pv[j]); }
     printf("aggregate: sum %.1f count %.0f min %.0f max %.0f avg %.6f\n", agg[0], agg[1], agg[2], agg[3], agg[4]);
     if (agg[0] != s || agg[1] != (double)np || agg[2] != mn || agg[3] != mx || agg[4] != s / (double)np) return 4;
+
+    // ---- device-side ingest and materialisation (ABI 4; record_batch_convert.rs:35-110 and :146-178 without a host loop): an Int32 column
+    //      with an Arrow validity BITMAP goes up as it is (4 bytes per row + 1 bit), is expanded / widened / zero-filled on the device,
+    //      filtered (a NULL never passes), gathered with its validity, and comes back as values + bitmap + NULL count ----
+    {
+        const uint64_t n = 100003;
+        std::vector<int32_t> col(n);
+        std::vector<uint8_t> bitmap((n + 7) / 8, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            col[i] = (int32_t)((i * 2654435761ull) % 2000) - 1000;
+            if (i % 7 != 3) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));       // every 7th row NULL
+        }
+        Slab draw, dbits, dval, dwide, didx, dn, dtake, dtv, dpackv, dnulls;
+        CK(alloc(n * 4, draw)); CK(alloc(bitmap.size(), dbits)); CK(alloc(n, dval)); CK(alloc(n * 8, dwide)); CK(alloc(n * 4, didx)); CK(alloc(8, dn));
+        CK(alloc(n * 8, dtake)); CK(alloc(n, dtv)); CK(alloc((n + 7) / 8, dpackv)); CK(alloc(8, dnulls));
+        CK(golap_xfer_enqueue(ctx, GOLAP_HOST_TO_DEVICE, (uint64_t)col.data(), draw.ptr, n * 4, 0));
+        CK(golap_xfer_enqueue(ctx, GOLAP_HOST_TO_DEVICE, (uint64_t)bitmap.data(), dbits.ptr, bitmap.size(), 1));
+        CK(golap_xfer_synchronize(ctx));
+        CK(golap_expand_validity(ctx, dbits.ptr, 0, n, dval.ptr, nullptr));                          // is_valid(i) per row, :36-40
+        CK(golap_widen_to_8byte(ctx, draw.ptr, GOLAP_WIDEN_I32, dval.ptr, n, dwide.ptr, nullptr));   // as i64, NULL -> 0, :102-110
+        golap_filter_predicate neg{0, golap_parse_cmp_op("<"), 0};
+        CK(golap_filter_compact_nullable(ctx, &neg, dwide.ptr, dval.ptr, n, didx.ptr, dn.ptr, nullptr));
+        CK(golap_ctx_synchronize(ctx, nullptr));
+        uint64_t kept = 0;
+        CK(golap_xfer_enqueue(ctx, GOLAP_DEVICE_TO_HOST, dn.ptr, (uint64_t)&kept, 8, 0));
+        CK(golap_xfer_synchronize(ctx));
+        CK(golap_take_8byte(ctx, dwide.ptr, didx.ptr, 0, kept, dtake.ptr, nullptr));                 // take_int64, executor.rs:496-507
+        CK(golap_take_1byte(ctx, dval.ptr, didx.ptr, 0, kept, dtv.ptr, nullptr));                    // ... and the rows' validity
+        CK(golap_pack_validity(ctx, dval.ptr, n, dpackv.ptr, dnulls.ptr, nullptr));                  // buffer_to_array's bitmap, :146-178
+        CK(golap_ctx_synchronize(ctx, nullptr));
+        std::vector<int64_t> got(kept);
+        std::vector<uint8_t> gotv(kept), back(bitmap.size());
+        uint64_t nulls = 0;
+        CK(golap_xfer_enqueue(ctx, GOLAP_DEVICE_TO_HOST, dtake.ptr, (uint64_t)got.data(), kept * 8, 0));
+        CK(golap_xfer_enqueue(ctx, GOLAP_DEVICE_TO_HOST, dtv.ptr, (uint64_t)gotv.data(), kept, 1));
+        CK(golap_xfer_enqueue(ctx, GOLAP_DEVICE_TO_HOST, dpackv.ptr, (uint64_t)back.data(), back.size(), 2));
+        CK(golap_xfer_enqueue(ctx, GOLAP_DEVICE_TO_HOST, dnulls.ptr, (uint64_t)&nulls, 8, 3));
+        CK(golap_xfer_synchronize(ctx));
+        uint64_t e = 0, bad = 0, enulls = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            const bool valid = i % 7 != 3;
+            enulls += !valid;
+            if (valid && col[i] < 0) { bad += e >= kept || got[e] != (int64_t)col[i] || gotv[e] != 1; ++e; }
+        }
+        printf("ingest: %llu negative non-NULL rows kept (expected %llu), %llu mismatches, %llu NULLs (expected %llu), bitmap %s\n", (unsigned long long)kept,
+               (unsigned long long)e, (unsigned long long)bad, (unsigned long long)nulls, (unsigned long long)enulls, back == bitmap ? "round-trips" : "DIFFERS");
+        if (kept != e || bad || nulls != enulls || back != bitmap) return 5;
+        for (Slab* sl : {&draw, &dbits, &dval, &dwide, &didx, &dn, &dtake, &dtv, &dpackv, &dnulls}) CK(golap_slab_free(ctx, sl->ptr, sl->cls));
+    }
 
     for (Slab* sl : {&dbk, &dpk, &dpv, &dpairs, &dcnt, &dmask, &dagg, &dfs}) CK(golap_slab_free(ctx, sl->ptr, sl->cls));
     golap_ctx_destroy(ctx);
