@@ -1055,10 +1055,11 @@ __device__ __forceinline__ unsigned long long jn_reserve(uint32_t* s_wt, unsigne
 // than one table chunk (then "unmatched" is only known after the last chunk).
 // NARROW: both sides are (key32, row id) tuple arrays (see ReserveArgs); gate/gate_skip: run_if / skip_if on the
 // device word that says whether the narrow pipeline was abandoned.
-// K16 (round 4, tuple pipeline only): the table keeps the UPPER 16 bits of a tuple's first word.  The word is hash_int32(key32 ^ key_hi),
-// a bijection of the key, and every row of a sub-partition shares the hash bits the partition passes consumed -- with >= 16 of them
-// (18 at 1B rows) the upper half decides equality.  8 KiB of keys instead of 16 and 1920 chain heads instead of 2048: 39.8 KiB per
-// work-group, FOUR per CU instead of three (the kernel is bound by per-work-group latency chains).
+// K16 (round 4, tuple pipeline only): the table keeps the UPPER 19 bits of a tuple's first word, packed with the chain link into ONE 32-bit
+// word.  The word is hash_int32(key32 ^ key_hi), a bijection of the key, and every row of a sub-partition shares the hash bits the
+// partition passes consumed -- with >= 13 of them (always, from 16M rows on; 18 at 1B) the upper 19 decide equality.  16 KiB for keys +
+// links instead of 24 and 1920 chain heads instead of 2048: 39.8 KiB per work-group, FOUR per CU instead of three (the kernel is bound
+// by per-work-group latency chains).
 constexpr int JN_HEADS16 = 1920;
 template <int JT, bool NARROW, bool K16 = false>
 __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const JoinSide& B, const JoinSide& P, uint2* __restrict__ out_pairs,
@@ -1067,20 +1068,35 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
     static_assert(!K16 || NARROW, "16-bit table keys are a form of the tuple pipeline");
     constexpr bool KEEP_B = (JT & 1) != 0, KEEP_P = (JT & 2) != 0;
     using KeyT = typename JoinKey<NARROW>::type;
-    using TabT = typename std::conditional<K16, uint16_t, KeyT>::type;
+    using TabT = typename std::conditional<K16, uint32_t, KeyT>::type;
     // chain heads: 4096 for the 72 KiB wide table (two work-groups per CU either way); 2048 for the narrow one, whose
     // 48 KiB then fit three work-groups per CU -- the kernel is bound by per-work-group latency chains, not by LDS reads
     constexpr int LOG2S = NARROW ? JN_LOG2_SLOTS - 1 : JN_LOG2_SLOTS;
     constexpr int NHEADS = K16 ? JN_HEADS16 : (1 << LOG2S);
-    auto tab_key = [](KeyT k) -> TabT { return K16 ? (TabT)((uint32_t)k >> 16) : (TabT)k; };
+    // K16: ONE 32-bit LDS word per table row = the key's upper 19 bits | (index of the next row in the chain + 1) in the lower 13 -- a chain
+    // step is one LDS read instead of two (the lower 13 key bits are among those the partition passes have already compared)
+    constexpr uint32_t KN_NEXT = 0x1FFFu;
+    auto tab_key = [](KeyT k) -> TabT { return (TabT)k; };
     auto slot_of_key = [](KeyT k) -> uint32_t {
         if (K16) return (uint32_t)(((unsigned long long)((uint32_t)k * 0x9E3779B1u) * (uint32_t)JN_HEADS16) >> 32);   // (32-bit multiply + mul-hi range reduction)
         return slot_hash((long long)k, LOG2S);
     };
-    __shared__ TabT t_keys[JN_CAP];
+    __shared__ TabT t_keys[JN_CAP];          // K16: the packed (key | next) words
     __shared__ uint32_t t_rids[JN_CAP];
     __shared__ uint32_t heads[NHEADS];
-    __shared__ uint16_t t_next[JN_CAP];
+    __shared__ uint16_t t_next[K16 ? 2 : JN_CAP];
+    // one chain step: does row e hold probe key k, and which row follows it (0xFFFF = none)
+    auto chain_step = [&](uint32_t e, KeyT k, bool& hit, uint32_t& nxt) {
+        if (K16) {
+            const uint32_t w = (uint32_t)t_keys[e];
+            hit = ((w ^ (uint32_t)k) & ~KN_NEXT) == 0u;
+            const uint32_t n = w & KN_NEXT;
+            nxt = n ? n - 1u : 0xFFFFu;
+        } else {
+            hit = t_keys[e] == tab_key(k);
+            nxt = t_next[e];
+        }
+    };
     __shared__ uint8_t t_hit[KEEP_B ? JN_CAP : 4];
     __shared__ uint32_t s_wt[JN_R * JN_WAVES];
     __shared__ unsigned long long s_base;
@@ -1148,10 +1164,14 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
             for (int r = 0; r < JN_CAP / JN_THREADS; ++r) {
                 const uint32_t i = r * JN_THREADS + tid;
                 if (i < nb) {
-                    t_keys[i] = tab_key(bk[r]);
                     t_rids[i] = brd[r];
                     const uint32_t old = atomicExch(&heads[slot_of_key(bk[r])], i);   // join_kernels.cuh:109
-                    t_next[i] = (uint16_t)old;                                                     // :110 (0xFFFFFFFF -> 0xFFFF)
+                    if (K16) {
+                        t_keys[i] = (TabT)(((uint32_t)bk[r] & ~KN_NEXT) | (old == JN_EMPTY ? 0u : old + 1u));
+                    } else {
+                        t_keys[i] = tab_key(bk[r]);
+                        t_next[i] = (uint16_t)old;                                                 // :110 (0xFFFFFFFF -> 0xFFFF)
+                    }
                 }
             }
         }
@@ -1178,12 +1198,15 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
                 if (valid) {
                     uint32_t e = heads[slot_of_key(pk[r])] & 0xFFFFu;
                     while (e != 0xFFFFu) {
-                        if (t_keys[e] == tab_key(pk[r])) {   // full-key compare (:152-153; K16: the bits the partition passes have not already compared)
+                        bool hit;
+                        uint32_t nxt;
+                        chain_step(e, pk[r], hit, nxt);
+                        if (hit) {   // full-key compare (:152-153; K16: the bits the partition passes have not already compared)
                             if (c == 0) f = e;
                             ++c;
                             if (KEEP_B) t_hit[e] = 1;   // same value from every writer: a plain store is enough
                         }
-                        e = t_next[e];
+                        e = nxt;
                     }
                 }
                 if (KEEP_P && valid) {
@@ -1217,12 +1240,15 @@ __device__ __forceinline__ void join_sub_partition(const uint32_t sp, const Join
                     uint32_t e = first[r];
                     uint32_t left = cnt[r];
                     for (;;) {
-                        if (t_keys[e] == tab_key(pk[r])) {
+                        bool hit;
+                        uint32_t nxt;
+                        chain_step(e, pk[r], hit, nxt);
+                        if (hit) {
                             if (pos < max_pairs) out_pairs[pos] = make_uint2(t_rids[e], prid[r]);   // join_kernels.cuh:157-160
                             ++pos;
                             if (--left == 0) break;
                         }
-                        e = t_next[e];
+                        e = nxt;
                     }
                 }
             }
@@ -2154,7 +2180,7 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     if (const char* e = knob("GOLAP_JOIN_STRIDE_GRID")) stride_grid = (uint32_t)std::max(1, atoi(e));   // debug hook
     const dim3 grid(run_if ? std::min<uint32_t>(n_sub, stride_grid) : n_sub), block(JN_THREADS);   // stand-by launch: small striding grid
     unsigned long long* oc = (unsigned long long*)out_count;
-    // 16-bit table keys: tuples carry the plain hash (hashed_key_hi given) and the passes have consumed >= 16 of its bits
+    // packed table rows (19 key bits + 13 link bits): tuples carry the plain hash (hashed_key_hi given) and the passes have consumed >= 13 of its bits
     uint32_t consumed = 0;
     if (!plan.passes.empty()) consumed = plan.passes.back().cfg.shift + plan.passes.back().bits;
     // ... and the sub-partitions are large enough for the fourth work-group per CU to pay (measured, join kernel alone, 32-bit -> 16-bit
@@ -2162,7 +2188,7 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
     // 300M, [9,8], 2289 rows, 1.79 -> 1.82; 1.5B, two table chunks per sub-partition, 14.10 -> 14.03)
     const char* k16_env = knob("GOLAP_JOIN_K16");   // "0": the 32-bit table for every tuple join, "1": the 16-bit one whenever it is valid (A/B hooks)
     const bool k16_pays = (k16_env && !strcmp(k16_env, "1")) || n_build / std::max<uint32_t>(1, n_sub) >= 2700;
-    const bool k16 = narrow && hashed_key_hi && !run_if && consumed >= 16 && k16_pays && !(k16_env && !strcmp(k16_env, "0"));
+    const bool k16 = narrow && hashed_key_hi && !run_if && consumed >= 13 && k16_pays && !(k16_env && !strcmp(k16_env, "0"));
     const uint32_t* dict_n = k16 ? hashed_key_hi + KEY_DICT_MAX : nullptr;
     if (k16) {
         switch (join_type) {
