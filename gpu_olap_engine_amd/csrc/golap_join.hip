@@ -2242,9 +2242,13 @@ static int32_t launch_lds_join(golap_ctx* ctx, hipStream_t st, const JoinPlan& p
 // out[0 .. 3] = the dictionary of upper halves (unused entries repeat entry 0), out[4] = how many distinct ones the samples hold; more
 // than KEY_DICT_MAX raise *wide.  (Round 3: a column with 2 .. 4 upper halves -- small negative next to small positive keys, two id
 // ranges -- keeps its 8-byte tuples, PassCfg::key_hi; before, a second upper half meant the 64-bit pipeline: 31 instead of 18 ms.)
+// spt: samples per thread and side (1 .. 8: 1024 .. 8192 evenly spaced keys of each side).  Every sample is a page of its own in a large
+// column: the 16384 loads of round 3's 8192 + 8192 samples took 43 us -- of a 2.3 ms join at 100M rows -- through the one CU's address
+// translation; 2 per thread (2048 per side, ~12 us) still meet any upper half that 0.2 % of the keys carry with probability 98 %, and
+// a key the sample misses is found by the first pass itself as ever.
 __global__ __launch_bounds__(1024) void k_key_dict(const long long* __restrict__ bkeys, unsigned long long nb, const long long* __restrict__ pkeys,
                                                   unsigned long long np, uint32_t* __restrict__ out, uint32_t* __restrict__ wide, uint32_t max_d,
-                                                  uint32_t window) {
+                                                  uint32_t window, uint32_t spt) {
     // max_d: entries the dictionary form of the first pass can use (1 or KEY_DICT_MAX); window: upper halves its offset form can tell
     // apart (the first pass's fan-out; 0: form not available).  The sampled upper halves go into a small LDS hash set until more than
     // KEY_DICT_MAX distinct ones are known (from then on only their signed minimum and maximum matter).
@@ -2255,11 +2259,12 @@ __global__ __launch_bounds__(1024) void k_key_dict(const long long* __restrict__
     const uint32_t tid = threadIdx.x;
     const uint32_t hi0 = (uint32_t)((unsigned long long)bkeys[0] >> 32);
     uint32_t smp[16];
+    const unsigned long long n_smp = (unsigned long long)spt * 1024;
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
-        const unsigned long long s = (unsigned long long)j * 1024 + tid;   // sample s of 8192
-        smp[2 * j] = nb ? (uint32_t)((unsigned long long)bkeys[(s * nb) >> 13] >> 32) : hi0;
-        smp[2 * j + 1] = np ? (uint32_t)((unsigned long long)pkeys[(s * np) >> 13] >> 32) : hi0;
+        const unsigned long long s = (unsigned long long)(j < spt ? j : 0) * 1024 + tid;   // sample s of n_smp (slots beyond spt repeat slot 0: no further load)
+        smp[2 * j] = nb ? (uint32_t)((unsigned long long)bkeys[(s * nb) / n_smp] >> 32) : hi0;
+        smp[2 * j + 1] = np ? (uint32_t)((unsigned long long)pkeys[(s * np) / n_smp] >> 32) : hi0;
     }
     for (uint32_t i = tid; i < SLOTS; i += 1024) s_set[i] = 0ull;
     if (tid == 0) { s_n = 0; s_min = (int)hi0; s_max = (int)hi0; }
@@ -2307,6 +2312,12 @@ __global__ __launch_bounds__(1024) void k_key_dict(const long long* __restrict__
         out[KEY_DICT_BASE_AT] = offs ? (uint32_t)s_min - (window - 1u - (uint32_t)(s_max - s_min)) / 2u : 0u;
         if (!small && !offs) atomicOr(wide, 1u);
     }
+}
+
+static uint32_t key_dict_samples() {   // samples per thread and side of k_key_dict (GOLAP_DICT_SAMPLES: 1 .. 8; 8 = round 3's 8192 per side)
+    const char* e = knob("GOLAP_DICT_SAMPLES");
+    const int v = e ? atoi(e) : 2;
+    return (uint32_t)(v >= 1 && v <= 8 ? v : 2);
 }
 
 // A/B hooks for the round-2 narrow kernels (scripts/ab_env.py): GOLAP_P1N = 0 (k_scatter_big) | 24 | 18 | 16, GOLAP_P2R = 0 (k_scatter_wc) | 4 | 2
@@ -2524,7 +2535,7 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
             hipLaunchKernelGGL(k_key_dict, dim3(1), dim3(1024), 0, st, (const long long*)p->build_key_ptr, (unsigned long long)p->n_build,
                                (const long long*)p->probe_key_ptr, (unsigned long long)p->n_probe, words + 2, words,
                                (p1n_variant() == 118 && ((p->build_key_ptr | p->probe_key_ptr) & 15) == 0) ? KEY_DICT_MAX : 1u,   // (launch_part1_narrow's dictionary forms)
-                               part1_offset_form_ok(p->build_key_ptr | p->probe_key_ptr) ? plan.passes[0].cfg.F : 0u);
+                               part1_offset_form_ok(p->build_key_ptr | p->probe_key_ptr) ? plan.passes[0].cfg.F : 0u, key_dict_samples());
             key_hi = words + 2;
         }
         if (p->join_type & 2) {
