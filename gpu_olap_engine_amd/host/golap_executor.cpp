@@ -1336,13 +1336,18 @@ int32_t golap_execute(golap_ctx* ctx, golap_plan* plan, golap_result** out_resul
     auto res = std::make_unique<golap_result>();
     int32_t s = ex.run(*plan, res->batches);
     if (s == GOLAP_OK) s = ex.to_host(res->batches);
-    ex.keep.clear();
     if (s != GOLAP_OK) {
-        if (ctx) (void)golap_ctx_synchronize(ctx, nullptr);   // nothing of this plan may still be running when its buffers go back to the pool
-        if (g_err.empty()) g_err = golap_last_error(ctx);
-        if (g_err.empty()) g_err = golap_last_error(nullptr);
+        const std::string why = !g_err.empty() ? g_err : std::string(golap_last_error(ctx));
+        if (ctx) {   // nothing of this plan may still be running or in flight when its buffers go back to the pool
+            (void)golap_ctx_synchronize(ctx, nullptr);
+            (void)golap_xfer_synchronize(ctx);
+        }
+        ex.pending.clear();
+        ex.keep.clear();
+        g_err = !why.empty() ? why : std::string(golap_last_error(nullptr));
         return s;
     }
+    ex.keep.clear();
     ex.prof.total_ms = now_ms() - t0;
     res->profile = ex.prof;
     *out_n = (uint32_t)res->batches.size();

@@ -617,3 +617,16 @@ def test_filter_join_aggregate_plan_stays_on_the_device(ctx):
     assert arrow_bytes <= prof["h2d_bytes"] <= arrow_bytes + 4096, prof       # each column once, at its Arrow width, validity as a bitmap
     assert prof["d2h_bytes"] < 64 * 1024, prof                                 # counts, key ranges, a 7-row group table -- no row-id list, no column
     assert prof["total_ms"] > 0 and prof["h2d_ms"] > 0
+
+
+def test_bench_operator_plan_line():
+    """bench.py --config OP: the Arrow in -> Arrow out leg at a small size -- the line verifies its own result against numpy and says where
+    the wall time went (each input column uploaded exactly once: h2d_bytes == the Arrow buffers' bytes)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "OP", "--rows", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["verify"]["groups"] > 0 and d["h2d_bytes"] == d["input_bytes"] and d["d2h_bytes"] < 1 << 20
+    assert d["end_to_end_ms"] >= d["h2d_ms"] > 0 and d["cpu_baseline"]["kind"] == "port"
