@@ -240,7 +240,10 @@ def bench_join(args, n_total, label):
         else:
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # barrier / max-over-ranks only; the join's own
                                                                                            # exchange is the library's RCCL communicator
-    ctx = Context(profiling=True, max_gpu_memory=0)
+    # profiling = 2: every kernel that does work is bracketed by hipEvents on its launch stream inside the library (the roofline's durations
+    # come from them), the ~17 stand-by launches of a join only while a recent join needed them -- a pair of events costs as much stream
+    # time as the empty launch it brackets (100M x 100M: 2.02 ms per join without any timing, 2.22 ms with every launch timed)
+    ctx = Context(profiling=2, max_gpu_memory=0)
     info = ctx.device_info()
 
     # ---- synthetic, device-resident inputs (counter-based: every rank generates its own shard) ----

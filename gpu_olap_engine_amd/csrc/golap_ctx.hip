@@ -55,7 +55,7 @@ uint32_t* Profiler::take_gate_slot() {
     }
     ++gate_used;
     uint32_t* s = gate_blocks[blk] + idx;
-    *s = 0;
+    *s = GATE_PENDING;
     return s;
 }
 
@@ -74,9 +74,11 @@ void Profiler::resolve() {
         for (auto& p : pending) any = any || p.gate_host;
         if (any) (void)hipDeviceSynchronize();   // the slot copies sit behind the events just waited for; profiling runs only
         for (auto& p : pending)
-            if (p.gate_host && ((*p.gate_host != 0u) == p.credit_when_set)) stats[p.stat].bytes += p.cond_bytes;
+            if (p.gate_host && *p.gate_host != GATE_PENDING && ((*p.gate_host != 0u) == p.credit_when_set)) stats[p.stat].bytes += p.cond_bytes;
     }
     pending.clear();
+    (void)recent_gate();      // (what has landed is remembered; the slots themselves are handed out again from here on)
+    noted_gates.clear();
     gate_used = 0;
 }
 
@@ -436,6 +438,7 @@ int32_t golap_ctx_create(const golap_engine_config* cfg, golap_ctx** out_ctx) {
     int32_t s = ctx->xfer.init(ctx, c.num_streams);
     if (s != GOLAP_OK) { golap_ctx_destroy(ctx); return s; }
     ctx->prof.enabled = c.enable_profiling != 0;
+    ctx->prof.light = c.enable_profiling >= 2;
     if (getenv("GOLAP_DEBUG_ENV")) {   // developer convenience: import GOLAP_* variables ONCE as knobs (scripts/, multi-process tests)
         extern char** environ;
         for (char** e = environ; e && *e; ++e)

@@ -109,6 +109,25 @@ struct Profiler {
     uint32_t gate_used = 0;                  // words handed out since the last resolve()
     const uint32_t* cur_gate_host = nullptr; // the running call's slot (nullptr: no conditional credits, e.g. during stream capture)
     static constexpr uint32_t GATE_BLOCK = 256;
+    static constexpr uint32_t GATE_PENDING = 0xFFFFFFFFu;   // a slot whose copy has not landed yet (gate words are 0 / 1)
+    // Timing events are launches of their own on the stream (~4 us each): a join that times its ~17 stand-by launches pays more for
+    // measuring them than they cost.  `mute` switches KernelTimer off for a scope; radix_hash_join mutes the stand-by pipeline when the
+    // most recent join whose gate word has already landed did not need it (recent_gates: the last calls' pinned slots).  A call whose
+    // gate turns out raised after all ran its 64-bit pipeline untimed -- once: the next call sees that word.
+    bool mute = false;
+    bool light = false;                        // golap_engine_config.enable_profiling == 2: muting is allowed
+    std::deque<const uint32_t*> noted_gates;   // slots of the joins since the last resolve(), oldest first (their copies land in order)
+    int last_known_gate = -1;                  // 0 / 1: the gate word of the most recent join whose copy has landed; -1: none yet
+    void note_gate_slot(const uint32_t* s) { noted_gates.push_back(s); }
+    int recent_gate() {
+        while (!noted_gates.empty()) {
+            const uint32_t v = *(const volatile uint32_t*)noted_gates.front();
+            if (v == GATE_PENDING) break;
+            last_known_gate = v ? 1 : 0;
+            noted_gates.pop_front();
+        }
+        return last_known_gate;
+    }
     uint32_t* take_gate_slot();
     uint32_t stat_index(const char* name);
     hipEvent_t get_event();
@@ -181,7 +200,7 @@ struct KernelTimer {
     bool on;
     // cond_bytes: credited at resolve time if the call's gate word turned out (credit_when_set ? non-zero : zero)
     KernelTimer(golap_ctx* c, const char* name, hipStream_t s, uint64_t bytes = 0, uint64_t cond_bytes = 0, bool credit_when_set = true)
-        : ctx(c), st(s), on(c->prof.enabled) {
+        : ctx(c), st(s), on(c->prof.enabled && !c->prof.mute) {
         if (on) {   // timing events have no meaning inside a stream capture (and must not become graph nodes)
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();

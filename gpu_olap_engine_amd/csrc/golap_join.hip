@@ -2551,12 +2551,19 @@ static int32_t radix_hash_join(golap_ctx* ctx, const golap_join_params* p, hipSt
                                   true, nullptr, words, probe_hit, key_hi));   // (key_hi is only set when both passes are the hashed-tuple kernels)
         gate = words;
     }
+    // (profiling contexts) the 64-bit pipeline standing by is not timed while recent joins did not need it: see Profiler::mute
+    struct MuteScope { Profiler& pr; bool prev; ~MuteScope() { pr.mute = prev; } } mute_scope{ctx->prof, ctx->prof.mute};
+    {
+        if (gate && ctx->prof.enabled && ctx->prof.light && ctx->prof.cur_gate_host && ctx->prof.recent_gate() == 0) ctx->prof.mute = true;
+    }
     GOLAP_TRY(run_side(ctx, st, "build", plan_b, p->build_key_ptr, 0, p->build_rid_base, p->n_build, nullptr, bb, rb, gate));
     GOLAP_TRY(run_side(ctx, st, "probe", plan_p, p->probe_key_ptr, 0, p->probe_rid_base, p->n_probe, nullptr, pb, rp, gate));
     GOLAP_TRY(launch_lds_join(ctx, st, plan, rb, rp, p->n_build, p->n_probe, p->out_pairs_ptr, p->out_count_ptr, p->max_pairs, p->join_type, false, gate,
                               nullptr, probe_hit));
+    ctx->prof.mute = mute_scope.prev;
     if (gate && ctx->prof.cur_gate_host) {
         (void)hipMemcpyAsync((void*)ctx->prof.cur_gate_host, gate, 4, hipMemcpyDeviceToHost, st);
+        ctx->prof.note_gate_slot(ctx->prof.cur_gate_host);
         ctx->prof.cur_gate_host = nullptr;
     }
     ws_end(ctx, st);

@@ -69,7 +69,7 @@ class Context:
         cfg = config if config is not None else default_config()
         cfg.device_id = torch.cuda.current_device()
         if profiling:
-            cfg.enable_profiling = 1
+            cfg.enable_profiling = int(profiling)      # True / 1: every launch is timed; 2: stand-by launches only while a recent join needed them
         if max_gpu_memory is not None:
             cfg.max_gpu_memory = max_gpu_memory
         if provision_sigmas is not None:

@@ -56,7 +56,9 @@ typedef struct golap_engine_config {
     uint32_t enable_cache;       /* lib.rs:30  default 1 (accepted, unused)     */
     int32_t  device_id;          /* HIP ordinal; -1 = current device            */
     uint32_t radix_bits;         /* join_kernels.cuh:22  RADIX_BITS = 8         */
-    uint32_t enable_profiling;   /* 1 = record per-kernel hipEvents (golap_stats) */
+    uint32_t enable_profiling;   /* 1 = record per-kernel hipEvents (golap_stats); 2 = the same, but the stand-by launches of a join (the 64-bit
+                                    pipeline behind the tuple pipeline: ~17 launches that return at once) are only timed while a recent join
+                                    needed them -- a pair of timing events costs as much stream time as the launch it brackets */
     uint32_t max_slabs_per_class;/* slab_allocator.rs:25-28 (constructor argument); default 4096: in practice only max_gpu_memory bounds the pool */
     uint32_t provision_sigmas;   /* standard deviations of head-room in the provisioned (no-histogram) layouts; 0 = default 6.
                                     Tests set 1 / GOLAP_PROVISION_NONE to force the overflow fall-backs; results never depend on it. */
