@@ -18,7 +18,10 @@ int32_t fail(golap_ctx* ctx, int32_t code, const char* fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_thread_err = buf;
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->err_mu);
+        ctx->err = buf;
+    }
     return code;
 }
 

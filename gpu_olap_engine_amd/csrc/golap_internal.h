@@ -174,6 +174,7 @@ struct golap_ctx {
     int device = 0;
     hipDeviceProp_t prop;
     std::mutex mu;                    // serialises compute calls on one context (SURVEY 8(b) threading)
+    std::mutex err_mu;                // fail() may be reached from several host threads at once (golap_xfer_enqueue is called per stream from many)
     std::string err;
     golap::SlabAllocator slabs;
     golap::TransferQueue xfer;
