@@ -951,3 +951,37 @@ def test_wide_first_pass_forms_agree(ctx):
         assert st["radix_scatter_p1_wide"]["total_ms"] > 0.05 and "radix_hist_p2" not in st, f"GOLAP_P1W={form}: not the no-histogram flow"
         bad = torch.nonzero(got != exp).flatten()
         assert m == n and bad.numel() == 0, f"GOLAP_P1W={form}: {m} pairs for {n} probe rows; {bad.numel()} probe rows without exactly their partner"
+
+
+def test_light_profiling_times_the_stand_by_pipeline_only_when_it_is_needed():
+    """golap_engine_config.enable_profiling = 2 (what bench.py uses): the kernels that do work are always timed; the 64-bit pipeline standing
+    by behind the tuple pipeline is timed only while the most recent join whose gate word has landed needed it -- one transitional join
+    runs it untimed, from then on its kernels are in the stats again.  Results are the same either way."""
+    from gpu_olap_engine_amd.engine import Context
+    n = 20_000_000
+    with Context(profiling=2, max_gpu_memory=0) as c:
+        bt = c.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+        pt = c.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+        out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+
+        def join():
+            pairs, cnt = c.join(bt, pt, out_pairs=out, max_pairs=n, strategy=N.JOIN_RADIX_HASH)
+            torch.cuda.synchronize()
+            v = c.verify_pairs(pairs, n, bt, pt).cpu().numpy().view(np.uint64)
+            assert int(cnt.item()) == n and int(v[0]) == n and int(v[2]) == n * (n - 1) // 2
+        join()                                   # nothing known yet: everything is timed
+        st = c.stats()
+        assert st["join_build_probe_lds"]["launches"] == 1 and st["join_build_probe_lds_wide"]["launches"] == 1
+        c.stats_reset()
+        join(); join()                           # the last join's gate word (0) is known: the stand-by pipeline is not timed
+        st = c.stats()
+        assert st["join_build_probe_lds"]["launches"] == 2 and st["radix_scatter_p1"]["launches"] == 4
+        assert st.get("join_build_probe_lds_wide", {"launches": 0})["launches"] == 0 and not any(k.endswith("_standby") and v["launches"] for k, v in st.items())
+        bt += ((bt * 0x9E3779B1) & 0xFF) << 44    # many upper key halves: the 64-bit pipeline does the joins from here on
+        pt += ((pt * 0x9E3779B1) & 0xFF) << 44
+        c.stats_reset()
+        join()                                   # transitional: ran wide, untimed
+        join()                                   # its gate word (1) is known now
+        st = c.stats()
+        assert st["join_build_probe_lds_wide"]["launches"] == 1 and st["join_build_probe_lds_wide"]["total_ms"] > st["join_build_probe_lds"]["total_ms"]
+        assert st["radix_scatter_p1_wide"]["launches"] == 2 and st["radix_scatter_p1_wide"]["total_ms"] > 0.05
