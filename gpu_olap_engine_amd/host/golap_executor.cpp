@@ -21,6 +21,7 @@
 // split by golap_pairs_unzip; composite GROUP BY keys are ranged by golap_key_minmax and packed by golap_pack_group_keys); only counts
 // (8 bytes), group tables and the final result come back.  No per-row host loop is left in execute_filter / _hash_join / _aggregate.
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cstdint>
@@ -35,6 +36,7 @@
 
 namespace {
 
+std::atomic<uint32_t> g_xfer_threads{8};   // host threads (= transfer streams used) of a transfer phase: golap_host_set_transfer_threads
 thread_local std::string g_err;
 int32_t herr(int32_t code, const std::string& msg) {
     g_err = msg;
@@ -382,7 +384,7 @@ int32_t Exec::flush() {
     }
     pending.clear();
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t T = (up_bytes + down_bytes) < (8ull << 20) ? 1 : std::min<size_t>({8, hw, pieces.size()});
+    const size_t T = (up_bytes + down_bytes) < (8ull << 20) ? 1 : std::min<size_t>({(size_t)g_xfer_threads.load(), hw, pieces.size()});
     std::vector<int32_t> status(T, GOLAP_OK);
     auto work = [&](size_t t) {
         for (size_t i = t; i < pieces.size(); i += T) {
@@ -629,14 +631,17 @@ static void and_leaves(const golap_expr& e, std::vector<const golap_expr*>& out)
 }
 
 int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::vector<RecordBatch>& out) {
-    for (RecordBatch& b : in) {
-        // non-binary predicate => every row passes (:474)
-        if (pred.kind != golap_expr::Binary) { out.push_back(std::move(b)); continue; }
+    // what each batch needs: nothing (every row passes: :474, :449-452), or a conjunction of <Int64 column> <op> <literal> comparisons
+    struct Todo { bool pass = true; std::vector<golap_filter_predicate> fps; std::vector<int> fcols; };
+    std::vector<Todo> todo(in.size());
+    std::vector<RecordBatch*> upload;
+    for (size_t bi = 0; bi < in.size(); ++bi) {
+        RecordBatch& b = in[bi];
+        Todo& td = todo[bi];
+        if (pred.kind != golap_expr::Binary) continue;   // non-binary predicate => every row passes (:474)
         std::vector<const golap_expr*> leaves;
         and_leaves(pred, leaves);
         if (leaves.size() > GOLAP_FILTER_AND_MAX) return herr(GOLAP_ERR_UNSUPPORTED, "GpuFilter: at most " + std::to_string(GOLAP_FILTER_AND_MAX) + " comparisons in one conjunction");
-        std::vector<golap_filter_predicate> fps;
-        std::vector<int> fcols;
         for (const golap_expr* lf : leaves) {
             if (lf->kind != golap_expr::Binary) continue;   // a non-binary leaf passes every row (:474)
             const golap_expr *l = lf->left.get(), *r = lf->right.get();
@@ -650,14 +655,25 @@ int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::
             int64_t lit;
             // operands that are not both Int64 => every row passes (:449-452, :471-472); a Utf8 column is its Int64 hash on this path (:93-97)
             if ((b.cols[ci].dtype != DType::Int64 && b.cols[ci].dtype != DType::Utf8) || !parse_i64(litx->value, lit)) continue;
-            fps.push_back(golap_filter_predicate{(uint64_t)ci, (int32_t)op, lit});
-            fcols.push_back(ci);
+            td.fps.push_back(golap_filter_predicate{(uint64_t)ci, (int32_t)op, lit});
+            td.fcols.push_back(ci);
         }
-        if (fps.empty()) { out.push_back(std::move(b)); continue; }
+        td.pass = td.fps.empty();
+        if (!td.pass && b.num_rows) upload.push_back(&b);
+    }
+    // ONE transfer phase for every batch the predicate runs on (a phase per batch left the link idle while the previous batch was filtered)
+    if (!upload.empty()) {
+        H_TRY(need_ctx());
+        H_TRY(to_device(upload));
+    }
+    for (size_t bi = 0; bi < in.size(); ++bi) {
+        RecordBatch& b = in[bi];
+        const Todo& td = todo[bi];
+        if (td.pass) { out.push_back(std::move(b)); continue; }
+        const std::vector<golap_filter_predicate>& fps = td.fps;
+        const std::vector<int>& fcols = td.fcols;
         const uint64_t n = b.num_rows;
         if (n == 0) continue;   // empty batches are dropped (:173)
-        H_TRY(need_ctx());
-        H_TRY(to_device({&b}));
         DevPtr didx, dcnt;
         H_TRY(temp(didx, n * 4));
         H_TRY(temp(dcnt, 8));
@@ -687,6 +703,7 @@ int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::
         }
         out.push_back(std::move(ob));
         H_TRY(end_op());
+        for (Column& c : b.cols) { c.d_data.reset(); c.d_valid.reset(); }   // the input batch's columns are not needed any more
     }
     return GOLAP_OK;
 }
@@ -1354,6 +1371,8 @@ int32_t golap_execute(golap_ctx* ctx, golap_plan* plan, golap_result** out_resul
     *out_result = res.release();
     return GOLAP_OK;
 }
+
+void golap_host_set_transfer_threads(uint32_t n) { g_xfer_threads.store(std::max<uint32_t>(1, std::min<uint32_t>(n, 64))); }
 
 int32_t golap_result_profile(const golap_result* r, golap_exec_profile* out) {
     if (!r || !out) return herr(GOLAP_ERR_INVALID_ARG, "null argument");

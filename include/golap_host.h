@@ -91,6 +91,9 @@ typedef struct golap_exec_profile {
     double   total_ms;         /* the whole call */
 } golap_exec_profile;
 int32_t golap_result_profile(const golap_result* r, golap_exec_profile* out);
+/* Host threads that feed the TransferQueue in a transfer phase (thread t -> stream t % num_streams; default 8 = EngineConfig's
+ * num_streams, lib.rs:37).  Process-wide; more than the context's streams only makes threads share a stream. */
+void golap_host_set_transfer_threads(uint32_t n);
 /* Moves batch i out as an Arrow struct array (the caller releases it through the Arrow callbacks). */
 int32_t golap_result_export(golap_result* r, uint32_t i, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 void    golap_result_free(golap_result* r);
