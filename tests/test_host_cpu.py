@@ -73,3 +73,26 @@ def test_device_arms_fail_loudly_without_ctx(O):
     b = pa.RecordBatch.from_arrays([pa.array(np.arange(4, dtype=np.int64))], names=["a"])
     with pytest.raises(O.OperatorError):     # no CPU fallback: the filter needs the device
         O.execute(O.GpuFilter(O.Batches([b]), O.BinaryExpr(O.Column(0, "a"), ">", O.Literal("1"))), NoCtx())
+
+
+def test_narrow_types_pass_through_with_their_own_types(O):
+    """Columns no operator touches leave as they came -- type, offset, nulls -- for every numeric Arrow type the importer knows (they are
+    only widened when an operator takes the batch to the device: record_batch_convert.rs:35-110)."""
+    n = 37
+    rng = np.random.default_rng(3)
+    specs = [("i8", pa.int8(), np.int8), ("u8", pa.uint8(), np.uint8), ("i16", pa.int16(), np.int16), ("u16", pa.uint16(), np.uint16),
+             ("i32", pa.int32(), np.int32), ("u32", pa.uint32(), np.uint32), ("i64", pa.int64(), np.int64), ("u64", pa.uint64(), np.uint64),
+             ("f32", pa.float32(), np.float32), ("f64", pa.float64(), np.float64)]
+    arrays, expect = [], []
+    for nm, t, dt in specs:
+        v = (rng.random(n) * 100).astype(dt)
+        nulls = rng.random(n) < 0.3
+        arrays.append(pa.array([None if m else x.item() for x, m in zip(v, nulls)], t))
+        expect.append([None if m else x.item() for x, m in zip(v, nulls)])
+    full = pa.RecordBatch.from_arrays(arrays, names=[s[0] for s in specs])
+    sl = full.slice(5, 29)
+    out = O.execute(O.GpuSort(O.Batches([full, sl])), NoCtx())
+    for j, (nm, t, _) in enumerate(specs):
+        assert out[0].schema.field(j).type == t and out[1].schema.field(j).type == t, nm
+        assert out[0].column(j).to_pylist() == expect[j], nm
+        assert out[1].column(j).to_pylist() == expect[j][5:34], nm
