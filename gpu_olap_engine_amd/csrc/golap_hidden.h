@@ -3,7 +3,8 @@
 // data-dependent control flow and waits vmcnt(0) at the first use of a prefetched value -- i.e. for every store issued behind the
 // prefetch.  Kernels that use these helpers issue every store at wave-uniform control flow (predicated through EXEC inside the
 // statement), so the number of operations younger than a load is a compile-time constant (cdna_hip_programming.md 5.7 item 1,
-// form (ii)).  Users: golap_part_narrow.h (both partition passes of the join), golap_ops.hip (k_agg_scatter_rsv).
+// form (ii)).  Users: golap_part_narrow.h (both partition passes of the join), golap_part_wide.h (the 64-bit-row pipeline's last pass),
+// golap_ops.hip (k_agg_scatter_rsv).
 #pragma once
 #include <stdint.h>
 
@@ -14,6 +15,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ld16_hidden(u32x4& v, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void ld8_hidden(u32x2& v, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ld4_hidden(uint32_t& v, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory"); }
 // Hidden loads of the ring pass go into FIXED registers v[104:119] that hipcc never allocates: k_part2_ring caps the compiler's
 // budget at 96 VGPRs (amdgpu_waves_per_eu(5); the kernel still gets what the asm statements name, occupancy is set by its LDS
 // anyway), the load names its destination in the asm text, and ld8_take copies the pair out AFTER the counted wait.  No
@@ -100,6 +102,7 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 __device__ __forceinline__ void pin(u32x4& v) { asm volatile("" : "+v"(v)); }   // no consumer of v is scheduled above this point
 __device__ __forceinline__ void pin(u32x2& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(uint32_t& v) { asm volatile("" : "+v"(v)); }
 // L2-served read of a word other work-groups may set (sc1 bypasses this CU's L1), hidden like the loads above.  (A scalar
 // `s_load_dword ... glc` poll by every wave was tried instead: 4096 uncached reads of ONE address per tile round serialise
 // at its memory channel -- the first pass ran 6 x slower.)

@@ -677,8 +677,13 @@ __device__ __forceinline__ uint32_t isqrt_u32(uint32_t x) {
 __global__ __launch_bounds__(1024) void k_slots_setup(GroupSrc gs, uint32_t G, uint32_t F, uint32_t sigmas,
                                                       uint32_t pad, uint32_t* __restrict__ slot_base, uint32_t* __restrict__ slot_cap,
                                                       unsigned long long limit_rows, uint32_t* __restrict__ overflow,
-                                                      const uint32_t* __restrict__ key_dict = nullptr, uint32_t dict_mul = 1) {
+                                                      const uint32_t* __restrict__ key_dict = nullptr, uint32_t dict_mul = 1,
+                                                      uint4* __restrict__ zero_ptr = nullptr, uint32_t zero_vec = 0, const uint32_t* __restrict__ zero_if = nullptr) {
     __shared__ uint32_t s_w[16];
+    // the cursors of a reserving last pass (k_part2_wide: fx.sub_len), cleared here instead of by a launch of their own -- only when
+    // that pass is going to run (zero_if: its gate word)
+    if (zero_ptr && (!zero_if || *zero_if != 0))
+        for (uint32_t z = threadIdx.x; z < zero_vec; z += blockDim.x) zero_ptr[z] = make_uint4(0u, 0u, 0u, 0u);
     if (key_dict && key_dict[KEY_DICT_MAX] > 1u) sigmas *= dict_mul;   // several upper key halves: wider slots (reserve_cap's comment)
     const uint32_t g = threadIdx.x, lane = g & 63, wv = g >> 6;
     uint32_t total = 0;
@@ -982,6 +987,7 @@ static_assert((8 * WC_MAX_F) % WC_THREADS == 0, "carry slots per thread (8-row s
 
 }  // namespace golap
 #include "golap_part_narrow.h"
+#include "golap_part_wide.h"
 namespace golap {
 
 // ---------------------------------------------------------------------------
@@ -1715,6 +1721,10 @@ static uint32_t part1_narrow_tile();
 // the 64-bit pipeline's reserving first pass: k_part1_narrow<.., WIDE> (12288-row tiles) when the column is 16-byte aligned, else
 // round 1's k_scatter_big.  GOLAP_P1W=0: the old kernel (A/B hook), 2: the new one with compiler-visible loads and stores.
 static int p1w_variant() { const char* e = knob("GOLAP_P1W"); return e ? atoi(e) : kernel_forms_now().p1w; }
+// the 64-bit pipeline's no-histogram LAST pass: k_part2_wide (golap_part_wide.h; 1 = hidden loads and stores, 2 = compiler-visible ones) when
+// both planes of the first pass's output are 16-byte aligned, else -- and with GOLAP_P2W=0 (A/B hook) -- round 1's k_scatter_wc<2, FIXED>
+static int p2w_variant() { const char* e = knob("GOLAP_P2W"); return e ? atoi(e) : kernel_forms_now().p2w; }
+constexpr int P2W_RPT = 12;   // 12288-row tiles: 144 KiB of LDS next to 8 KiB of per-bucket words at F = 512
 static uint32_t wide_chunks(uint64_t n_rows, uint32_t* chunk_rows_out) {
     return p1w_variant() != 0 ? first_pass_chunks(n_rows, chunk_rows_out, 12288, 4) : first_pass_chunks(n_rows, chunk_rows_out);
 }
@@ -1980,17 +1990,35 @@ static int32_t run_side(golap_ctx* ctx, hipStream_t st, const char* side, JoinPl
             if (!side_flag2) GOLAP_TRY(zero_async(ctx, st, (void*)(flag), 4));
             uint32_t sigmas, pad;
             provision_of("GOLAP_SLOT_SIGMAS", sigmas, pad);   // (test knob: 0 forces overflows)
+            const int p2w = (cur_rids && ((cur_keys | cur_rids) & 15) == 0 && F <= (uint32_t)WC_MAX_F && (((uint64_t)G * F) & 3) == 0) ? p2w_variant() : 0;
             hipLaunchKernelGGL(k_slots_setup, dim3(1), dim3(1024), 0, st, groups, G, F, sigmas, pad, slot_base, slot_cap,
-                               (unsigned long long)final_rows(plan, n_rows, false), flag);
+                               (unsigned long long)final_rows(plan, n_rows, false), flag, (const uint32_t*)nullptr, 1u,
+                               p2w ? (uint4*)sub_len : (uint4*)nullptr, p2w ? (uint32_t)((uint64_t)G * F / 4) : 0u, gate);   // (ws_take hands out 256-byte aligned blocks)
             FixedArgs fx{groups, slot_base, slot_cap, sub_start, sub_len, flag, flag};   // (skip_if = its own overflow word: set before the launch only by the guard above)
             PassCfg cfg = pp.cfg;
             cfg.S = 1;
             {
                 snprintf(name, sizeof name, "%s_scatter_p%zu%s", pfx, k + 1, sfx);
                 KernelTimer t(ctx, name, st, gate ? 0 : 24 * n_rows, gate ? 24 * n_rows : 0, true);
-                hipLaunchKernelGGL((k_scatter_wc<2, true>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F), st, (const long long*)cur_keys,
-                                   (const uint32_t*)cur_rids, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                   (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, gate);
+                if (p2w != 0) {
+                    // chunks per group: its per-XCD pieces x GOLAP_P2W_SPLIT parts each (8 x that when the group is one extent).  Measured at
+                    // 1B rows, F = 512, both sides (profiles/r04_ab/p2w_split.log): split 1 -> 12.1 ms, 2 -> 11.26, 4 -> 11.33, 8 -> 11.48
+                    // (k_scatter_wc<2, FIXED>: 12.55): 16 work-groups of ~10 tiles per group keep two groups in flight per XCD -- runs of one
+                    // bucket arrive ~1 us apart and meet in the L2 -- without paying a work-group's start and drain every 5 tiles
+                    const char* se = knob("GOLAP_P2W_SPLIT");
+                    const uint32_t split = se && atoi(se) >= 1 && atoi(se) <= 8 ? (uint32_t)atoi(se) : 2u;
+                    const uint32_t C = (groups.cursor && groups.nsub > 1 ? groups.nsub : 8u) * split;
+                    if (p2w == 2)
+                        hipLaunchKernelGGL((k_part2_wide<P2W_RPT, false>), dim3(G * C), dim3(P2W_THREADS), part2_wide_lds_bytes(F, P2W_RPT * P2W_THREADS), st,
+                                           (const long long*)cur_keys, (const uint32_t*)cur_rids, (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, G, C, gate);
+                    else
+                        hipLaunchKernelGGL((k_part2_wide<P2W_RPT, true>), dim3(G * C), dim3(P2W_THREADS), part2_wide_lds_bytes(F, P2W_RPT * P2W_THREADS), st,
+                                           (const long long*)cur_keys, (const uint32_t*)cur_rids, (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, G, C, gate);
+                } else {
+                    hipLaunchKernelGGL((k_scatter_wc<2, true>), dim3(G), dim3(WC_THREADS), scatter_wc_lds_bytes(F), st, (const long long*)cur_keys,
+                                       (const uint32_t*)cur_rids, rid_base, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                       (long long*)buf.final_keys, (uint32_t*)buf.final_rids, cfg, fx, gate);
+                }
             }
             GOLAP_HIP_TRY(ctx, hipGetLastError());
             res.alt_start = sub_start;
@@ -2115,6 +2143,8 @@ static int32_t ensure_scatter_lds(golap_ctx* ctx) {
             for (const void* f : p1) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part1_narrow_lds_bytes(PT_MAX_F, 18432)));
             const void* p1w[] = {(const void*)k_part1_narrow<12, 12288, true, true, 0, 0, 1>, (const void*)k_part1_narrow<12, 12288, true, false, 0, 0, 1>};
             for (const void* f : p1w) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part1_narrow_lds_bytes(WC_MAX_F, 12288, true)));
+            const void* p2w[] = {(const void*)k_part2_wide<P2W_RPT, true>, (const void*)k_part2_wide<P2W_RPT, false>};
+            for (const void* f : p2w) GOLAP_HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_wide_lds_bytes(WC_MAX_F, P2W_RPT * P2W_THREADS)));
             const void* p2[] = {(const void*)k_part2_ring<4, 32, true>, (const void*)k_part2_ring<4, 64, true>, (const void*)k_part2_ring<4, 128, true>,
                                 (const void*)k_part2_ring<4, 256, true>, (const void*)k_part2_ring<4, 32, false>, (const void*)k_part2_ring<4, 64, false>,
                                 (const void*)k_part2_ring<4, 128, false>, (const void*)k_part2_ring<4, 256, false>,

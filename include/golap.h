@@ -89,7 +89,7 @@ typedef struct golap_device_info {
     uint64_t total_mem_bytes;
     uint64_t free_mem_bytes;
     uint32_t l2_bytes;
-    /* ABI 4: which form of the four hand-scheduled kernels this library launches by default.  The forms with hidden (inline-asm) memory
+    /* ABI 4: which form of the five hand-scheduled kernels this library launches by default.  The forms with hidden (inline-asm) memory
      * operations and counted waits were audited -- statically on the generated code and on a GPU against the plain forms -- for ONE
      * hipcc (audited_with); a library built by any other hipcc (built_with) launches the plain forms: hidden_memory_forms = 0. */
     uint32_t hidden_memory_forms;

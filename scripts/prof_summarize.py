@@ -66,7 +66,7 @@ json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 # reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes.  Keyed by the library's profile names.
 NAMES = [("k_part1_narrow<12, 12288", "radix_scatter_p1_wide"), ("k_part1_narrow<", "radix_scatter_p1"), ("k_part2_ring<", "radix_scatter_p2"),
          ("k_join_lds16<0", "join_build_probe_lds"), ("k_join_lds<0, true", "join_build_probe_lds"),
-         ("k_scatter_big<1", "radix_scatter_p1_wide"), ("k_scatter_wc<2, true", "radix_scatter_p2_wide"), ("k_join_lds<0, false", "join_build_probe_lds_wide"),
+         ("k_scatter_big<1", "radix_scatter_p1_wide"), ("k_part2_wide<", "radix_scatter_p2_wide"), ("k_scatter_wc<2, true", "radix_scatter_p2_wide"), ("k_join_lds<0, false", "join_build_probe_lds_wide"),
          ("k_hist<1", "radix_hist_p1"),
          ("k_group_lds<", "hash_aggregate_lds"), ("k_agg_scatter_rsv<", "agg_partition_scatter"), ("k_agg_scatter_wc<", "agg_partition_scatter"), ("k_agg_scatter_big<", "agg_partition_scatter"),
          ("k_agg_scatter<", "agg_partition_scatter"),

@@ -1,5 +1,5 @@
 """Static audit of the kernels that hide memory operations from hipcc (csrc/golap_hidden.h: the ASM forms of csrc/golap_part_narrow.h
-and k_agg_scatter_rsv in csrc/golap_ops.hip).
+and csrc/golap_part_wide.h, and k_agg_scatter_rsv in csrc/golap_ops.hip).
 
 Those kernels issue their loads and stores in `asm volatile` statements and wait for them with hand-counted `s_waitcnt vmcnt(N)`
 (cdna_hip_programming.md 5.7).  That is only sound while the compiler (1) never spills -- a spilled or reloaded register may be the
@@ -20,14 +20,14 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # The instantiations the product is known to launch by default (k_part1_narrow<18, 18432, VEC2, ASM> and the four ring lengths): they
 # must be present; every OTHER instantiation with ASM = true found in the assembly is audited as well (discovered, not listed).
 EXPECTED = ["k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi0ELi0EEE", "k_part1_narrowILi18ELi18432ELb1ELb1ELi0ELi1ELi0EEE", "k_part1_narrowILi14ELi14336ELb1ELb1ELi0ELi2ELi0EEE",
-            "k_part1_narrowILi12ELi12288ELb1ELb1ELi0ELi0ELi1EEE", "k_part2_ringILi4ELi32ELb1ELi0EEE",
+            "k_part1_narrowILi12ELi12288ELb1ELb1ELi0ELi0ELi1EEE", "k_part2_wideILi12ELb1EEE", "k_part2_ringILi4ELi32ELb1ELi0EEE",
             "k_part2_ringILi4ELi64ELb1ELi0EEE", "k_part2_ringILi4ELi128ELb1ELi0EEE", "k_part2_ringILi4ELi256ELb1ELi0EEE",
             "k_agg_scatter_rsvIiLb1ELb1EEE", "k_agg_scatter_rsvIiLb0ELb1EEE", "k_agg_scatter_rsvIxLb1ELb1EEE", "k_agg_scatter_rsvIxLb0ELb1EEE"]
 # template <int RPT, int WIN, bool VEC2, bool ASM, int DIAG, int DICT, int WIDE> k_part1_narrow / template <int RPT, int R, bool ASM, int DIAG> k_part2_ring
-# template <typename KeyT, bool VAL_F64, bool ASM> k_agg_scatter_rsv
+# template <typename KeyT, bool VAL_F64, bool ASM> k_agg_scatter_rsv; template <int RPT, bool ASM> k_part2_wide (csrc/golap_part_wide.h)
 # (the whole template argument list is part of the key, up to the EEE that closes it: a new template parameter shows up as a new key)
 ASM_FORMS = re.compile(r"^_ZN5golap\d+(k_part1_narrowILi\d+ELi\d+ELb[01]ELb1E(?:Li\d+E)+EE|k_part2_ringILi\d+ELi\d+ELb1E(?:Li\d+E)+EE|"
-                       r"k_agg_scatter_rsvI[a-z]Lb[01]ELb1E(?:L[a-z]\d+E)*EE)\w*:", re.M)
+                       r"k_agg_scatter_rsvI[a-z]Lb[01]ELb1E(?:L[a-z]\d+E)*EE|k_part2_wideILi\d+ELb1E(?:L[a-z]\d+E)*EE)\w*:", re.M)
 # The audit reads ONE compiler's output: the hand-counted waits and the fixed-register scheme were validated (on the GPU, row by row:
 # tests/test_join_gpu.py::test_hidden_forms_match_plain_forms) with exactly this hipcc.  A different compiler must be re-validated
 # there before this constant is changed.
@@ -117,6 +117,22 @@ def test_the_audit_sees_a_planted_violation(asm):
         _audit(planted, key)
 
 
+def test_the_audit_sees_a_planted_stray_wait(asm):
+    """a compiler-style `s_waitcnt vmcnt(0)` in a block of the tile loop (it would drain the prefetch on every tile) must fail the
+    audit; the same line in a cold block behind s_endpgm must not"""
+    key = "k_part2_wideILi12ELb1EEE"
+    name, lines = _body(asm, key)
+    at = next(i for i, l in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", l) and "in Loop" in l)
+    bad = lines[:at + 1] + ["\ts_waitcnt vmcnt(0)"] + lines[at + 1:]
+    start = asm.index("\n".join(lines))
+    planted = asm[:start] + "\n".join(bad) + asm[start + len("\n".join(lines)):]
+    with pytest.raises(AssertionError, match="compiler-inserted vmcnt waits"):
+        _audit(planted, key)
+    end = max(i for i, l in enumerate(lines) if "s_endpgm" in l)
+    cold = lines[:end + 1] + [".LBB999_999:", "\ts_waitcnt vmcnt(0)", "\ts_endpgm"] + lines[end + 1:]
+    _audit(asm[:start] + "\n".join(cold) + asm[start + len("\n".join(lines)):], key)
+
+
 def _audit(asm, key):
     name, lines = _body(asm, key)
     # (1) no spills, no scratch
@@ -198,14 +214,18 @@ def _audit(asm, key):
         nv = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\n(?:.*\n)*?\s+\.amdhsa_next_free_vgpr (\d+)", asm)
         assert nv and int(nv.group(1)) >= first + 2 * pairs, f"{key}: kernel descriptor does not cover the fixed registers"
     # (3) every vmcnt wait in the kernel is one of ours (inside an asm statement), except before the main loop / after it
-    stray, in_asm, seen_loop = [], False, False
+    #     (which block an instruction belongs to, and whether that block is part of a loop, is what hipcc's own block comments say:
+    #     `.LBBn_m:  ; in Loop: Header=...`, `; %bb.k:  ; in Loop: ...`, `; =>This Loop Header`, `; Parent Loop ...` -- cold blocks
+    #     placed behind s_endpgm carry no such comment and are not part of the tile loop, whatever stands in the lines above them)
+    stray, in_asm, in_loop = [], False, False
     for i, l in enumerate(lines):
+        if re.match(r"\s*(\.LBB\d+_\d+:|; %bb\.\d+:)", l):
+            nxt = lines[i + 1] if i + 1 < len(lines) else ""
+            in_loop = any(w in l for w in ("in Loop", "Loop Header", "Parent Loop")) or (nxt.strip().startswith(";") and "Loop Header" in nxt)
         if "ASMSTART" in l:
             in_asm = True
         elif "ASMEND" in l:
             in_asm = False
-        elif "Loop Header" in l and "Depth=1" in l:
-            seen_loop = True
-        elif "s_waitcnt" in l and "vmcnt" in l and not in_asm and seen_loop and "in Loop" in "".join(lines[max(0, i - 40):i]):
+        elif "s_waitcnt" in l and "vmcnt" in l and not in_asm and in_loop:
             stray.append((i, l.strip()))
     assert not stray, f"{key}: compiler-inserted vmcnt waits inside the tile loop: {stray[:3]}"

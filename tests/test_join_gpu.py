@@ -867,9 +867,37 @@ def test_hidden_forms_match_plain_forms(ctx, bits, ring):
                                              f"first {bad[:8].tolist()} -> {got[bad[:8]].tolist()}")
 
 
+@pytest.mark.parametrize("bits", ["9,9", "9,7", "8,6"])
+def test_wide_last_pass_forms_match(ctx, bits):
+    """The 64-bit-row pipeline's no-histogram last pass: k_part2_wide (csrc/golap_part_wide.h) with hidden loads and stores (GOLAP_P2W=1,
+    the default of an audited build), with compiler-visible ones (2) and round 1's write-combining k_scatter_wc<2, FIXED> (0), row by
+    row -- behind the reserving first pass (groups = per-XCD pieces, every piece ends in a partial tile) and behind the exact first
+    pass (GOLAP_RESERVE=0: groups start at odd rows, so every tile takes the clamped 8- and 4-byte loads).  Keys with 256 scattered
+    upper halves: no 8-byte tuple can carry them."""
+    n = 24_000_011
+    bt = ctx.generate(N.GEN_BUILD_KEYS, n, modulus=n)
+    pt = ctx.generate(N.GEN_SM64_MOD_I64, n, modulus=n, seed=43)
+    inv = torch.empty(n, dtype=torch.int64, device="cuda")
+    inv[bt] = torch.arange(n, dtype=torch.int64, device="cuda")
+    exp = inv[pt]
+    del inv
+    bt += ((bt * 0x9E3779B1) & 0xFF) << 44
+    pt += ((pt * 0x9E3779B1) & 0xFF) << 44
+    for reserve in ("1", "0"):
+        for form in ("1", "2", "0"):
+            ctx.stats_reset()
+            m, got = _pairs_by_probe(ctx, bt, pt, n, GOLAP_PASS_BITS=bits, GOLAP_RESERVE=reserve, GOLAP_P2W=form)
+            st = ctx.stats()
+            p2 = [k for k, v in st.items() if "scatter_p2" in k and "standby" not in k and v["total_ms"] > 0.05]
+            assert p2, f"no last-pass scatter in the profile: {sorted(st)}"
+            bad = torch.nonzero(got != exp).flatten()
+            assert m == n and bad.numel() == 0, (f"bits {bits} reserve {reserve} GOLAP_P2W={form}: {m} pairs for {n} probe rows; {bad.numel()} probe rows without "
+                                                 f"exactly their partner, first {bad[:8].tolist()} -> {got[bad[:8]].tolist()}")
+
+
 def test_a_build_by_an_unaudited_compiler_runs_the_plain_forms(ctx):
     """GOLAP_HIDDEN_FORMS=0 flips the one switch a compiler mismatch flips (csrc/golap_variants.h: a library built by a hipcc other
-    than the audited one): golap_device_info says so, every one of the four hand-scheduled kernels takes its plain form -- tuple
+    than the audited one): golap_device_info says so, every one of the five hand-scheduled kernels takes its plain form -- tuple
     pipeline, 64-bit-row pipeline, dictionary columns (which then take the 64-bit rows: the dictionary forms exist hidden only) and
     the GROUP BY scatter -- and every result is still exact."""
     info = ctx.device_info()

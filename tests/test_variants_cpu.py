@@ -16,7 +16,7 @@ PROBE = r"""
 #include "golap_variants.h"
 int main(int argc, char** argv) {
     const golap::KernelForms f = golap::default_kernel_forms(argc > 1 ? argv[1] : nullptr);
-    printf("%d %d %d %d %d %d\n", (int)golap::kHiddenFormsAudited, f.p1n, f.p2r, f.p1w, (int)f.agg_rsv_hidden, (int)f.hidden);
+    printf("%d %d %d %d %d %d %d\n", (int)golap::kHiddenFormsAudited, f.p1n, f.p2r, f.p1w, f.p2w, (int)f.agg_rsv_hidden, (int)f.hidden);
     return 0;
 }
 """
@@ -36,19 +36,19 @@ def _audited():
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/include/hip/hip_version.h"), reason="ROCm headers not installed")
 def test_this_images_compiler_is_the_audited_one_and_selects_the_hidden_forms(tmp_path):
-    assert _run(tmp_path, []) == [1, 118, 104, 1, 1, 1]
+    assert _run(tmp_path, []) == [1, 118, 104, 1, 1, 1, 1]
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/include/hip/hip_version.h"), reason="ROCm headers not installed")
 @pytest.mark.parametrize("fake", [(0, 1, 0), (0, 0, 1), (1, 0, 0)])
 def test_a_library_built_by_another_compiler_selects_the_plain_forms(tmp_path, fake):
-    """a compiler upgrade (patch, minor or major) without a new audit: every one of the four kernels takes its plain form"""
+    """a compiler upgrade (patch, minor or major) without a new audit: every one of the five kernels takes its plain form"""
     mj, mn, pt = (a + d for a, d in zip(_audited(), fake))
     defs = [f"-DGOLAP_BUILD_HIP_MAJOR={mj}", f"-DGOLAP_BUILD_HIP_MINOR={mn}", f"-DGOLAP_BUILD_HIP_PATCH={pt}"]
-    assert _run(tmp_path, defs) == [0, 18, 4, 2, 0, 0]
+    assert _run(tmp_path, defs) == [0, 18, 4, 2, 2, 0, 0]
     # the developer's switch to run the GPU half of the audit on such a build, and the way back
-    assert _run(tmp_path, defs, "1") == [0, 118, 104, 1, 1, 1]
-    assert _run(tmp_path, [], "0") == [1, 18, 4, 2, 0, 0]
+    assert _run(tmp_path, defs, "1") == [0, 118, 104, 1, 1, 1, 1]
+    assert _run(tmp_path, [], "0") == [1, 18, 4, 2, 2, 0, 0]
 
 
 def test_the_isa_audit_and_the_header_name_the_same_compiler():
