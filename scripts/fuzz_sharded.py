@@ -51,7 +51,7 @@ def worker(rank, world, port, budget, seed, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     import oracle
     from gpu_olap_engine_amd.distributed import NativeShardedJoin
     from gpu_olap_engine_amd.engine import Context
@@ -134,7 +134,8 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     world = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import tempfile, uuid
+    port = os.path.join(tempfile.gettempdir(), f"golap_rdzv_{os.getpid()}_{uuid.uuid4().hex}")   # a FileStore rendezvous: no port to race for
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     procs = [mpc.Process(target=worker, args=(r, world, port, budget, seed, q)) for r in range(world)]

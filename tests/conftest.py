@@ -23,3 +23,18 @@ def ctx():
     c = Context(profiling=True, max_gpu_memory=0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _no_stray_ranks():
+    """A multi-process test that fails half-way (one rank raised, the others still wait for it in a collective) must not leave
+    its ranks behind: they would hold the GPU and keep the test session from exiting.  Ends exactly the processes this session
+    started (multiprocessing's own list of live children), never anything by name."""
+    yield
+    import multiprocessing
+    for p in multiprocessing.active_children():
+        p.terminate()
+        p.join(10)
+        if p.is_alive():
+            p.kill()
+            p.join(10)

@@ -84,11 +84,15 @@ class OracleBackend:
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """the ranks' rendezvous: a fresh FILE (torch FileStore), not a TCP port -- `bind(0)`, close, hand the number to another process is a
+    race (seen once in ~450 GPU tests: EADDRINUSE in rank 0, the other ranks waiting for it until the test's timeout); gloo's own
+    pair sockets are bound by gloo itself.  (The name and the `port` arguments stay: it is what identifies a rendezvous.)"""
+    import atexit
+    import tempfile
+    import uuid
+    path = os.path.join(tempfile.gettempdir(), f"golap_rdzv_{os.getpid()}_{uuid.uuid4().hex}")
+    atexit.register(lambda: os.path.exists(path) and os.remove(path))
+    return path
 
 
 def _widen_some(b, p, lo, hi, n, wide):
@@ -110,7 +114,7 @@ def _worker(rank, world, port, n, variant, q, max_msg=1 << 30, e1=0, wide=""):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         import oracle
         from gpu_olap_engine_amd.distributed import ShardedJoin, shard_range
@@ -190,7 +194,7 @@ def _agg_worker(rank, world, port, n, G, q):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         import oracle
         from gpu_olap_engine_amd.distributed import ShardedAggregate, shard_range
@@ -238,7 +242,7 @@ def _plan_worker(rank, world, port, n, max_msg, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         from gpu_olap_engine_amd.engine import shard_range, sharded_plan
         pl = sharded_plan(world, n, max_msg_bytes=max_msg)

@@ -21,11 +21,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """the ranks' rendezvous: a fresh FILE (torch FileStore), not a TCP port -- `bind(0)`, close, hand the number to another process is a
+    race (seen once in ~450 GPU tests: EADDRINUSE in rank 0, the other ranks waiting for it until the test's timeout); gloo's own
+    pair sockets are bound by gloo itself.  (The name and the `port` arguments stay: it is what identifies a rendezvous.)"""
+    import atexit
+    import tempfile
+    import uuid
+    path = os.path.join(tempfile.gettempdir(), f"golap_rdzv_{os.getpid()}_{uuid.uuid4().hex}")
+    atexit.register(lambda: os.path.exists(path) and os.remove(path))
+    return path
 
 
 def _keys(variant, n, lo, cnt):
@@ -58,7 +62,7 @@ def _worker(rank, world, port, n, variant, mode, join_type, wide_rank, max_msg, 
         os.environ["GOLAP_SHARD_FAST"] = "1"       # the fast path at test sizes (its size condition is a speed rule, not a correctness one)
         os.environ["GOLAP_LOCAL_BITS"] = "6"       # ... with a ring-sized local fan-out (64) although the tables would fit LDS with less
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         from gpu_olap_engine_amd.distributed import NativeShardedJoin
         from gpu_olap_engine_amd.engine import Context, shard_range
@@ -128,7 +132,7 @@ def _worker_big(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         from gpu_olap_engine_amd import _native as N
         from gpu_olap_engine_amd.distributed import NativeShardedJoin
@@ -238,7 +242,7 @@ def _worker_uneven(rank, world, port, n, cuts, mode, q):
         os.environ["GOLAP_SHARD_FAST"] = "1"
         os.environ["GOLAP_LOCAL_BITS"] = "6"
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         import oracle
         from gpu_olap_engine_amd.distributed import NativeShardedJoin
@@ -422,7 +426,7 @@ def _worker_err(rank, world, port, n, mode, bad_rank, q):
         os.environ["GOLAP_SHARD_FAST"] = "1"
         os.environ["GOLAP_LOCAL_BITS"] = "6"
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         import oracle
         from gpu_olap_engine_amd import _native as N
@@ -482,7 +486,7 @@ def _worker_agg(rank, world, port, n, groups, hashed, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         import oracle
         from gpu_olap_engine_amd import _native as N
@@ -591,7 +595,7 @@ def _worker_composite(rank, world, port, n, jt, q, plain_rank=-1, cols=2, mode=N
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         from gpu_olap_engine_amd.distributed import NativeShardedJoin
         from gpu_olap_engine_amd.engine import Context, shard_range
