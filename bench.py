@@ -385,7 +385,7 @@ def bench_join(args, n_total, label):
                 assert int(v[0].item()) == mw, f"{name} emitted pairs with unequal keys"
             gb = alg_join / (msw * 1e-3) / 1e9
             return {"ms_per_step": round(msw, 3), "value": round(2 * n_total / (msw * 1e-3), 1), "unit": "rows/s", "join_alg_GBps": round(gb, 1),
-                    "join_roofline_frac": round(gb / HBM_PEAK_GBPS, 4), "roofline": roofline_of(statsw, n_total, 1, False, mw),
+                    "join_roofline_frac": round(gb / HBM_PEAK_GBPS, 4), "roofline": roofline_of(statsw, n_total, 1, name == "random_upper_halves", mw),   # (PMC traffic only for the 64-bit-row kernels: profiles/r04_bench_1b_wide)
                     "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in statsw.items() if v["total_ms"] / args.steps > 0.02},
                     "workload": what}
         bkeys += 1 << 40
