@@ -558,6 +558,25 @@ def test_bench_launches_its_own_ranks():
         assert sj["exchange"]["build_per_link_GBps"] > 0 and sj["exchange"]["probe_per_link_GBps"] > 0
 
 
+def test_bench_draws_workspaces_and_keeps_the_fastest():
+    """bench.py --workspace-draws K (single-GPU joins): K contexts -- K physical placements of the workspace slab -- are tried before the
+    warm-up, the fastest is kept, every draw is in the line (DESIGN 9 'Run-to-run spread'); --workspace-draws 1 takes the first as
+    it comes.  The line still verifies its own result."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k in (3, 1):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C3", "--rows", "30000000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0",
+                              "--workspace-draws", str(k)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["verify"]["matches"] == 30_000_000 and d["verify"]["probe_id_sum_ok"]
+        if k == 1:
+            assert "workspace_draws" not in d
+        else:
+            w = d["workspace_draws"]
+            assert w["draws"] == k and len(w["ms_per_join"]) == k and w["ms_per_join"][w["kept"]] == min(w["ms_per_join"]) and "stopped_by" not in w
+
+
 def test_join_partitioned_two_sources(ctx):
     """post-exchange path: 2 sources x 128 slots on one device must equal the plain join."""
     n = 600_000
