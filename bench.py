@@ -50,6 +50,9 @@ def parse_args():
                     help="C5/C3 main leg: key columns as generated (below 2^32) | + 2^40 | two upper halves | 2^16 key-dependent upper halves (the 64-bit-row "
                          "pipeline): what the profiles of the wide kernels are taken on")
     ap.add_argument("--no-others", action="store_true", help="C5 default run: skip the other_configs block (C3, C4, C4L, C1)")
+    ap.add_argument("--pipelining", action="store_true",
+                    help="OP: a filter's batch k is filtered while batch k + 1 is uploaded (golap_host_set_pipelining(1)) -- the A/B of the default, "
+                         "one transfer phase for all batches; measured slower (DESIGN.md 8)")
     ap.add_argument("--sharded", action="store_true", help="force the partition-exchange path (golap_sharded_join) even with 1 rank")
     ap.add_argument("--workspace-draws", type=int, default=6,
                     help="single-GPU joins: contexts (= workspace slabs, i.e. physical placements of the partition buffers) tried before the warm-up; "
@@ -654,6 +657,7 @@ def bench_operator_plan(args, n):
     torch.cuda.set_device(0)
     ctx = Context(profiling=False, max_gpu_memory=0)
     info = ctx.device_info()
+    O.load_host().golap_host_set_pipelining(1 if args.pipelining else 0)
     n_c = max(1000, n // 100)
     rng = np.random.default_rng(5)
     o_cust = rng.integers(0, n_c + n_c // 10, n, dtype=np.int64)            # 1 in 11 orders references nobody
@@ -702,6 +706,7 @@ def bench_operator_plan(args, n):
             "config": {"workload": f"OP GpuAggregate{{GpuHashJoin{{customers {n_c} rows, GpuFilter{{orders {n} rows in {nb} batches, flag < 5}}}}, GROUP BY seg, SUM + COUNT}} "
                                    f"through golap_plan_* / golap_execute, inputs in pageable host memory (pyarrow), result back as Arrow"},
             "end_to_end_ms": round(ms, 3), "input_bytes": in_bytes,
+            "pipelined_filter": bool(args.pipelining),   # batch k filtered while batch k + 1 is uploaded (h2d_ms then holds those kernels too); off by default
             "h2d_bytes": int(avg["h2d_bytes"]), "h2d_ms": round(avg["h2d_ms"], 3), "h2d_GBps": round(avg["h2d_bytes"] / max(avg["h2d_ms"], 1e-9) / 1e6, 2),
             "d2h_bytes": int(avg["d2h_bytes"]), "d2h_ms": round(avg["d2h_ms"], 3), "d2h_GBps": round(avg["d2h_bytes"] / max(avg["d2h_ms"], 1e-9) / 1e6, 4),
             "device_and_host_ms": round(avg["total_ms"] - avg["h2d_ms"] - avg["d2h_ms"], 3), "kernel_wait_ms": round(avg["kernel_wait_ms"], 3),

@@ -24,10 +24,12 @@
 #include <atomic>
 #include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,6 +39,7 @@
 namespace {
 
 std::atomic<uint32_t> g_xfer_threads{8};   // host threads (= transfer streams used) of a transfer phase: golap_host_set_transfer_threads
+std::atomic<uint32_t> g_pipeline{0};       // GpuFilter over several batches: batch k is filtered while batch k + 1 is uploaded (golap_host_set_pipelining; measured: loses, off)
 thread_local std::string g_err;
 int32_t herr(int32_t code, const std::string& msg) {
     g_err = msg;
@@ -329,6 +332,9 @@ struct Exec {
     void up(const void* src, uint64_t dst, uint64_t bytes) { if (bytes) pending.push_back({GOLAP_HOST_TO_DEVICE, (uint64_t)(uintptr_t)src, dst, bytes}); }
     void down(uint64_t src, void* dst, uint64_t bytes) { if (bytes) pending.push_back({GOLAP_DEVICE_TO_HOST, src, (uint64_t)(uintptr_t)dst, bytes}); }
     int32_t flush();
+    // the transfers of `list`, cut into pieces and dealt to the host threads, ONE wait; touches nothing of this object but `ctx`
+    // (flush() runs it on the calling thread, the filter's Uploader on its own)
+    int32_t run_transfers(const std::vector<Xfer>& list, uint64_t& up_bytes, uint64_t& down_bytes) const;
     int32_t ksync() {
         const double t0 = now_ms();
         const int32_t s = golap_ctx_synchronize(ctx, nullptr);
@@ -356,10 +362,17 @@ struct Exec {
         return -1;
     }
 
+    // record_batch_to_gpu_buffers in three steps: queue (allocations + the raw uploads into `pending`), the transfer, finish (the kernels
+    // that expand / widen / hash what has landed) -- to_device() is the three in a row, the pipelined filter runs them per batch
+    struct IngestJob { Column* c = nullptr; DevPtr raw, bitmap, offs, offs32; uint64_t bit_off = 0; int64_t str_first = 0; int widen = -1; bool large = false; };
+    int32_t ingest_queue(const std::vector<RecordBatch*>& bs, std::vector<IngestJob>& jobs);
+    int32_t ingest_finish(std::vector<IngestJob>& jobs);
     int32_t to_device(const std::vector<RecordBatch*>& bs);
     int32_t to_host(std::vector<RecordBatch>& bs);
     int32_t run(golap_plan& p, std::vector<RecordBatch>& out);
     int32_t filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::vector<RecordBatch>& out);
+    struct FilterTodo { bool pass = true; std::vector<golap_filter_predicate> fps; std::vector<int> fcols; };
+    int32_t filter_pipelined(std::vector<RecordBatch>& in, const std::vector<FilterTodo>& todo, std::vector<RecordBatch>& out);
     int32_t projection(std::vector<RecordBatch>& in, const std::vector<std::unique_ptr<golap_expr>>& exprs, std::vector<RecordBatch>& out);
     int32_t hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out);
     int32_t aggregate(std::vector<RecordBatch>& in, golap_plan& p, std::vector<RecordBatch>& out);
@@ -371,24 +384,22 @@ struct Exec {
 // Runs the queued transfers: large ones are cut into 32 MiB pieces and dealt to up to 8 host threads, thread t on transfer stream t
 // (transfer_queue.rs:72: stream_id % num_streams) -- pageable Arrow buffers are staged through that stream's two pinned bounce buffers,
 // so the staging memcpy of one stream runs beside the DMA of the others; the caller waits ONCE, for all of them.
-int32_t Exec::flush() {
-    if (pending.empty()) return GOLAP_OK;
-    H_TRY(need_ctx());
-    const double t0 = now_ms();
+int32_t Exec::run_transfers(const std::vector<Xfer>& list, uint64_t& up_bytes, uint64_t& down_bytes) const {
     std::vector<Xfer> pieces;
-    uint64_t up_bytes = 0, down_bytes = 0;
+    up_bytes = down_bytes = 0;
     const uint64_t piece = 32ull << 20;
-    for (const Xfer& x : pending) {
+    for (const Xfer& x : list) {
         (x.dir == GOLAP_HOST_TO_DEVICE ? up_bytes : down_bytes) += x.bytes;
         for (uint64_t o = 0; o < x.bytes; o += piece) pieces.push_back({x.dir, x.src + o, x.dst + o, std::min(piece, x.bytes - o)});
     }
-    pending.clear();
+    if (pieces.empty()) return GOLAP_OK;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t T = (up_bytes + down_bytes) < (8ull << 20) ? 1 : std::min<size_t>({(size_t)g_xfer_threads.load(), hw, pieces.size()});
     std::vector<int32_t> status(T, GOLAP_OK);
+    golap_ctx* c = ctx;
     auto work = [&](size_t t) {
         for (size_t i = t; i < pieces.size(); i += T) {
-            const int32_t s = golap_xfer_enqueue(ctx, pieces[i].dir, pieces[i].src, pieces[i].dst, pieces[i].bytes, (uint32_t)t);
+            const int32_t s = golap_xfer_enqueue(c, pieces[i].dir, pieces[i].src, pieces[i].dst, pieces[i].bytes, (uint32_t)t);
             if (s != GOLAP_OK) { status[t] = s; return; }
         }
     };
@@ -399,13 +410,24 @@ int32_t Exec::flush() {
         work(0);
         for (auto& x : th) x.join();
     }
-    const int32_t sync = golap_xfer_synchronize(ctx);
+    const int32_t sync = golap_xfer_synchronize(c);
+    for (int32_t s : status) H_TRY(s);
+    return sync;
+}
+
+int32_t Exec::flush() {
+    if (pending.empty()) return GOLAP_OK;
+    H_TRY(need_ctx());
+    const double t0 = now_ms();
+    std::vector<Xfer> list;
+    list.swap(pending);
+    uint64_t up_bytes = 0, down_bytes = 0;
+    const int32_t s = run_transfers(list, up_bytes, down_bytes);
     const double dt = now_ms() - t0;
     // (a phase moves one way: uploads at an operator's start, downloads of counts / results at its end)
     if (up_bytes >= down_bytes) { prof.h2d_bytes += up_bytes; prof.h2d_ms += dt; prof.d2h_bytes += down_bytes; }
     else { prof.d2h_bytes += down_bytes; prof.d2h_ms += dt; prof.h2d_bytes += up_bytes; }
-    for (int32_t s : status) H_TRY(s);
-    return sync;
+    return s;
 }
 
 // ---------------------------------------------------------------------------
@@ -414,9 +436,8 @@ int32_t Exec::flush() {
 // Every column of `bs` that is not in HBM yet goes there: phase 1 queues the raw uploads of ALL of them (values at their Arrow width
 // from the array offset on, the validity bitmap from the byte that holds the first row's bit, string offsets and bytes), one flush;
 // phase 2 expands the bitmaps to a byte per row, widens to 8 bytes with NULL -> 0 (:102-110) and hashes strings (:112-130) in place.
-int32_t Exec::to_device(const std::vector<RecordBatch*>& bs) {
-    struct Job { Column* c; DevPtr raw, bitmap, offs, offs32; uint64_t bit_off = 0; int64_t str_first = 0; int widen = -1; bool large = false; };
-    std::vector<Job> jobs;
+int32_t Exec::ingest_queue(const std::vector<RecordBatch*>& bs, std::vector<IngestJob>& jobs) {
+    using Job = IngestJob;
     for (RecordBatch* b : bs)
         for (Column& c : b->cols) {
             if (c.where == Column::Device) continue;
@@ -463,9 +484,11 @@ int32_t Exec::to_device(const std::vector<RecordBatch*>& bs) {
             }
             jobs.push_back(std::move(j));
         }
-    if (jobs.empty()) return GOLAP_OK;
-    H_TRY(flush());
-    for (Job& j : jobs) {
+    return GOLAP_OK;
+}
+
+int32_t Exec::ingest_finish(std::vector<IngestJob>& jobs) {
+    for (IngestJob& j : jobs) {
         Column& c = *j.c;
         const uint64_t n = c.rows;
         if (c.where == Column::Arrow && n) {
@@ -490,6 +513,14 @@ int32_t Exec::to_device(const std::vector<RecordBatch*>& bs) {
         c.in_valid.clear(); c.in_valid.shrink_to_fit();
     }
     return GOLAP_OK;
+}
+
+int32_t Exec::to_device(const std::vector<RecordBatch*>& bs) {
+    std::vector<IngestJob> jobs;
+    H_TRY(ingest_queue(bs, jobs));
+    if (jobs.empty()) return GOLAP_OK;
+    H_TRY(flush());
+    return ingest_finish(jobs);
 }
 
 // gpu_buffers_to_record_batch (record_batch_convert.rs:136-178): the result leaves the device once -- values as they are, validity
@@ -632,7 +663,7 @@ static void and_leaves(const golap_expr& e, std::vector<const golap_expr*>& out)
 
 int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::vector<RecordBatch>& out) {
     // what each batch needs: nothing (every row passes: :474, :449-452), or a conjunction of <Int64 column> <op> <literal> comparisons
-    struct Todo { bool pass = true; std::vector<golap_filter_predicate> fps; std::vector<int> fcols; };
+    using Todo = FilterTodo;
     std::vector<Todo> todo(in.size());
     std::vector<RecordBatch*> upload;
     for (size_t bi = 0; bi < in.size(); ++bi) {
@@ -661,6 +692,8 @@ int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::
         td.pass = td.fps.empty();
         if (!td.pass && b.num_rows) upload.push_back(&b);
     }
+    // several batches, on request: batch k is filtered while batch k + 1 travels (filter_pipelined below; measured slower, see there)
+    if (upload.size() >= 2 && g_pipeline.load()) return filter_pipelined(in, todo, out);
     // ONE transfer phase for every batch the predicate runs on (a phase per batch left the link idle while the previous batch was filtered)
     if (!upload.empty()) {
         H_TRY(need_ctx());
@@ -708,6 +741,127 @@ int32_t Exec::filter(std::vector<RecordBatch>& in, const golap_expr& pred, std::
     return GOLAP_OK;
 }
 
+// GpuFilter over several batches, pipelined (golap_host_set_pipelining(1); OFF by default): the TransferQueue's double-buffered streams
+// carry batch k + 1 (fed by a background thread that runs the batches' transfer lists in order, each with its own wait) while the compute
+// stream expands / widens / filters / gathers batch k.  Nothing is read back per batch: the kept-row count stays in HBM
+// (golap_take_8byte / golap_take_1byte take it as count_ptr), the output columns are provisioned for the batch's row count, and ALL counts
+// come back in one download behind the last batch.
+// MEASURED (bench.py --config OP [--pipelining], 100M orders in 4 batches, interleaved runs on one box, profiles/r04_final/op_pipelining_ab.log):
+// 58.3 / 62.1 ms pipelined against 53.9 / 53.8 ms with one transfer phase for all batches -- the upload falls from 55 to 47-51 GB/s.
+// Knowing that batch k has landed takes golap_xfer_synchronize, which drains EVERY stream: at each batch boundary the link waits for the
+// last bounce buffers (8 MiB per stream) and then for the first staging memcpy of the next batch, ~2 ms per boundary, to hide a filter
+// that is 0.3 ms of kernels per 25M-row batch on this chip.  The plan is bound by the PCIe link (46 of 54 ms); what the device does
+// behind it -- the join, the pair sort, the gathers, the GROUP BY -- needs every batch anyway.  Kept as a tested option (both settings
+// give the same rows: test_filter_batches_pipelined_and_in_one_phase, the operator fuzzer flips it per round), not as the default.
+struct Uploader {
+    const Exec& ex;
+    std::vector<std::vector<Xfer>> lists;
+    std::vector<int32_t> status;
+    size_t done = 0;
+    uint64_t up_bytes = 0;
+    double busy_ms = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> stop{false};
+    std::thread th;
+    explicit Uploader(const Exec& e) : ex(e) {}
+    void start() {
+        status.assign(lists.size(), GOLAP_OK);
+        th = std::thread([this] {
+            for (size_t i = 0; i < lists.size(); ++i) {
+                int32_t s = GOLAP_OK;
+                uint64_t up = 0, down = 0;
+                const double t0 = now_ms();
+                if (!stop.load()) s = ex.run_transfers(lists[i], up, down);
+                const double dt = now_ms() - t0;
+                std::lock_guard<std::mutex> lk(mu);
+                status[i] = s;
+                up_bytes += up;
+                busy_ms += dt;
+                done = i + 1;
+                cv.notify_all();
+            }
+        });
+    }
+    int32_t wait(size_t i) {   // the transfers of list i have landed
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done > i; });
+        return status[i];
+    }
+    void join() { if (th.joinable()) th.join(); }
+    ~Uploader() { stop.store(true); join(); }   // (an operator that fails half-way: nothing is enqueued any more, what is in flight is waited for)
+};
+
+int32_t Exec::filter_pipelined(std::vector<RecordBatch>& in, const std::vector<FilterTodo>& todo, std::vector<RecordBatch>& out) {
+    H_TRY(need_ctx());
+    struct Slot { int list = -1; std::vector<IngestJob> jobs; DevPtr didx, dcnt; RecordBatch ob; uint64_t kept = 0; bool ran = false; };
+    std::vector<Slot> slots(in.size());
+    Uploader upl(*this);
+    // allocations and transfer lists of every batch first (what one transfer phase for all of them allocated up front as well)
+    for (size_t bi = 0; bi < in.size(); ++bi) {
+        if (todo[bi].pass || in[bi].num_rows == 0) continue;
+        std::vector<RecordBatch*> one{&in[bi]};
+        H_TRY(ingest_queue(one, slots[bi].jobs));
+        slots[bi].list = (int)upl.lists.size();
+        upl.lists.emplace_back();
+        upl.lists.back().swap(pending);
+    }
+    const double t_start = now_ms();
+    upl.start();
+    for (size_t bi = 0; bi < in.size(); ++bi) {
+        RecordBatch& b = in[bi];
+        const FilterTodo& td = todo[bi];
+        Slot& sl = slots[bi];
+        if (td.pass || b.num_rows == 0) continue;
+        const uint64_t n = b.num_rows;
+        H_TRY(upl.wait((size_t)sl.list));
+        H_TRY(ingest_finish(sl.jobs));
+        H_TRY(temp(sl.didx, n * 4));
+        H_TRY(temp(sl.dcnt, 8));
+        const size_t nf = td.fps.size();
+        std::vector<uint64_t> kptrs(nf, 0), vptrs(nf, 0);
+        for (size_t k = 0; k < nf; ++k) {
+            const Column& c = b.cols[td.fcols[k]];
+            kptrs[k] = c.d_data->ptr;
+            vptrs[k] = c.d_valid ? c.d_valid->ptr : 0;          // a comparison with NULL is not true: such rows do not pass
+        }
+        if (nf == 1) H_TRY(golap_filter_compact_nullable(ctx, &td.fps[0], kptrs[0], vptrs[0], n, sl.didx->ptr, sl.dcnt->ptr, nullptr));
+        else H_TRY(golap_filter_compact_and(ctx, td.fps.data(), kptrs.data(), vptrs.data(), (uint32_t)nf, n, sl.didx->ptr, sl.dcnt->ptr, nullptr));
+        for (Column& c : b.cols) {      // take_int64 (:496-507) of at most n rows: the kernels read the count where the compaction left it
+            Column oc;
+            oc.name = c.name; oc.dtype = c.dtype; oc.rows = 0; oc.where = Column::Device;
+            H_TRY(dev_alloc(oc.d_data, n * 8));
+            H_TRY(golap_take_8byte(ctx, c.d_data->ptr, sl.didx->ptr, sl.dcnt->ptr, n, oc.d_data->ptr, nullptr));
+            if (c.d_valid) {
+                H_TRY(dev_alloc(oc.d_valid, n));
+                H_TRY(golap_take_1byte(ctx, c.d_valid->ptr, sl.didx->ptr, sl.dcnt->ptr, n, oc.d_valid->ptr, nullptr));
+            }
+            sl.ob.cols.push_back(std::move(oc));
+        }
+        sl.ran = true;
+    }
+    upl.join();
+    prof.h2d_bytes += upl.up_bytes;
+    prof.h2d_ms += now_ms() - t_start;   // the upload phase's wall time; the kernels of all batches but the last ran inside it
+    H_TRY(ksync());
+    for (Slot& sl : slots)
+        if (sl.ran) down(sl.dcnt->ptr, &sl.kept, 8);
+    H_TRY(flush());
+    for (size_t bi = 0; bi < in.size(); ++bi) {
+        Slot& sl = slots[bi];
+        if (todo[bi].pass) { out.push_back(std::move(in[bi])); continue; }
+        if (!sl.ran || sl.kept == 0) continue;                  // empty batches are dropped (:173)
+        sl.ob.num_rows = sl.kept;
+        for (Column& c : sl.ob.cols) c.rows = sl.kept;
+        out.push_back(std::move(sl.ob));
+    }
+    H_TRY(end_op());
+    for (size_t bi = 0; bi < in.size(); ++bi)
+        if (slots[bi].ran)
+            for (Column& c : in[bi].cols) { c.d_data.reset(); c.d_valid.reset(); }   // the input batches' columns are not needed any more
+    return GOLAP_OK;
+}
+
 // execute_projection, executor.rs:184-214 (column references and literals; arithmetic stays on the planner's CPU side)
 int32_t Exec::projection(std::vector<RecordBatch>& in, const std::vector<std::unique_ptr<golap_expr>>& exprs, std::vector<RecordBatch>& out) {
     for (RecordBatch& b : in) {
@@ -741,6 +895,17 @@ int32_t Exec::projection(std::vector<RecordBatch>& in, const std::vector<std::un
 // ---------------------------------------------------------------------------
 // execute_hash_join, executor.rs:220-265
 // ---------------------------------------------------------------------------
+// JoinKernel::choose_strategy (join_kernel.rs:71-77) looks at the build side only: <= 1M rows -> BroadcastHashJoin.  The operator knows the
+// probe side too, and the broadcast join's global table only probes fast while it stays in an XCD's L2 (18 bytes per build row): with 1M
+// build rows it takes 3.26 ms for 50M probe rows, the radix join 0.75 ms; with 30 000 build rows the two are level at 50M probe rows and
+// broadcast wins below; with 1000 build rows broadcast wins everywhere (profiles/r04_final/strategy_ab.log).  So: the reference's rule,
+// except that a build side beyond 65 536 rows goes through the radix join.  Same pairs either way (both strategies are tested against the
+// oracle); the C ABI's golap_choose_strategy stays the reference's rule.
+static golap_join_strategy pick_strategy(uint64_t n_build) {
+    const golap_join_strategy s = golap_choose_strategy(n_build);
+    return (s == GOLAP_JOIN_BROADCAST_HASH && n_build > 65536) ? GOLAP_JOIN_RADIX_HASH : s;
+}
+
 int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>& right, golap_plan& p, std::vector<RecordBatch>& out) {
     if (left.empty() || right.empty()) return GOLAP_OK;                 // :231-233 -> vec![]
     if (p.left_keys.empty() || p.right_keys.empty()) return herr(GOLAP_ERR_INVALID_ARG, "GpuHashJoin needs one key per side");
@@ -818,7 +983,7 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
                 jp.build_validity[k] = bk[k].vptr;
                 jp.probe_validity[k] = pk[k].vptr;
             }
-            H_TRY(golap_join(ctx, golap_choose_strategy(nb), &jp, nullptr));   // JoinKernel::choose_strategy, join_kernel.rs:71-77
+            H_TRY(golap_join(ctx, pick_strategy(nb), &jp, nullptr));   // JoinKernel::choose_strategy, join_kernel.rs:71-77, refined above
             H_TRY(read_u64(dcnt->ptr, &m));
             if (m <= cap) break;
             cap = m;   // too small: retry with the exact size (the first buffer goes back to the pool at the end of the operator)
@@ -828,7 +993,9 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
     for (Column& c : ob.cols) { c.rows = m; c.where = m ? Column::Device : Column::Host; }
     if (m) {
         // canonical order (probe_rid, build_rid): the device order is unspecified (join_kernels.cuh:155) -- sorted, split into one index
-        // vector per side and used for the gathers without leaving the device
+        // vector per side and used for the gathers without leaving the device.  (Leaving the sort out where a GROUP BY hides the order
+        // gains nothing: the radix join emits pairs in sub-partition order, and the five payload gathers of the OP plan then take 4.3
+        // instead of 2.2 ms -- exactly the sort's 2.2 ms; profiles/r04_final/op_breakdown_unsorted_pairs.log.)
         H_TRY(golap_sort_u64(ctx, dpairs->ptr, m, nullptr));
         DevPtr dl, dr;
         H_TRY(temp(dl, m * 4));
@@ -1373,6 +1540,7 @@ int32_t golap_execute(golap_ctx* ctx, golap_plan* plan, golap_result** out_resul
 }
 
 void golap_host_set_transfer_threads(uint32_t n) { g_xfer_threads.store(std::max<uint32_t>(1, std::min<uint32_t>(n, 64))); }
+void golap_host_set_pipelining(uint32_t on) { g_pipeline.store(on ? 1u : 0u); }
 
 int32_t golap_result_profile(const golap_result* r, golap_exec_profile* out) {
     if (!r || !out) return herr(GOLAP_ERR_INVALID_ARG, "null argument");

@@ -53,6 +53,7 @@ HOST_SIGNATURES = {
     "golap_result_export": (C.c_int32, [_VP, C.c_uint32, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
     "golap_result_profile": (C.c_int32, [_VP, C.c_void_p]),
     "golap_host_set_transfer_threads": (None, [C.c_uint32]),
+    "golap_host_set_pipelining": (None, [C.c_uint32]),
     "golap_result_free": (None, [_VP]),
     "golap_host_last_error": (C.c_char_p, []),
 }

@@ -94,6 +94,11 @@ int32_t golap_result_profile(const golap_result* r, golap_exec_profile* out);
 /* Host threads that feed the TransferQueue in a transfer phase (thread t -> stream t % num_streams; default 8 = EngineConfig's
  * num_streams, lib.rs:37).  Process-wide; more than the context's streams only makes threads share a stream. */
 void golap_host_set_transfer_threads(uint32_t n);
+/* 1: GpuFilter over several batches uploads batch k + 1 (a background thread feeding the TransferQueue) while the device filters batch
+ * k, and reads all kept-row counts back once, behind the last batch.  0 (the default): one transfer phase for all batches, then the
+ * kernels -- measured faster on the PCIe-bound plans this layer sees (54 against 58-62 ms).  Process-wide; results
+ * do not depend on it. */
+void golap_host_set_pipelining(uint32_t on);
 /* Moves batch i out as an Arrow struct array (the caller releases it through the Arrow callbacks). */
 int32_t golap_result_export(golap_result* r, uint32_t i, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 void    golap_result_free(golap_result* r);

@@ -214,6 +214,7 @@ def main():
     while time.time() < t_end:
         rnd += 1
         k = kinds[int(rng.integers(0, len(kinds)))]
+        O.load_host().golap_host_set_pipelining(int(rng.integers(0, 2)))   # a filter's batches: one transfer phase (the default) or pipelined
         try:
             what = k(rng, ctx)
         except Exception as e:

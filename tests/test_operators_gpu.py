@@ -107,6 +107,56 @@ def test_hash_join_edge_cases(ctx):
         O.execute(O.GpuHashJoin(O.Batches([l]), O.Batches([r]), [O.Column(0, "id")], [O.Column(0, "id")], join_type="Cross"), ctx)
 
 
+@pytest.mark.parametrize("jt,code", [("Inner", 0), ("Full", 3)])
+def test_hash_join_with_a_build_side_beyond_the_l2_takes_the_radix_join(ctx, jt, code):
+    """The operator refines JoinKernel::choose_strategy (join_kernel.rs:71-77, build side only): a build side of more than 65 536 rows goes
+    through the radix join even below the reference's 1M-row threshold (its global table would no longer probe out of an XCD's L2).  The
+    same pairs in the same canonical order as the reference's restatement, payload and NULLs of the missing side included."""
+    rng = np.random.default_rng(31)
+    nb, n_p = 150_000, 400_001
+    lk = rng.integers(0, 120_000, nb).astype(np.int64)             # duplicates on the build side
+    rk = rng.integers(0, 140_000, n_p).astype(np.int64)            # some probe keys match nobody
+    lp, rp = rng.random(nb), rng.integers(0, 10**9, n_p).astype(np.int64)
+    cut = 90_001
+    left = O.Batches([rb(id=lk[:cut], lpay=lp[:cut]), rb(id=lk[cut:], lpay=lp[cut:])])
+    right = O.Batches([rb(fk=rk, rpay=rp)])
+    out = O.execute(O.GpuHashJoin(left, right, [O.Column(0, "id")], [O.Column(0, "fk")], join_type=jt), ctx)[0]
+    pairs, _ = oracle.hash_join_outer(lk, rk, code)
+    NULL = 0xFFFFFFFF
+    bi, pi = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+    bnull, pnull = bi == NULL, pi == NULL
+    assert out.num_rows == len(pairs)
+    for col, src, idx, null in ((0, lk, bi, bnull), (1, lp, bi, bnull), (2, rk, pi, pnull), (3, rp, pi, pnull)):
+        got = out.column(col)
+        assert got.null_count == int(null.sum()) and np.array_equal(np.array(got.is_null()), null)
+        assert np.array_equal(got.to_numpy(zero_copy_only=False)[~null], src[idx[~null]])
+
+
+def test_group_by_over_a_join_with_either_strategy(ctx):
+    """GpuAggregate over GpuHashJoin: the groups and their exact sums are numpy's whichever strategy the operator picks for the build side
+    -- the radix join (150 000 build rows) or the broadcast join (3 000)."""
+    rng = np.random.default_rng(37)
+    for n_c in (150_000, 3_000):
+        n_o = 600_000
+        c_id = rng.permutation(n_c).astype(np.int64)
+        c_seg = rng.integers(0, 50, n_c).astype(np.int64)
+        o_cust = rng.integers(0, n_c + n_c // 5, n_o).astype(np.int64)
+        o_amt = rng.integers(1, 1000, n_o).astype(np.float64)
+        plan = O.GpuAggregate(O.GpuHashJoin(O.Batches([rb(id=c_id, seg=c_seg)]), O.Batches([rb(cust=o_cust[:250_000], amt=o_amt[:250_000]), rb(cust=o_cust[250_000:], amt=o_amt[250_000:])]),
+                                            [O.Column(0, "id")], [O.Column(0, "cust")]),
+                              [O.Column(1, "seg")], [O.Sum(O.Column(3, "amt")), O.Count(O.Column(3, "amt")), O.Min(O.Column(3, "amt")), O.Max(O.Column(3, "amt"))])
+        out = O.execute(plan, ctx)[0]
+        keep = o_cust < n_c
+        seg_of = np.empty(n_c, np.int64)
+        seg_of[c_id] = c_seg
+        seg = seg_of[o_cust[keep]]
+        assert out.column(0).to_pylist() == list(range(50))
+        assert np.array_equal(out.column(1).to_numpy(), np.bincount(seg, weights=o_amt[keep], minlength=50))
+        assert np.array_equal(out.column(2).to_numpy(), np.bincount(seg, minlength=50).astype(np.float64))
+        for g in (0, 17, 49):
+            assert out.column(3)[g].as_py() == o_amt[keep][seg == g].min() and out.column(4)[g].as_py() == o_amt[keep][seg == g].max()
+
+
 @pytest.mark.parametrize("jt,code", [("Left", 1), ("Right", 2), ("Full", 3)])
 def test_outer_joins_produce_arrow_nulls(ctx, jt, code):
     """JoinType::{Left,Right,Full} (logical_plan.rs:53-58): the missing side's columns are Arrow nulls."""
@@ -513,6 +563,54 @@ def test_filter_conjunction(ctx):
     # a leaf with an unknown comparison selects nothing (executor.rs:464), and so does the conjunction
     out = O.execute(O.GpuFilter(O.Batches([rb]), And(O.BinaryExpr(A, "~", O.Literal("1")), O.BinaryExpr(B, "<", O.Literal("500")))), ctx)
     assert sum(x.num_rows for x in out) == 0
+
+
+@pytest.mark.parametrize("pipelined", [0, 1])
+def test_filter_batches_pipelined_and_in_one_phase(ctx, pipelined):
+    """GpuFilter over several batches: by default all batches go up in one transfer phase first; with golap_host_set_pipelining(1) batch k
+    is filtered while batch k + 1 is uploaded and every kept-row count comes back in ONE download behind the last batch.  The same rows either
+    way: batches that keep nothing or are empty are dropped (executor.rs:173), NULL predicate operands do not pass, narrow types, strings
+    (as their hashes) and validity bitmaps that start mid-byte travel with their rows."""
+    rng = np.random.default_rng(23)
+    L = O.load_host()
+    hashes = {f"s{i}": oracle.fnv1a_hash(f"s{i}".encode()) for i in range(37)}
+    batches, exp = [], []
+    for bi, n in enumerate((50_000, 0, 1, 131_073, 4_097, 20_000)):
+        k = rng.integers(0, 1000, n).astype(np.int64)
+        if bi == 4:
+            k += 5000                                                   # this batch keeps no row
+        knull = rng.random(n) < 0.1
+        v32 = rng.integers(-1000, 1000, n).astype(np.int32)
+        f = rng.random(n)
+        fnull = rng.random(n) < 0.2
+        s = [f"s{int(x) % 37}" for x in k]
+        cols = [pa.array(k, mask=knull), pa.array(v32), pa.array(f, mask=fnull), pa.array(s, pa.string())]
+        b = pa.RecordBatch.from_arrays(cols, names=["k", "v", "f", "s"])
+        if n > 100:
+            b = b.slice(3, n - 7)                                        # bitmaps and values from an offset that is not a multiple of 8
+            k, knull, v32, f, fnull, s = k[3:n - 4], knull[3:n - 4], v32[3:n - 4], f[3:n - 4], fnull[3:n - 4], s[3:n - 4]
+        batches.append(b)
+        m = ~knull & (k >= 100) & (k < 700)
+        if m.any():
+            exp.append((k[m], v32[m].astype(np.int64), f[m], fnull[m], [x for x, keep in zip(s, m) if keep]))
+    pred = O.BinaryExpr(O.BinaryExpr(O.Column(0, "k"), ">=", O.Literal("100")), "AND", O.BinaryExpr(O.Column(0, "k"), "<", O.Literal("700")))
+    L.golap_host_set_pipelining(pipelined)
+    try:
+        prof = {}
+        out = O.execute(O.GpuFilter(O.Batches(batches), pred), ctx, profile=prof)
+    finally:
+        L.golap_host_set_pipelining(0)
+    assert len(out) == len(exp)
+    for o, (k, v, f, fnull, s) in zip(out, exp):
+        assert o.schema.names == ["k", "v", "f", "s"] and o.num_rows == len(k)
+        assert o.column(0).null_count == 0 and np.array_equal(o.column(0).to_numpy(), k)
+        assert np.array_equal(o.column(1).to_numpy(), v)
+        got_f = o.column(2)
+        assert got_f.null_count == int(fnull.sum())
+        assert np.array_equal(np.array(got_f.is_null()), fnull) and np.array_equal(got_f.to_numpy(zero_copy_only=False)[~fnull], f[~fnull])
+        assert np.array_equal(o.column(3).to_numpy().view(np.uint64), np.array([hashes[x] for x in s], np.uint64))
+    up = sum(b.nbytes for b in batches if b.num_rows)
+    assert 0.9 * up < prof["h2d_bytes"] <= 1.01 * up + 65536, prof     # every buffer went up once, whichever way
 
 
 def test_utf8_hash_known_answers(ctx):
