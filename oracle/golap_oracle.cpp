@@ -14,15 +14,26 @@
 //   * launch params          : pinned by gpu-kernel-compiler/src/filter_kernel.rs:86-95.
 //   * aggregate identities   : pinned by gpu-kernel-compiler/src/aggregate_kernel.rs:138-143.
 //   * 8-byte widening layout : pinned by arrow-interop/src/record_batch_convert.rs:201-217.
-//   * hash values, partition ids, join row-id pairs, grouped sums:
+//   * hash values            : the reference's tests hold no vector, but join_kernels.cuh:26-34 names
+//                              its hash: "MurmurHash3 32-bit finalizer", a PUBLISHED algorithm (fmix32
+//                              of A. Appleby's MurmurHash3).  MurmurHash3_x86_32("", seed) == fmix32(seed),
+//                              so tests/test_oracle.py::test_hashes_against_an_independent_murmurhash3 pins
+//                              orc_hash_int32 / orc_hash_int64 / the first pass's partition ids against an
+//                              independent implementation (scikit-learn's port of the reference C++) and
+//                              the published empty-message vectors; the 64-bit fold is :36-41 verbatim.
+//   * partition ids beyond the first pass, join row-id pairs, grouped sums:
 //                              PARITY UNPINNED BY THE REFERENCE -- its tests hold no
 //                              vector for them, its GPU kernels are never launched and
 //                              its CPU join returns no rows (executor.rs:255-264).  The
 //                              reference cannot be built here (Rust + CUDA toolchains
 //                              absent; join_kernels.cuh needs <cuda_runtime.h>).  These
 //                              are pinned instead by hand-evaluated vectors of
-//                              join_kernels.cuh:26-41 committed in tests/golden/ and by an
-//                              independent numpy twin (tests/np_twin.py).
+//                              join_kernels.cuh:26-41 committed in tests/golden/, by an
+//                              independent numpy twin (tests/np_twin.py) and by independent
+//                              implementations of the same relational semantics: Apache Arrow C++
+//                              (Acero hash join / hash aggregate, pyarrow.compute) and pandas merge
+//                              (tests/test_oracle_vs_arrow.py: joins of all four types incl. composite
+//                              and NULL keys, filters with NULLs, grouped and ungrouped aggregates).
 //
 // Every function cites the reference file:line it follows (paths relative to
 // the reference root).

@@ -23,6 +23,35 @@ def test_hash_kats():
         assert (oracle.partition_id(h, 0), oracle.partition_id(h, 24)) == (p0, p24)
 
 
+def test_hashes_against_an_independent_murmurhash3():
+    """join_kernels.cuh:26-34 calls hash_int32 "MurmurHash3 32-bit finalizer": a PUBLISHED third-party algorithm (A. Appleby, MurmurHash3.cpp,
+    fmix32).  MurmurHash3_x86_32 of the EMPTY message with seed s is exactly fmix32(s) (no block, no tail, h1 ^= len is a no-op), so any
+    independent MurmurHash3_x86_32 pins the oracle's hash: here scikit-learn's Cython port of Appleby's reference code, plus the three
+    empty-message vectors that circulate with every MurmurHash3 test suite.  hash_int64 is then the reference's own fold,
+    hash_int32(lo ^ hi) (:36-41), and the partition id (hash >> shift) & 255 (:69)."""
+    sk = pytest.importorskip("sklearn.utils")
+    mm3 = lambda seed: int(sk.murmurhash3_32(b"", seed=int(seed), positive=True))
+    for seed, h in ((0, 0x00000000), (1, 0x514E28B7), (0xFFFFFFFF, 0x81F16F39)):          # published MurmurHash3_x86_32("", seed)
+        assert mm3(seed) == h and oracle.hash_int32(int(np.uint32(seed).astype(np.int32))) == h
+    rng = np.random.default_rng(2024)
+    k32 = np.concatenate([np.array([0, 1, 2, 42, 255, 256, 65535, 65536, 2**31 - 1, 2**31, 2**32 - 1], np.uint64),
+                          rng.integers(0, 2**32, 20000, dtype=np.uint64), np.arange(1 << 12, dtype=np.uint64) << np.uint64(20)])
+    exp = np.array([mm3(k) for k in k32], np.uint32)
+    # keys in [0, 2^32): the upper half is 0, hash_int64(k) = hash_int32(k)
+    assert np.array_equal(oracle.hash_int64_array(k32.astype(np.int64)), exp)
+    assert np.array_equal(T.hash_int64(k32.astype(np.int64)), exp)
+    for k, h in zip(k32[:200].tolist(), exp[:200].tolist()):
+        assert oracle.hash_int32(int(np.uint32(k).astype(np.int32))) == h
+    # full-range keys: the fold, then the same finalizer
+    k64 = np.concatenate([np.array([-1, -2, 2**63 - 1, -2**63, 0x0123456789ABCDEF, 2**32, 2**32 + 1], np.int64), rng.integers(-2**63, 2**63 - 1, 20000, dtype=np.int64)])
+    u = k64.view(np.uint64)
+    fold = (u ^ (u >> np.uint64(32))) & np.uint64(0xFFFFFFFF)
+    assert np.array_equal(oracle.hash_int64_array(k64), np.array([mm3(f) for f in fold], np.uint32))
+    # and the 256-way partition id of the first pass on top of it (:69)
+    _, _, off = oracle.radix_partition(k64)
+    assert np.array_equal(np.diff(off.astype(np.int64)), np.bincount(np.array([mm3(f) & 255 for f in fold]), minlength=256))
+
+
 def test_dense_partition_sizes():
     _, _, off = oracle.radix_partition(np.arange(1 << 20, dtype=np.int64))
     s = np.diff(off.astype(np.int64))
