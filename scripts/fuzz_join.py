@@ -44,12 +44,53 @@ def draw_keys(rng, n, kind, domain):
     raise ValueError(kind)
 
 
+GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix64(z):
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def surrogates(cols, valids, side_seed, keep):
+    """k_surrogate (csrc/golap_join.hip) restated: the 64-bit surrogate key of every row, narrowed by the GOLAP_GJ_HASH_BITS test knob"""
+    n = cols[0].size
+    null = np.zeros(n, bool)
+    for c, v in enumerate(valids if valids is not None else []):
+        if v is not None:
+            null |= v == 0
+    with np.errstate(over="ignore"):
+        if len(cols) == 1:
+            s = np.ascontiguousarray(cols[0], dtype=np.int64).view(np.uint64).copy()
+        else:
+            s = np.full(n, 0x243F6A8885A308D3, np.uint64)
+            for c, col in enumerate(cols):
+                s = _mix64(s ^ np.ascontiguousarray(col, dtype=np.int64).view(np.uint64)) + GOLDEN * np.uint64(c + 1)
+        s_null = _mix64(np.uint64(side_seed) + np.arange(n, dtype=np.uint64) * GOLDEN)
+    return np.where(null, s_null, s) & np.uint64(keep)
+
+
+def false_pairs(bc, pc, bv, pv, bits, true_inner):
+    """candidate pairs of the surrogate join that the real columns refute: what k_gj_verify will find (<= 64 are repaired, more set the
+    count word to 2^64 - 1, include/golap.h)"""
+    keep = (1 << bits) - 1
+    sb = surrogates(bc, bv, 0x6A09E667F3BCC908, keep)
+    sp = surrogates(pc, pv, 0xBB67AE8584CAA73B, keep)
+    ub, cb = np.unique(sb, return_counts=True)
+    up, cp = np.unique(sp, return_counts=True)
+    _, ib, ip = np.intersect1d(ub, up, assume_unique=True, return_indices=True)
+    return int((cb[ib].astype(np.int64) * cp[ip].astype(np.int64)).sum()) - int(true_inner)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    torch.cuda.set_device(0)
-    ctx = Context(profiling=False, max_gpu_memory=0)
+    dry = os.environ.get("FUZZ_DRY") == "1"           # CPU side only: the recipes and their false-pair counts, no device
+    if not dry:
+        torch.cuda.set_device(0)
+        ctx = Context(profiling=False, max_gpu_memory=0)
     t_end = time.time() + budget
     rnd = 0
     while time.time() < t_end:
@@ -108,13 +149,35 @@ def main():
                 mk = lambda n: [None if rng.random() < 0.3 else (rng.random(n) > 0.15).astype(np.uint8) for _ in range(ncols)]
                 bv, pv = mk(nb), mk(npr)
             exp, me = oracle.hash_join_multi(bc, pc, jt, bv, pv)
+            # The knob narrows the surrogates so that the verify / repair route runs.  How many false pairs that makes depends on the KEYS (one
+            # column: the surrogate is the key itself, so structured keys collide in bulk): counted here, the buffer sized for them, and
+            # beyond 64 the library's answer must be the impossible count 2^64 - 1 instead of a repaired list.
+            n_false, general = 0, ncols > 1 or any(v is not None for v in (bv or []) + (pv or []))
+            if "GOLAP_GJ_HASH_BITS" in env and general and nb and npr:
+                n_false = false_pairs(bc, pc, bv, pv, int(env["GOLAP_GJ_HASH_BITS"]), oracle.hash_join_multi(bc, pc, 0, bv, pv)[1])
+                recipe += f" false_pairs={n_false}"
+                if n_false > 5_000_000:
+                    continue
+            if dry:
+                print("dry  " + recipe + f" matches={me}", flush=True)
+                continue
             for k in HOOKS:
                 ctx.debug_set(k, env.get(k))
             tv = lambda v: None if v is None else [None if x is None else dt(x) for x in v]
-            pairs, cnt = ctx.join([dt(c) for c in bc], [dt(c) for c in pc], max_pairs=max(1, me + 72), strategy=strategy, join_type=jt,
+            pairs, cnt = ctx.join([dt(c) for c in bc], [dt(c) for c in pc], max_pairs=max(1, me + n_false + 72), strategy=strategy, join_type=jt,
                                   build_valid=tv(bv), probe_valid=tv(pv))
+            if n_false > 64:
+                torch.cuda.synchronize()
+                ok = int(cnt.item()) == -1                       # 2^64 - 1 read as int64
+                print(("ok   " if ok else "FAIL ") + recipe + f" matches={me} (more false pairs than can be repaired: the impossible count)", flush=True)
+                if not ok:
+                    sys.exit(1)
+                continue
         else:
             exp, me = oracle.hash_join_outer(b, p, jt)
+            if dry:
+                print("dry  " + recipe + f" matches={me}", flush=True)
+                continue
             for k in HOOKS:
                 ctx.debug_set(k, env.get(k))
             pairs, cnt = ctx.join(dt(np.ascontiguousarray(b, dtype=np.int64)), dt(np.ascontiguousarray(p, dtype=np.int64)), max_pairs=max(1, me + 8),
