@@ -789,6 +789,25 @@ def test_surrogate_collisions_are_repaired(ctx, jt):
     _multi_check(ctx, b, p, jt, N.JOIN_BROADCAST_HASH, knobs={"GOLAP_GJ_HASH_BITS": "20"})
 
 
+@pytest.mark.parametrize("strategy", STRATS)
+def test_more_false_pairs_than_can_be_repaired_give_the_impossible_count(ctx, strategy):
+    """include/golap.h: when the verification of a surrogate-key join finds more false pairs than its repair list holds (64; with 64-bit
+    surrogates that has probability < 1e-60), the count word is set to 2^64 - 1 -- a count no join can have -- instead of a list that
+    silently keeps false pairs.  The knob narrows the surrogates to 8 bits: nothing really matches, ~35 000 candidate pairs do."""
+    rng = np.random.default_rng(29)
+    nb, npr = 3000, 3000
+    b = [np.arange(nb) * 2, rng.integers(0, 5, nb)]
+    p = [np.arange(npr) * 2 + 1, rng.integers(0, 5, npr)]
+    tb = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.int64)).cuda() for c in b]
+    tp = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.int64)).cuda() for c in p]
+    with ctx.knobs(GOLAP_GJ_HASH_BITS="8"):
+        pairs, cnt = ctx.join(tb, tp, max_pairs=200_000, strategy=strategy, join_type=N.JT_INNER)
+        torch.cuda.synchronize()
+    assert int(cnt.item()) == -1                                          # 0xFFFFFFFFFFFFFFFF read as int64
+    pairs, cnt = ctx.join(tb, tp, max_pairs=200_000, strategy=strategy, join_type=N.JT_INNER)   # the knob gone: no candidate, no pair
+    assert int(cnt.item()) == 0
+
+
 @pytest.mark.parametrize("jt", [N.JT_INNER, N.JT_FULL])
 def test_composite_key_join_four_full_range_columns(ctx, jt):
     """four Int64 key columns whose values span all of int64 (hash-like ids; a mixed-radix packing would need ~250 bits), NULLs in two of
