@@ -985,6 +985,9 @@ int32_t Exec::hash_join(std::vector<RecordBatch>& left, std::vector<RecordBatch>
             }
             H_TRY(golap_join(ctx, pick_strategy(nb), &jp, nullptr));   // JoinKernel::choose_strategy, join_kernel.rs:71-77, refined above
             H_TRY(read_u64(dcnt->ptr, &m));
+            // golap.h (golap_join_params): 2^64 - 1 is no count -- the verification of a surrogate-key join met more false pairs than it
+            // can repair (probability < 1e-60 with 64-bit surrogates; the test hook that narrows them gets here)
+            if (m == ~0ull) return herr(GOLAP_ERR_UNSUPPORTED, "GpuHashJoin: more colliding surrogate keys than the pair verification can repair");
             if (m <= cap) break;
             cap = m;   // too small: retry with the exact size (the first buffer goes back to the pool at the end of the operator)
         }

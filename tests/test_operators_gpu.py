@@ -157,6 +157,21 @@ def test_group_by_over_a_join_with_either_strategy(ctx):
             assert out.column(3)[g].as_py() == o_amt[keep][seg == g].min() and out.column(4)[g].as_py() == o_amt[keep][seg == g].max()
 
 
+def test_hash_join_reports_unrepairable_surrogate_collisions(ctx):
+    """A composite-key join whose surrogate keys collide more often than the pair verification can repair (only reachable with the test
+    hook that narrows them to a few bits) is an error of the operator, not a result: golap_join's count word reads 2^64 - 1 (golap.h)."""
+    rng = np.random.default_rng(3)
+    n = 3000
+    left = rb(a=np.arange(n, dtype=np.int64) * 2, b=rng.integers(0, 5, n).astype(np.int64))
+    right = rb(c=np.arange(n, dtype=np.int64) * 2 + 1, d=rng.integers(0, 5, n).astype(np.int64))
+    plan = lambda: O.GpuHashJoin(O.Batches([left]), O.Batches([right]), [O.Column(0, "a"), O.Column(1, "b")], [O.Column(0, "c"), O.Column(1, "d")])
+    with ctx.knobs(GOLAP_GJ_HASH_BITS="8"):
+        with pytest.raises(O.OperatorError, match="colliding surrogate keys"):
+            O.execute(plan(), ctx)
+    out = O.execute(plan(), ctx)                                     # without the hook: nothing matches, an empty batch with the joined schema
+    assert len(out) == 1 and out[0].num_rows == 0 and out[0].schema.names == ["a", "b", "c", "d"]
+
+
 @pytest.mark.parametrize("jt,code", [("Left", 1), ("Right", 2), ("Full", 3)])
 def test_outer_joins_produce_arrow_nulls(ctx, jt, code):
     """JoinType::{Left,Right,Full} (logical_plan.rs:53-58): the missing side's columns are Arrow nulls."""
