@@ -76,6 +76,22 @@ def test_composite_and_null_keys_match_acero(nk, jt):
     assert np.array_equal(canonical(got), arrow_join(bcols, pcols, jt, bvalid, pvalid))
 
 
+@pytest.mark.parametrize("jt", [0, 1, 2, 3])
+def test_join_edge_cases_match_acero(jt):
+    """empty sides, one row, every key NULL on one side, every row the same key (a full cross product of the two groups)"""
+    e = np.empty(0, np.int64)
+    one = np.array([7], np.int64)
+    same_b, same_p = np.full(37, 5, np.int64), np.full(53, 5, np.int64)
+    cases = [([e], [e], None, None), ([e], [one], None, None), ([one], [e], None, None), ([one], [one], None, None), ([one], [one + 1], None, None),
+             ([same_b], [same_p], None, None),
+             ([same_b], [same_p], [np.zeros(37, np.uint8)], None),                    # every build key NULL: nothing matches
+             ([same_b, same_b], [same_p, same_p], [None, (np.arange(37) % 2).astype(np.uint8)], [(np.arange(53) % 3 > 0).astype(np.uint8), None])]
+    for bc, pc_, bv, pv in cases:
+        got = oracle.hash_join_multi(bc, pc_, jt, bv, pv)
+        got = got[0] if isinstance(got, tuple) else got
+        assert np.array_equal(canonical(got), arrow_join(bc, pc_, jt, bv, pv)), (jt, [len(c) for c in bc], [len(c) for c in pc_])
+
+
 @pytest.mark.parametrize("op,fn", [("=", "equal"), ("!=", "not_equal"), ("<", "less"), ("<=", "less_equal"), (">", "greater"), (">=", "greater_equal")])
 def test_filter_masks_match_arrow_compute(op, fn):
     """eval_filter_mask (executor.rs:443-476) against pyarrow.compute; with a validity array: Arrow's Kleene-free comparison yields NULL for a
